@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json metric on MI355X: GB/s of haystack scanned (+ rows/s) by the DFA table-walk
+hot path on the 10M x 256-char synthetic batch.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--rows R] [--scaling weak|strong]
+
+One "step" = one pass of the hot path over the whole device-resident batch (one kernel launch per GPU; for
+N > 1 followed by the RCCL gather of the result bitmap to rank 0).  N > 1 is launched by the driver with
+torch.distributed.run, one rank per GPU; rows are sharded by contiguous row blocks, no data-path collective
+other than the result gather.  Rank 0 prints ONE JSON line.
+
+  value       whole-job algorithmic GB/s (input bytes + result bytes, per step, all GPUs) over
+              the barrier-bracketed wall time of exactly K steps (max over ranks), inputs resident in HBM
+  roofline    the scan kernel alone: algorithmic bytes per launch / mean launch duration from HIP events
+              recorded on the launch stream inside the timed region; peak = 8 TB/s HBM3E
+  cpu_baseline  the CPU oracle (oracle/needle_walk.c, a port of the reference's generated loops -- NOT the JVM
+              bytecode path: no JDK on the box) on a bounded sample of the same rows, all host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_pattern(workload):
+    from needle_amd import workload as W
+    from needle_amd.pattern import DFACompiler, LEFTMOST_LONGEST  # noqa: F401
+    if workload == "c2":
+        return DFACompiler.compile("[0-9]+", "DigitPlus"), "'[0-9]+' containedIn()", None
+    if workload == "c3":
+        words = W.keywords(1000)
+        return DFACompiler.compile("|".join(words), "Keywords1k"), "union-of-1k-keywords find()", words
+    if workload == "c5":
+        return DFACompiler.compile(W.script_regex(), "ScriptRuns"), "BMP char-class regex find() over UTF-16", None
+    raise SystemExit("unknown workload " + workload)
+
+
+def make_rows(workload, words, row0, n_rows, device):
+    """Shard [row0, row0 + n_rows) of the synthetic batch, generated on the GPU in slabs."""
+    import torch
+    from needle_amd import workload as W
+    dtype = torch.int16 if workload == "c5" else torch.uint8
+    out = torch.empty((n_rows, 256), dtype=dtype, device=device)
+    slab = 1 << 19
+    for s in range(0, n_rows, slab):
+        n = min(slab, n_rows - s)
+        if workload == "c2":
+            out[s:s + n] = W.digits_batch(torch, row0 + s, n, 256, device=device)
+        elif workload == "c3":
+            out[s:s + n] = W.keyword_batch(torch, words, row0 + s, n, 256, device=device)
+        else:
+            out[s:s + n] = W.script_batch(torch, row0 + s, n, 256, device=device)
+    return out
+
+
+def cpu_baseline(workload, pattern, rows_dev, budget_s=12.0):
+    """Times the CPU oracle on a bounded sample of the same rows (rank 0, N = 1 only)."""
+    import numpy as np
+    from oracle.walker import Dfa, OraclePattern
+    t = pattern.tables()
+    d = {k: Dfa(t["class_map"], t["stride"], v["table"], v["accepting"], v["max_char"]) for k, v in t["dfas"].items()}
+    o = OraclePattern(d["matches"], d["contained_in"], d["forwards"], d["backwards"], t["fixed_len"], -1)
+    cores = os.cpu_count() or 1
+    n = min(rows_dev.shape[0], 1 << 20)
+    host = rows_dev[:n].cpu().numpy()
+    if host.dtype == np.int16:
+        host = host.view(np.uint16)
+    fn = o.batch_contained_in if workload == "c2" else o.batch_find
+    fn(host[:4096], threads=cores)
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        fn(host, threads=cores)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or passes >= 64:
+            break
+    rows_s = passes * n / el
+    in_bytes = host.shape[1] * host.dtype.itemsize
+    return {"value": rows_s * in_bytes / 1e9, "unit": "GB/s", "rows_per_s": rows_s, "cores": cores, "kind": "port",
+            "sample": "%d passes over the first %d rows of the same batch (%s), OpenMP static over rows; "
+                      "CPU restatement of the generated loops, not the JVM bytecode path" % (passes, n, workload)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (weak) or in total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from needle_amd.sharding import shard_range, gather_bitmap
+    pattern, what, words = make_pattern(args.workload)
+    total_rows = args.rows * world if args.scaling == "weak" else args.rows
+    row0, n_rows = shard_range(total_rows, world, rank)
+    rows = make_rows(args.workload, words, row0, n_rows, dev)
+    cw = rows.element_size()
+    op = pattern.contained_in_batch if args.workload == "c2" else pattern.find_batch
+    is_find = args.workload != "c2"
+
+    def step():
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        res = op(rows)
+        ev1.record()
+        words_ = res[0] if is_find else res
+        if world > 1:
+            gather_bitmap(words_, total_rows, world, rank)
+        return res, (ev0, ev1)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res, _ev = step()
+    fence()
+    t0 = time.perf_counter()
+    events = []
+    for _ in range(args.steps):
+        res, ev = step()
+        events.append(ev)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+
+    # algorithmic bytes: L*w input bytes + result bytes (1 bit/row; find adds 2 x int32/row)
+    per_row = 256 * cw + (8 if is_find else 0)
+    bytes_gpu = n_rows * per_row + ((n_rows + 63) // 64) * 8
+    bytes_job = total_rows * per_row + ((total_rows + 63) // 64) * 8
+    ms_per_step = elapsed / args.steps * 1e3
+    matched = None
+    if rank == 0:
+        from needle_amd.pattern import unpack_bitmap
+        w0 = res[0] if is_find else res
+        matched = int(unpack_bitmap(w0, n_rows).sum())
+    out = {
+        "metric": "GB/s haystack scanned (10M x 256-char batch per GPU, DFA table walk)",
+        "value": bytes_job / (elapsed / args.steps) / 1e9,
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "u8" if cw == 1 else "u16",
+        "data": "synthetic",
+        "rows_per_s": total_rows / (elapsed / args.steps),
+        "matches_per_s": None if matched is None else matched * world / (elapsed / args.steps),
+        "config": {"workload": "%s: %s over %d x 256 %s rows per GPU" % (args.workload, what, n_rows, "UTF-16" if cw == 2 else "ASCII"),
+                   "rows_total": total_rows, "row_chars": 256, "char_bytes": cw, "parallelism": "row-shard x%d" % world,
+                   "result": "bitmap" + ("+start/end int32" if is_find else ""), "pattern": pattern.info()},
+        "roofline": {"bound": "hbm", "achieved": bytes_gpu / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_gpu / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "needle::scan_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_gpu},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, pattern, rows)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

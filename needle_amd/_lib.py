@@ -1,0 +1,84 @@
+"""ctypes binding of libneedle_hip.so (include/needle_hip.h).  Fails loudly if the library is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libneedle_hip.so")
+
+NEEDLE_OK, ERR_INVALID, ERR_SYNTAX, ERR_COMPILE, ERR_UNSUPPORTED, ERR_DEVICE = 0, 1, 2, 3, 4, 5
+
+EXPORTS = [
+    "needle_version", "needle_last_error", "needle_device_count", "needle_compile", "needle_pattern_from_tables",
+    "needle_pattern_destroy", "needle_pattern_get_info", "needle_pattern_get_class_map", "needle_pattern_get_table",
+    "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_matches_host",
+    "needle_contained_in_host", "needle_find_host", "needle_matcher_create", "needle_matcher_destroy",
+    "needle_matcher_matches", "needle_matcher_contained_in", "needle_matcher_find", "needle_matcher_find_range",
+    "needle_matcher_start", "needle_matcher_end",
+]
+
+
+class DfaDesc(ctypes.Structure):
+    _fields_ = [("n_states", ctypes.c_int32), ("max_char", ctypes.c_int32), ("table", ctypes.c_void_p),
+                ("table_string", ctypes.c_char_p), ("accepting", ctypes.c_void_p)]
+
+
+class TableDesc(ctypes.Structure):
+    _fields_ = [("class_map", ctypes.c_void_p), ("stride", ctypes.c_int32), ("matches", DfaDesc),
+                ("contained_in", DfaDesc), ("forwards", DfaDesc), ("backwards", DfaDesc), ("fixed_len", ctypes.c_int32)]
+
+
+class BatchView(ctypes.Structure):
+    _fields_ = [("rows", ctypes.c_void_p), ("char_width", ctypes.c_uint32), ("n_rows", ctypes.c_uint64),
+                ("row_stride", ctypes.c_uint64), ("row_len", ctypes.c_uint32), ("lengths", ctypes.c_void_p)]
+
+
+class PatternInfo(ctypes.Structure):
+    _fields_ = [("stride", ctypes.c_int32), ("n_states", ctypes.c_int32 * 4), ("max_char", ctypes.c_int32 * 4),
+                ("fixed_len", ctypes.c_int32), ("min_len", ctypes.c_int32), ("max_len", ctypes.c_int32),
+                ("kernel_mode", ctypes.c_int32 * 4)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Import torch first when both are used so that one HIP runtime (torch's) serves both."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libneedle_hip.so is not built (%s). Run `python -m needle_amd.build` "
+                          "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    P, I, VP = ctypes.POINTER, ctypes.c_int, ctypes.c_void_p
+    L.needle_version.restype = ctypes.c_char_p
+    L.needle_last_error.restype = ctypes.c_char_p
+    L.needle_device_count.restype = I
+    L.needle_compile.argtypes = [VP, ctypes.c_size_t, I, P(VP)]
+    L.needle_pattern_from_tables.argtypes = [P(TableDesc), P(VP)]
+    L.needle_pattern_destroy.argtypes = [VP]
+    L.needle_pattern_destroy.restype = None
+    L.needle_pattern_get_info.argtypes = [VP, P(PatternInfo)]
+    L.needle_pattern_get_class_map.argtypes = [VP, VP]
+    L.needle_pattern_get_table.argtypes = [VP, I, VP, VP]
+    for n in ("needle_matches_dev", "needle_contained_in_dev"):
+        getattr(L, n).argtypes = [VP, P(BatchView), VP, VP]
+    L.needle_find_dev.argtypes = [VP, P(BatchView), VP, VP, VP, VP]
+    for n in ("needle_matches_host", "needle_contained_in_host"):
+        getattr(L, n).argtypes = [VP, P(BatchView), VP]
+    L.needle_find_host.argtypes = [VP, P(BatchView), VP, VP, VP]
+    L.needle_matcher_create.argtypes = [VP, VP, ctypes.c_size_t, P(VP)]
+    L.needle_matcher_destroy.argtypes = [VP]
+    L.needle_matcher_destroy.restype = None
+    for n in ("needle_matcher_matches", "needle_matcher_contained_in", "needle_matcher_find"):
+        getattr(L, n).argtypes = [VP, P(I)]
+    L.needle_matcher_find_range.argtypes = [VP, I, I, P(I)]
+    L.needle_matcher_start.argtypes = [VP]
+    L.needle_matcher_end.argtypes = [VP]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().needle_last_error().decode("utf-8", "replace")

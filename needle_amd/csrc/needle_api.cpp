@@ -1,0 +1,438 @@
+// C ABI of libneedle_hip.so (include/needle_hip.h): pattern objects, per-device program cache, batch entry
+// points, and the single-haystack Matcher mirror.  No CPU matching path exists in this library.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/needle_hip.h"
+#include "needle_device.h"
+#include "needle_lower.h"
+#include "needle_regex.h"
+
+namespace needle {
+hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
+int waves_for_lds_bytes(uint32_t prog_lds_bytes);
+} // namespace needle
+
+using namespace needle;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what) {
+    return fail(NEEDLE_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+struct DevProgram {
+    Program prog;
+    uint8_t *d_blob = nullptr;
+};
+
+struct needle_pattern {
+    RefTables t;
+    std::mutex mu;
+    // (device, which, char_width, global_walk) -> program resident in that device's HBM
+    std::map<std::tuple<int, int, int, int>, DevProgram> cache;
+    std::map<int, int> cus; // device -> CU count
+    ~needle_pattern() {
+        for (auto &kv : cache)
+            if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
+    }
+};
+
+static constexpr size_t kMaxProgLds = 160u * 1024u - 4u * kTileBytes; // smallest workgroup shape: 4 waves
+
+static int get_program(needle_pattern *p, int which, int cw, bool global_walk, const DevProgram **out, int *n_cus) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->cus.count(dev)) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        p->cus[dev] = prop.multiProcessorCount;
+    }
+    if (n_cus) *n_cus = p->cus[dev];
+    auto key = std::make_tuple(dev, which, cw, global_walk ? 1 : 0);
+    auto it = p->cache.find(key);
+    if (it == p->cache.end()) {
+        DevProgram dp;
+        dp.prog = lower(p->t, (Which)which, cw, kMaxProgLds, global_walk);
+        HIP_TRY(hipMalloc((void **)&dp.d_blob, dp.prog.blob.size()));
+        HIP_TRY(hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice));
+        it = p->cache.emplace(key, std::move(dp)).first;
+    }
+    *out = &it->second;
+    return NEEDLE_OK;
+}
+
+static int check_view(const needle_batch_view *v, bool device) {
+    if (!v) return fail(NEEDLE_ERR_INVALID, "batch view is NULL");
+    if (v->char_width != 1 && v->char_width != 2) return fail(NEEDLE_ERR_INVALID, "char_width must be 1 or 2");
+    if (v->n_rows && !v->rows) return fail(NEEDLE_ERR_INVALID, "rows is NULL");
+    if (v->row_len > v->row_stride) return fail(NEEDLE_ERR_INVALID, "row_len > row_stride");
+    if (device) {
+        if ((v->row_stride * v->char_width) % 16 != 0)
+            return fail(NEEDLE_ERR_INVALID, "row_stride * char_width must be a multiple of 16 bytes for device batches");
+        if (((uintptr_t)v->rows) % 16 != 0) return fail(NEEDLE_ERR_INVALID, "rows must be 16-byte aligned");
+        if (v->n_rows && v->row_stride == 0) return fail(NEEDLE_ERR_INVALID, "row_stride is 0");
+    }
+    return NEEDLE_OK;
+}
+
+static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
+                   int32_t *d_end, void *stream) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, true);
+    if (rc) return rc;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_bitmap) return fail(NEEDLE_ERR_INVALID, "bitmap is NULL");
+    if (op == OP_FIND && (!d_start || !d_end)) return fail(NEEDLE_ERR_INVALID, "start/end is NULL");
+
+    const int which = op == OP_MATCHES ? W_MATCHES : op == OP_CONTAINED_IN ? W_CONTAINED_IN : W_FORWARDS;
+    const DevProgram *fp = nullptr, *bp = nullptr;
+    int n_cus = 0;
+    rc = get_program(p, which, (int)v->char_width, false, &fp, &n_cus);
+    if (rc) return rc;
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = (const uint8_t *)v->rows;
+    a.n_rows = v->n_rows;
+    a.stride_bytes = v->row_stride * v->char_width;
+    a.total_bytes = a.n_rows * a.stride_bytes;
+    a.row_len = v->row_len;
+    a.lengths = v->lengths;
+    a.prog = fp->d_blob;
+    a.hdr = fp->prog.hdr;
+    a.fixed_len = -1;
+    if (op == OP_FIND) {
+        a.fixed_len = p->t.fixed_len;
+        if (a.fixed_len < 0) {
+            rc = get_program(p, W_BACKWARDS, (int)v->char_width, true, &bp, nullptr);
+            if (rc) return rc;
+            a.bprog = bp->d_blob;
+            a.bhdr = bp->prog.hdr;
+        }
+    }
+    a.bitmap = d_bitmap;
+    a.start = d_start;
+    a.end = d_end;
+    HIP_TRY(launch_scan(op, (int)v->char_width, a, n_cus, (hipStream_t)stream));
+    return NEEDLE_OK;
+}
+
+// Host-buffer convenience: pad rows to a 16-byte stride, upload, run, download.
+static int run_host(const needle_pattern *p, int op, const needle_batch_view *v, uint64_t *bitmap, int32_t *start,
+                    int32_t *end) {
+    int rc = check_view(v, false);
+    if (rc) return rc;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!bitmap) return fail(NEEDLE_ERR_INVALID, "bitmap is NULL");
+    const size_t cw = v->char_width;
+    const uint64_t src_stride = v->row_stride * cw;
+    uint64_t dst_stride = (src_stride + 15) & ~(uint64_t)15;
+    if (dst_stride == 0) dst_stride = 16;
+    const size_t words = (v->n_rows + 63) / 64;
+    uint8_t *d_rows = nullptr;
+    uint32_t *d_len = nullptr;
+    uint64_t *d_bm = nullptr;
+    int32_t *d_s = nullptr, *d_e = nullptr;
+    auto cleanup = [&]() {
+        if (d_rows) (void)hipFree(d_rows);
+        if (d_len) (void)hipFree(d_len);
+        if (d_bm) (void)hipFree(d_bm);
+        if (d_s) (void)hipFree(d_s);
+        if (d_e) (void)hipFree(d_e);
+    };
+#define HIP_TRY_C(expr)                                    \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) {                            \
+            cleanup();                                     \
+            return hip_fail(_e, #expr);                    \
+        }                                                  \
+    } while (0)
+    HIP_TRY_C(hipMalloc((void **)&d_rows, v->n_rows * dst_stride));
+    if (dst_stride == src_stride) {
+        HIP_TRY_C(hipMemcpy(d_rows, v->rows, v->n_rows * src_stride, hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY_C(hipMemset(d_rows, 0, v->n_rows * dst_stride));
+        if (src_stride)
+            HIP_TRY_C(hipMemcpy2D(d_rows, dst_stride, v->rows, src_stride, src_stride, v->n_rows, hipMemcpyHostToDevice));
+    }
+    if (v->lengths) {
+        HIP_TRY_C(hipMalloc((void **)&d_len, v->n_rows * 4));
+        HIP_TRY_C(hipMemcpy(d_len, v->lengths, v->n_rows * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY_C(hipMalloc((void **)&d_bm, words * 8));
+    if (op == OP_FIND) {
+        if (!start || !end) {
+            cleanup();
+            return fail(NEEDLE_ERR_INVALID, "start/end is NULL");
+        }
+        HIP_TRY_C(hipMalloc((void **)&d_s, v->n_rows * 4));
+        HIP_TRY_C(hipMalloc((void **)&d_e, v->n_rows * 4));
+    }
+    needle_batch_view dv = *v;
+    dv.rows = d_rows;
+    dv.lengths = d_len;
+    dv.row_stride = dst_stride / cw;
+    rc = run_dev(p, op, &dv, d_bm, d_s, d_e, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    HIP_TRY_C(hipDeviceSynchronize());
+    HIP_TRY_C(hipMemcpy(bitmap, d_bm, words * 8, hipMemcpyDeviceToHost));
+    if (op == OP_FIND) {
+        HIP_TRY_C(hipMemcpy(start, d_s, v->n_rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY_C(hipMemcpy(end, d_e, v->n_rows * 4, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+    return NEEDLE_OK;
+#undef HIP_TRY_C
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *needle_version(void) { return "needle_hip 0.1 (gfx950)"; }
+const char *needle_last_error(void) { return g_err.c_str(); }
+
+int needle_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int needle_compile(const uint16_t *regex, size_t n, int flags, needle_pattern **out) {
+    if (!out) return fail(NEEDLE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!regex && n) return fail(NEEDLE_ERR_INVALID, "regex is NULL"); // Objects.requireNonNull, RegexParser.java:87
+    if (flags & ~NEEDLE_ALL_FLAGS) return fail(NEEDLE_ERR_INVALID, "unknown flag bits"); // CompilerOptions.java:9-16
+    needle_pattern *p = new needle_pattern();
+    std::string err;
+    int rc = compile_regex(std::u16string((const char16_t *)regex, n), flags, p->t, err);
+    if (rc != NEEDLE_OK) {
+        delete p;
+        return fail(rc, err);
+    }
+    if (!validate_tables(p->t, err)) {
+        delete p;
+        return fail(NEEDLE_ERR_COMPILE, err);
+    }
+    *out = p;
+    return NEEDLE_OK;
+}
+
+static int take_dfa(const needle_dfa_desc &d, int stride, RefDfa &o, std::string &err) {
+    if (d.n_states < 1 || d.n_states > 16383) { err = "n_states out of range (1..16383)"; return NEEDLE_ERR_COMPILE; }
+    if (!d.accepting) { err = "accepting is NULL"; return NEEDLE_ERR_INVALID; }
+    o.n_states = d.n_states;
+    o.max_char = d.max_char;
+    o.accepting.resize(d.n_states);
+    for (int i = 0; i < d.n_states; ++i) o.accepting[i] = d.accepting[i] ? 1 : 0;
+    if (d.table) {
+        o.table.assign(d.table, d.table + (size_t)d.n_states * stride);
+    } else if (d.table_string) {
+        if (!decode_table_string(d.table_string, d.n_states, stride, o.table, err)) return NEEDLE_ERR_INVALID;
+    } else {
+        err = "neither table nor table_string given";
+        return NEEDLE_ERR_INVALID;
+    }
+    return NEEDLE_OK;
+}
+
+int needle_pattern_from_tables(const needle_table_desc *desc, needle_pattern **out) {
+    if (!out) return fail(NEEDLE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!desc || !desc->class_map) return fail(NEEDLE_ERR_INVALID, "desc / class_map is NULL");
+    if (desc->stride < 1 || desc->stride > 255) return fail(NEEDLE_ERR_INVALID, "stride out of range");
+    needle_pattern *p = new needle_pattern();
+    p->t.class_map.assign(desc->class_map, desc->class_map + 65536);
+    p->t.stride = desc->stride;
+    p->t.fixed_len = desc->fixed_len < 0 ? -1 : desc->fixed_len;
+    const needle_dfa_desc *ds[4] = {&desc->matches, &desc->contained_in, &desc->forwards, &desc->backwards};
+    std::string err;
+    for (int w = 0; w < 4; ++w) {
+        int rc = take_dfa(*ds[w], desc->stride, p->t.dfa[w], err);
+        if (rc) {
+            delete p;
+            return fail(rc, err);
+        }
+    }
+    if (!validate_tables(p->t, err)) {
+        delete p;
+        return fail(NEEDLE_ERR_INVALID, err);
+    }
+    *out = p;
+    return NEEDLE_OK;
+}
+
+void needle_pattern_destroy(needle_pattern *p) { delete p; }
+
+int needle_pattern_get_info(const needle_pattern *p, needle_pattern_info *o) {
+    if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    memset(o, 0, sizeof(*o));
+    o->stride = p->t.stride;
+    o->fixed_len = p->t.fixed_len;
+    o->min_len = p->t.min_len;
+    o->max_len = p->t.max_len;
+    for (int w = 0; w < 4; ++w) {
+        o->n_states[w] = p->t.dfa[w].n_states;
+        o->max_char[w] = p->t.dfa[w].max_char;
+        o->kernel_mode[w] = (int)lower(p->t, (Which)w, 1, kMaxProgLds, false).hdr.mode;
+    }
+    return NEEDLE_OK;
+}
+
+int needle_pattern_get_class_map(const needle_pattern *p, uint8_t *cm) {
+    if (!p || !cm) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    memcpy(cm, p->t.class_map.data(), 65536);
+    return NEEDLE_OK;
+}
+
+int needle_pattern_get_table(const needle_pattern *p, int which, int16_t *table, uint8_t *accepting) {
+    if (!p || which < 0 || which > 3) return fail(NEEDLE_ERR_INVALID, "bad argument");
+    const RefDfa &d = p->t.dfa[which];
+    if (table) memcpy(table, d.table.data(), d.table.size() * 2);
+    if (accepting) memcpy(accepting, d.accepting.data(), d.accepting.size());
+    return NEEDLE_OK;
+}
+
+int needle_matches_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, void *s) {
+    return run_dev(p, OP_MATCHES, v, bm, nullptr, nullptr, s);
+}
+int needle_contained_in_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, void *s) {
+    return run_dev(p, OP_CONTAINED_IN, v, bm, nullptr, nullptr, s);
+}
+int needle_find_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, int32_t *st, int32_t *en, void *s) {
+    return run_dev(p, OP_FIND, v, bm, st, en, s);
+}
+int needle_matches_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm) {
+    return run_host(p, OP_MATCHES, v, bm, nullptr, nullptr);
+}
+int needle_contained_in_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm) {
+    return run_host(p, OP_CONTAINED_IN, v, bm, nullptr, nullptr);
+}
+int needle_find_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, int32_t *st, int32_t *en) {
+    return run_host(p, OP_FIND, v, bm, st, en);
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Matcher mirror: fields as the generated class declares them (DFAClassBuilder.addFields :688-699); the
+// constructor leaves them at the JVM default 0 (the generated <init> only stores string and length).
+struct needle_matcher {
+    const needle_pattern *p;
+    std::vector<uint16_t> s;
+    int next_start = 0, start = 0, end = 0;
+};
+
+static int one_row(const needle_matcher *m, int op, int from, int *matched, int *st, int *en) {
+    const size_t n = m->s.size() - (size_t)from;
+    needle_batch_view v;
+    memset(&v, 0, sizeof(v));
+    v.rows = n ? (const void *)(m->s.data() + from) : (const void *)&v; // never read when n == 0
+    v.char_width = 2;
+    v.n_rows = 1;
+    v.row_stride = n;
+    v.row_len = (uint32_t)n;
+    uint64_t bm = 0;
+    int32_t s32 = -1, e32 = -1;
+    int rc = run_host(m->p, op, &v, &bm, &s32, &e32);
+    if (rc) return rc;
+    *matched = (int)(bm & 1);
+    if (st) *st = s32;
+    if (en) *en = e32;
+    return NEEDLE_OK;
+}
+
+extern "C" {
+
+int needle_matcher_create(const needle_pattern *p, const uint16_t *s, size_t n, needle_matcher **out) {
+    if (!p || !out || (!s && n)) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    needle_matcher *m = new needle_matcher();
+    m->p = p;
+    m->s.assign(s, s + n);
+    *out = m;
+    return NEEDLE_OK;
+}
+
+void needle_matcher_destroy(needle_matcher *m) { delete m; }
+
+int needle_matcher_matches(needle_matcher *m, int *r) {
+    if (!m || !r) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    return one_row(m, OP_MATCHES, 0, r, nullptr, nullptr);
+}
+
+int needle_matcher_contained_in(needle_matcher *m, int *r) {
+    if (!m || !r) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    return one_row(m, OP_CONTAINED_IN, 0, r, nullptr, nullptr);
+}
+
+// find(FROM, TO): DFAClassBuilder.createFindMethodInternal :625-659.  TO is ignored by the generated
+// indexForwards (its slot is overwritten with this.length, DFAMethodComponents.java:19-21).
+int needle_matcher_find_range(needle_matcher *m, int from, int to, int *r) {
+    (void)to;
+    if (!m || !r) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    *r = 0;
+    if (m->next_start == -1) return NEEDLE_OK; // :629-630
+    const int length = (int)m->s.size();
+    const RefDfa &fw = m->p->t.dfa[W_FORWARDS];
+    int index;
+    int st = 0;
+    bool have_start = false;
+    if (from < 0) return fail(NEEDLE_ERR_INVALID, "from < 0 (StringIndexOutOfBoundsException in the reference)");
+    if (from >= length) {
+        // both generated loops are skipped: indexForwards returns its initial lastMatch (:355-356,468)
+        index = fw.accepting[0] ? 0 : -1;
+    } else {
+        int matched = 0, s32 = -1, e32 = -1;
+        int rc = one_row(m, OP_FIND, from, &matched, &s32, &e32);
+        if (rc) return rc;
+        if (matched) {
+            index = e32 + from;
+            st = s32 + from; // the backward walk is bounded by FROM (:651-652) == index 0 of the sub-row
+            have_start = true;
+        } else {
+            index = -1;
+        }
+    }
+    m->end = index;
+    m->next_start = index;
+    if (index == -1) return NEEDLE_OK;
+    if (!have_start) {
+        // index came from the literal 0 above; start as the reference computes it with an empty walk
+        if (m->p->t.fixed_len >= 0) st = index - m->p->t.fixed_len;
+        else st = m->p->t.dfa[W_BACKWARDS].accepting[0] ? from : 0x7FFFFFFF; // :543-547 with index-1 < FROM
+    }
+    m->start = st;
+    *r = 1;
+    return NEEDLE_OK;
+}
+
+int needle_matcher_find(needle_matcher *m, int *r) {
+    if (!m) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    return needle_matcher_find_range(m, m->next_start, (int)m->s.size(), r); // :616-623
+}
+
+int needle_matcher_start(const needle_matcher *m) { return m ? m->start : -1; }
+int needle_matcher_end(const needle_matcher *m) { return m ? m->end : -1; }
+
+} // extern "C"

@@ -1,0 +1,202 @@
+// Lowering of the reference's tables into device programs (see needle_lower.h, needle_device.h).
+//
+// What gets folded in here so that the kernels' inner loops are pure lookups:
+//   * dead state -1            -> sink state 0 (matches / indexForwards / indexBackwards stop there:
+//                                 DFAClassBuilder.java:892,461,578) or -> the start state for containedIn
+//                                 (its outer loop restarts with state = 0 at the NEXT char, :975-1001,
+//                                 and wasAccepted(-1) == wasAccepted(0) == false whenever that matters)
+//   * `c > maxChar` exits      -> an OVER column with the same targets (:899-901, :1012-1016, :451-457, :573-575)
+//   * containedIn's per-char `if (wasAccepted(state)) return true` (:1008) -> accepting states made absorbing
+//   * ragged rows              -> a PAD column (identity for matches/containedIn, sink for the index walks)
+//   * wasAccepted<X>(state)    -> states renumbered so that accepted(s) == (s >= A0)
+#include "needle_lower.h"
+#include <cstdlib>
+#include <cstring>
+#include <map>
+
+namespace needle {
+
+bool decode_table_string(const char *s, int32_t n_states, int32_t stride, std::vector<int16_t> &out, std::string &err) {
+    out.assign((size_t)n_states * stride, (int16_t)-1);
+    const char *p = s;
+    auto hex = [&](long &v) -> bool {
+        char *e = nullptr;
+        v = strtol(p, &e, 16);
+        if (e == p) return false;
+        p = e;
+        return true;
+    };
+    while (*p) {
+        long st;
+        if (!hex(st) || *p != ':') { err = "malformed table string (state)"; return false; }
+        ++p;
+        for (;;) {
+            long bc, tgt;
+            if (!hex(bc) || *p != '-') { err = "malformed table string (class)"; return false; }
+            ++p;
+            if (!hex(tgt)) { err = "malformed table string (target)"; return false; }
+            if (st < 0 || st >= n_states || bc < 0 || bc >= stride || tgt < 0 || tgt > 32767) {
+                err = "table string entry out of range";
+                return false;
+            }
+            out[(size_t)st * stride + bc] = (int16_t)tgt;
+            if (*p == ',') { ++p; continue; }
+            break;
+        }
+        if (*p == ';') { ++p; continue; }
+        if (*p != 0) { err = "malformed table string (separator)"; return false; }
+    }
+    return true;
+}
+
+bool validate_tables(const RefTables &t, std::string &err) {
+    if (t.class_map.size() != 65536) { err = "class_map must have 65536 entries"; return false; }
+    if (t.stride < 1 || t.stride > 255) { err = "stride (N) out of range"; return false; }
+    for (int c = 0; c < 65536; ++c)
+        if (t.class_map[c] >= t.stride) { err = "class_map entry >= stride"; return false; }
+    for (int w = 0; w < 4; ++w) {
+        const RefDfa &d = t.dfa[w];
+        if (d.n_states < 1 || d.n_states > 16383) { // DFACompiler.checkForOverLongDFAs, DFACompiler.java:76-83
+            err = "n_states out of range (1..16383)";
+            return false;
+        }
+        if (d.table.size() != (size_t)d.n_states * t.stride || d.accepting.size() != (size_t)d.n_states) {
+            err = "table/accepting size mismatch";
+            return false;
+        }
+        if (d.max_char < 0 || d.max_char > 0xFFFF) { err = "max_char out of range"; return false; }
+        for (int16_t v : d.table)
+            if (v < -1 || v >= d.n_states) { err = "table target out of range"; return false; }
+    }
+    return true;
+}
+
+static uint32_t append(std::vector<uint8_t> &blob, const void *src, size_t n) {
+    while (blob.size() % 16) blob.push_back(0);
+    const uint32_t off = (uint32_t)blob.size();
+    const uint8_t *b = (const uint8_t *)src;
+    blob.insert(blob.end(), b, b + n);
+    return off;
+}
+
+Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk) {
+    const RefDfa &d = t.dfa[which];
+    const int N = t.stride;
+    const int n_ref = d.n_states;
+    const int n_dev = n_ref + 1;
+    const int n_cols = N + 2, OVER = N, PAD = N + 1;
+
+    // device numbering: 0 sink | non-accepting | accepting
+    std::vector<int> dev(n_ref);
+    int next_id = 1;
+    for (int s = 0; s < n_ref; ++s)
+        if (!d.accepting[s]) dev[s] = next_id++;
+    const int accept_lo = next_id;
+    for (int s = 0; s < n_ref; ++s)
+        if (d.accepting[s]) dev[s] = next_id++;
+
+    const bool contained = which == W_CONTAINED_IN;
+    const int dead = contained ? dev[0] : 0;
+    std::vector<uint16_t> next((size_t)n_dev * n_cols, 0); // sink row: all 0
+    for (int s = 0; s < n_ref; ++s) {
+        uint16_t *row = &next[(size_t)dev[s] * n_cols];
+        if (contained && d.accepting[s]) {
+            for (int k = 0; k < n_cols; ++k) row[k] = (uint16_t)dev[s];
+            continue;
+        }
+        for (int k = 0; k < N; ++k) {
+            const int16_t tgt = d.table[(size_t)s * N + k];
+            row[k] = (uint16_t)(tgt < 0 ? dead : dev[tgt]);
+        }
+        row[OVER] = (uint16_t)dead;
+        row[PAD] = (which == W_MATCHES || contained) ? (uint16_t)dev[s] : (uint16_t)0;
+    }
+
+    Program p;
+    memset(&p.hdr, 0, sizeof(p.hdr));
+    p.hdr.n_states = n_dev;
+    p.hdr.n_cols = n_cols;
+    p.hdr.start = dev[0];
+    p.hdr.accept_lo = accept_lo;
+    p.hdr.root_accepting = d.accepting[0] ? 1 : 0;
+    p.hdr.pad_col = PAD;
+
+    auto col_of = [&](int c) -> uint8_t { return (uint8_t)(c > d.max_char ? OVER : t.class_map[c]); };
+
+    Mode mode;
+    if (global_walk) mode = MODE_GLOBAL;
+    else if (n_dev <= 8) mode = MODE_NIBBLE;
+    else if (n_dev <= 256) mode = MODE_TABLE8;
+    else mode = MODE_TABLE16;
+
+    // char -> column maps
+    std::vector<uint8_t> cmap8(256), ptab(256), pages;
+    for (int c = 0; c < 256; ++c) cmap8[c] = col_of(c);
+    if (char_width == 2) {
+        std::map<std::vector<uint8_t>, int> seen;
+        for (int hi = 0; hi < 256; ++hi) {
+            std::vector<uint8_t> pg(256);
+            for (int lo = 0; lo < 256; ++lo) pg[lo] = col_of((hi << 8) | lo);
+            auto it = seen.find(pg);
+            if (it == seen.end()) {
+                it = seen.emplace(pg, (int)seen.size()).first;
+                pages.insert(pages.end(), pg.begin(), pg.end());
+            }
+            ptab[hi] = (uint8_t)it->second;
+        }
+        p.hdr.n_pages = (uint32_t)(pages.size() / 256);
+    }
+
+    const size_t maps_bytes = char_width == 1 ? 256 : 256 + pages.size();
+    if (mode == MODE_TABLE8 && maps_bytes + next.size() + 64 > lds_table_budget) mode = MODE_TABLE16; // -> MODE_GLOBAL below
+
+    auto emit_maps = [&]() {
+        if (char_width == 1) {
+            p.hdr.off_cmap = append(p.blob, cmap8.data(), 256);
+        } else {
+            p.hdr.off_ptab = append(p.blob, ptab.data(), 256);
+            p.hdr.off_pages = append(p.blob, pages.data(), pages.size());
+        }
+    };
+
+    if (mode == MODE_NIBBLE) {
+        auto pack = [&](int col) {
+            uint32_t F = 0;
+            for (int s = 0; s < n_dev; ++s) F |= (uint32_t)next[(size_t)s * n_cols + col] << (4 * s);
+            return F;
+        };
+        std::vector<uint32_t> f;
+        if (char_width == 1) {
+            f.resize(257);
+            for (int c = 0; c < 256; ++c) f[c] = pack(cmap8[c]);
+            f[256] = pack(PAD);
+        } else {
+            f.resize(n_cols);
+            for (int k = 0; k < n_cols; ++k) f[k] = pack(k);
+        }
+        p.hdr.off_f = append(p.blob, f.data(), f.size() * 4);
+        if (char_width == 2) emit_maps();
+        p.hdr.lds_bytes = (uint32_t)p.blob.size();
+    } else if (mode == MODE_TABLE8) {
+        emit_maps();
+        std::vector<uint8_t> t8(next.size());
+        for (size_t i = 0; i < next.size(); ++i) t8[i] = (uint8_t)next[i];
+        p.hdr.off_table = append(p.blob, t8.data(), t8.size());
+        p.hdr.lds_bytes = (uint32_t)p.blob.size();
+    } else {
+        emit_maps();
+        const uint32_t maps_end = (uint32_t)((p.blob.size() + 15) & ~(size_t)15);
+        p.hdr.off_table = append(p.blob, next.data(), next.size() * 2);
+        if (mode == MODE_TABLE16 && p.blob.size() <= lds_table_budget) {
+            p.hdr.lds_bytes = (uint32_t)p.blob.size();
+        } else {
+            mode = MODE_GLOBAL;
+            p.hdr.lds_bytes = global_walk ? 0 : maps_end; // maps stay in LDS, the table is read from HBM/L2
+        }
+    }
+    while (p.blob.size() % 16) p.blob.push_back(0);
+    p.hdr.mode = mode;
+    return p;
+}
+
+} // namespace needle

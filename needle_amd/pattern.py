@@ -1,0 +1,259 @@
+"""Host-side mirror of the reference's interface for this path, over the C ABI (include/needle_hip.h):
+
+    DFACompiler.compile(regex, className[, flags]) -> Pattern   needle-compiler/.../DFACompiler.java:16-37
+    Pattern.matcher(String) -> Matcher, flag constants          needle-types/.../Pattern.java:3-34
+    Matcher.matches/containedIn/find/find(int,int)/start/end    needle-types/.../Matcher.java:6-26
+
+plus the batch entry points the reference does not have (one launch over many haystacks).  Everything that
+matches goes through the HIP kernels; nothing here walks an automaton on the CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import BatchView, DfaDesc, PatternInfo, TableDesc
+
+# flag constants, same values as the reference (Pattern.java:9-31)
+CASE_INSENSITIVE = 0x02
+DOTALL = 0x20
+UNICODE_CASE = 0x40
+UNICODE_CHARACTER_CLASS = 0x100
+LEFTMOST_LONGEST = 0x800000
+ALL_FLAGS = DOTALL | CASE_INSENSITIVE | UNICODE_CASE | LEFTMOST_LONGEST | UNICODE_CHARACTER_CLASS
+
+
+class PatternException(RuntimeError):
+    """NC/PatternException.java"""
+
+
+class PatternSyntaxException(PatternException):
+    """NC/PatternSyntaxException.java (RegexParser.java:86-98,293-295)"""
+
+
+class PatternClassCompilationException(PatternException):
+    """NC/PatternClassCompilationException.java (DFACompiler.java:34-36,71-83)"""
+
+
+class DeviceError(RuntimeError):
+    """HIP failure / no device (IllegalStateException in the Java shim)."""
+
+
+def _check(rc):
+    if rc == _lib.NEEDLE_OK:
+        return
+    msg = _lib.last_error()
+    if rc == _lib.ERR_INVALID:
+        raise ValueError(msg)
+    if rc == _lib.ERR_SYNTAX:
+        raise PatternSyntaxException(msg)
+    if rc in (_lib.ERR_COMPILE, _lib.ERR_UNSUPPORTED):
+        raise PatternClassCompilationException(msg)
+    raise DeviceError(msg)
+
+
+def _utf16(s):
+    """str -> uint16 code units (surrogate pairs for astral chars, like java.lang.String)."""
+    if isinstance(s, np.ndarray):
+        return np.ascontiguousarray(s, dtype=np.uint16)
+    return np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16).copy()
+
+
+class Matcher:
+    """One haystack + cursor (the generated class's fields, DFAClassBuilder.java:688-699)."""
+
+    def __init__(self, pattern, s):
+        self._pattern = pattern  # keeps the native pattern alive
+        self._units = _utf16(s)
+        h = ctypes.c_void_p()
+        _check(_lib.lib().needle_matcher_create(pattern._h, self._units.ctypes.data, self._units.size, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().needle_matcher_destroy(h)
+
+    def _bool(self, fn, *args):
+        r = ctypes.c_int(0)
+        _check(fn(self._h, *args, ctypes.byref(r)))
+        return bool(r.value)
+
+    def matches(self):
+        return self._bool(_lib.lib().needle_matcher_matches)
+
+    def containedIn(self):
+        return self._bool(_lib.lib().needle_matcher_contained_in)
+
+    def find(self, start=None, end=None):
+        if start is None:
+            return self._bool(_lib.lib().needle_matcher_find)
+        return self._bool(_lib.lib().needle_matcher_find_range, int(start), int(end))
+
+    def start(self):
+        return _lib.lib().needle_matcher_start(self._h)
+
+    def end(self):
+        return _lib.lib().needle_matcher_end(self._h)
+
+
+WHICH = {"matches": 0, "contained_in": 1, "forwards": 2, "backwards": 3}
+
+
+class Pattern:
+    """A compiled pattern: immutable, shareable, tables resident in HBM per device."""
+
+    def __init__(self, handle, regex=None, flags=0):
+        self._h = handle
+        self.regex = regex
+        self.flags = flags
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().needle_pattern_destroy(h)
+
+    # ---- reference interface
+    def matcher(self, s):
+        return Matcher(self, s)
+
+    # ---- construction from the tables a generated class carries
+    @classmethod
+    def from_tables(cls, class_map, stride, dfas, fixed_len=-1):
+        """dfas: {"matches"|"contained_in"|"forwards"|"backwards": dict(n_states, max_char, accepting (ids),
+        table (flat int16) | table_strings (list[str]))}"""
+        cm = np.ascontiguousarray(class_map, dtype=np.uint8)
+        assert cm.size == 65536
+        keep = [cm]
+        desc = TableDesc()
+        desc.class_map = cm.ctypes.data
+        desc.stride = int(stride)
+        desc.fixed_len = -1 if fixed_len is None else int(fixed_len)
+        for name in WHICH:
+            spec = dfas[name]
+            d = DfaDesc()
+            d.n_states = int(spec["n_states"])
+            d.max_char = 0xFFFF if spec.get("max_char") is None else int(spec["max_char"])
+            acc = np.zeros(d.n_states, dtype=np.uint8)
+            for s in spec["accepting"]:
+                acc[int(s)] = 1
+            keep.append(acc)
+            d.accepting = acc.ctypes.data
+            if spec.get("table") is not None:
+                t = np.ascontiguousarray(spec["table"], dtype=np.int16)
+                assert t.size == d.n_states * desc.stride
+                keep.append(t)
+                d.table = t.ctypes.data
+                d.table_string = None
+            else:
+                d.table = None
+                d.table_string = ";".join(spec["table_strings"]).encode("ascii")
+            setattr(desc, name, d)
+        h = ctypes.c_void_p()
+        _check(_lib.lib().needle_pattern_from_tables(ctypes.byref(desc), ctypes.byref(h)))
+        del keep
+        return cls(h)
+
+    # ---- introspection
+    def info(self):
+        i = PatternInfo()
+        _check(_lib.lib().needle_pattern_get_info(self._h, ctypes.byref(i)))
+        return {"stride": i.stride, "n_states": dict(zip(WHICH, i.n_states)), "max_char": dict(zip(WHICH, i.max_char)),
+                "fixed_len": i.fixed_len, "min_len": i.min_len, "max_len": i.max_len,
+                "kernel_mode": dict(zip(WHICH, i.kernel_mode))}
+
+    def tables(self):
+        """The pattern's tables in the reference layout (class map, stride, 4 x (table, accepting, max_char))."""
+        inf = self.info()
+        cm = np.zeros(65536, dtype=np.uint8)
+        _check(_lib.lib().needle_pattern_get_class_map(self._h, cm.ctypes.data))
+        out = {"class_map": cm, "stride": inf["stride"], "fixed_len": inf["fixed_len"], "min_len": inf["min_len"],
+               "max_len": inf["max_len"], "dfas": {}}
+        for name, w in WHICH.items():
+            n = inf["n_states"][name]
+            t = np.zeros(n * inf["stride"], dtype=np.int16)
+            a = np.zeros(n, dtype=np.uint8)
+            _check(_lib.lib().needle_pattern_get_table(self._h, w, t.ctypes.data, a.ctypes.data))
+            out["dfas"][name] = {"n_states": n, "table": t, "accepting": np.nonzero(a)[0].tolist(),
+                                 "max_char": inf["max_char"][name]}
+        return out
+
+    # ---- batches
+    def _run(self, op, rows, lengths, stream):
+        L = _lib.lib()
+        v = BatchView()
+        if isinstance(rows, np.ndarray):  # host buffers: upload + run + download inside the library
+            rows = np.ascontiguousarray(rows)
+            if rows.dtype == np.int16:
+                rows = rows.view(np.uint16)
+            assert rows.ndim == 2 and rows.dtype in (np.uint8, np.uint16), "rows: 2-D uint8/uint16"
+            n, stride = rows.shape
+            v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.ctypes.data, rows.dtype.itemsize, n, stride, stride
+            if lengths is not None:
+                lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+                assert lengths.shape == (n,)
+                v.lengths = lengths.ctypes.data
+            words = np.zeros((n + 63) // 64, dtype=np.uint64)
+            if op == "find":
+                st = np.full(n, -1, dtype=np.int32)
+                en = np.full(n, -1, dtype=np.int32)
+                _check(L.needle_find_host(self._h, ctypes.byref(v), words.ctypes.data, st.ctypes.data, en.ctypes.data))
+                return words, st, en
+            fn = L.needle_matches_host if op == "matches" else L.needle_contained_in_host
+            _check(fn(self._h, ctypes.byref(v), words.ctypes.data))
+            return words
+        import torch  # device tensors: plumbing only (memory + stream)
+        assert isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dim() == 2 and rows.is_contiguous()
+        assert rows.dtype in (torch.uint8, torch.int16, torch.uint16), "rows: uint8 or (u)int16 code units"
+        n, stride = rows.shape
+        cw = rows.element_size()
+        v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.data_ptr(), cw, n, stride, stride
+        if lengths is not None:
+            assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.shape == (n,) and lengths.is_contiguous()
+            v.lengths = lengths.data_ptr()
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            words = torch.empty((n + 63) // 64, dtype=torch.int64, device=rows.device)
+            if op == "find":
+                st = torch.empty(n, dtype=torch.int32, device=rows.device)
+                en = torch.empty(n, dtype=torch.int32, device=rows.device)
+                _check(L.needle_find_dev(self._h, ctypes.byref(v), words.data_ptr(), st.data_ptr(), en.data_ptr(), s))
+                return words, st, en
+            fn = L.needle_matches_dev if op == "matches" else L.needle_contained_in_dev
+            _check(fn(self._h, ctypes.byref(v), words.data_ptr(), s))
+            return words
+
+    def matches_batch(self, rows, lengths=None, stream=None):
+        """bitmap words (bit r&63 of word r>>6 = matches() of row r)."""
+        return self._run("matches", rows, lengths, stream)
+
+    def contained_in_batch(self, rows, lengths=None, stream=None):
+        return self._run("contained_in", rows, lengths, stream)
+
+    def find_batch(self, rows, lengths=None, stream=None):
+        """(bitmap words, start int32[n], end int32[n]); unmatched rows have start = end = -1."""
+        return self._run("find", rows, lengths, stream)
+
+
+def unpack_bitmap(words, n_rows):
+    """bitmap words -> bool array of n_rows (numpy)."""
+    if not isinstance(words, np.ndarray):
+        words = words.cpu().numpy()
+    w = np.ascontiguousarray(words).view(np.uint64)
+    bits = np.unpackbits(w.view(np.uint8), bitorder="little")
+    return bits[:n_rows].astype(bool)
+
+
+class DFACompiler:
+    """DFACompiler.compile / compileToBytes entry point (DFACompiler.java:16-74): regex -> Pattern."""
+
+    @staticmethod
+    def compile(regex, class_name=None, flags=0):
+        if regex is None:
+            raise TypeError("regex string cannot be null")  # Objects.requireNonNull, RegexParser.java:87
+        if flags & ~ALL_FLAGS:
+            raise ValueError("Unknown flag bits")  # CompilerOptions.java:9-16
+        u = _utf16(regex)
+        h = ctypes.c_void_p()
+        _check(_lib.lib().needle_compile(u.ctypes.data, u.size, int(flags), ctypes.byref(h)))
+        return Pattern(h, regex, flags)

@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: libneedle_hip.so loads and exports every symbol that
+include/needle_hip.h declares; argument validation works without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_snapshot
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from needle_amd import build
+    build.build()
+    from needle_amd import _lib
+    return _lib.lib()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "needle_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(needle_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    from needle_amd import _lib
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_version_and_error_strings(lib):
+    assert b"needle_hip" in lib.needle_version()
+    assert isinstance(lib.needle_last_error(), bytes)
+
+
+def test_from_tables_roundtrip_and_validation(lib):
+    from needle_amd.pattern import Pattern
+    from oracle.walker import class_map_from_runs, decode_table_strings
+    doc = load_snapshot("UnionOfManyNames")
+    cm = class_map_from_runs(doc["class_map_runs"])
+    names = {"matches": "Matches", "contained_in": "ContainedIn", "forwards": "Forwards", "backwards": "Backwards"}
+    dfas = {k: dict(n_states=doc["dfas"][v]["n_states"], max_char=doc["dfas"][v]["max_char"],
+                    accepting=doc["dfas"][v]["accepting"], table_strings=doc["dfas"][v]["table_strings"])
+            for k, v in names.items()}
+    p = Pattern.from_tables(cm, doc["stride"], dfas, fixed_len=-1)
+    t = p.tables()
+    assert t["stride"] == doc["stride"]
+    assert (t["class_map"] == cm).all()
+    for k, v in names.items():
+        want = decode_table_strings(doc["dfas"][v]["table_strings"], doc["dfas"][v]["n_states"], doc["stride"])
+        assert (t["dfas"][k]["table"] == want).all()
+        assert t["dfas"][k]["accepting"] == doc["dfas"][v]["accepting"]
+    info = p.info()
+    assert info["n_states"]["matches"] == 31 and info["kernel_mode"]["matches"] == 1  # 32 device states -> uint8 LDS table
+    # malformed table string / out-of-range target -> ValueError, not a crash
+    bad = dict(dfas)
+    bad["matches"] = dict(dfas["matches"], table_strings=["0:zz-1"])
+    with pytest.raises(ValueError):
+        Pattern.from_tables(cm, doc["stride"], bad)
+    bad["matches"] = dict(dfas["matches"], table_strings=["0:1-7f"])
+    with pytest.raises(ValueError):
+        Pattern.from_tables(cm, doc["stride"], bad)
+
+
+def test_small_automata_lower_to_nibble_mode(lib):
+    from test_gpu_parity import pattern_from_fixture
+    p = pattern_from_fixture(load_snapshot("DigitPlus"))
+    assert set(p.info()["kernel_mode"].values()) == {0}
