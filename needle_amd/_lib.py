@@ -50,6 +50,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libneedle_hip.so is not built (%s). Run `python -m needle_amd.build` "
                           "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever is mapped first serves
+    # the whole process, and two HSA runtimes in one process cannot both open the GPU -- so when torch is
+    # installed make sure ITS runtime is the one already loaded before our DT_NEEDED is resolved.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     P, I, VP = ctypes.POINTER, ctypes.c_int, ctypes.c_void_p
     L.needle_version.restype = ctypes.c_char_p

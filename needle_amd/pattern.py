@@ -71,8 +71,8 @@ class Matcher:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            _lib.lib().needle_matcher_destroy(h)
+        if h and _lib is not None and _lib._lib is not None:  # module globals may be gone at interpreter exit
+            _lib._lib.needle_matcher_destroy(h)
 
     def _bool(self, fn, *args):
         r = ctypes.c_int(0)
@@ -110,8 +110,8 @@ class Pattern:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            _lib.lib().needle_pattern_destroy(h)
+        if h and _lib is not None and _lib._lib is not None:
+            _lib._lib.needle_pattern_destroy(h)
 
     # ---- reference interface
     def matcher(self, s):

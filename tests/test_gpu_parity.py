@@ -104,7 +104,7 @@ def test_gpu_equals_oracle_on_seeded_batches(name, n_rows, stride, ragged, oracl
     assert (c == oc).all()
     assert (f == of).all() and (fs == ofs).all() and (fe == ofe).all()
     if not ragged and n_rows > 100:
-        assert oc.any() and not oc.all()
+        assert oc.any() and om.sum() < n_rows
     # same batch as UTF-16 code units with some non-Latin-1 chars mixed in
     rows16 = rows.astype(np.uint16)
     mask = rng.random(rows16.shape) < 0.02
