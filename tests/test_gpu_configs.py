@@ -1,0 +1,156 @@
+"""GPU parity for the BASELINE.json configs, patterns built by the product's own table generator (needle_compile):
+C1 http://.+ matches() on 1k short strings, C2 [0-9]+ containedIn(), C3 1k-keyword union find(), C5 BMP class
+regex over UTF-16, plus every matches.txt golden row through the single-haystack Matcher mirror.  Oracle =
+oracle/needle_walk.c fed with the SAME tables (read back through the C ABI); bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_compile_matches_txt import flag_sets, needs_jdk_tables, oracle_for
+from test_gpu_parity import gpu_run, rows_from_strings
+
+
+def compiled(pattern, flags=0):
+    from needle_amd.pattern import DFACompiler
+    o, _ = oracle_for(pattern, flags)
+    return DFACompiler.compile(pattern, "t", flags), o
+
+
+@pytest.mark.gpu
+def test_c1_url_matches_1k_strings():
+    from needle_amd import workload as W
+    p, o = compiled("http://.+")
+    hs = W.url_strings(1000)
+    rows, lens = rows_from_strings(hs, np.uint8)
+    m, c, f, fs, fe = gpu_run(p, rows, lens)
+    want = np.array([o.matches(h) for h in hs])
+    assert (m == want).all()
+    assert 400 < want.sum() < 600  # 50 % well-formed; the newline / no-prefix variants must not match
+    assert (c == np.array([o.contained_in(h) for h in hs])).all()
+    for i, h in enumerate(hs):
+        found, s, e = o.find(h)
+        assert f[i] == found and (not found or (fs[i], fe[i]) == (s, e))
+    # DFACompilerTest.java:524-540
+    mm = p.matcher("http://www.google.com")
+    assert mm.matches() and mm.containedIn() and mm.find() and (mm.start(), mm.end()) == (0, 21)
+    mm = p.matcher("http://Γειά σου.com")
+    assert mm.find() and (mm.start(), mm.end()) == (0, 19)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ragged", [False, True])
+def test_c2_digits_contained_in(ragged):
+    import torch
+    from needle_amd import workload as W
+    from needle_amd.pattern import unpack_bitmap
+    p, o = compiled("[0-9]+")
+    n = 200_003
+    rows = W.digits_batch(torch, 12345, n, 256, device="cuda")
+    host = rows.cpu().numpy()
+    assert (host == W.digits_batch(np, 12345, n, 256)).all()
+    lens = None
+    tl = None
+    if ragged:
+        lens = (np.arange(n, dtype=np.uint32) * 2654435761 % 257).astype(np.uint32)
+        tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    got = unpack_bitmap(p.contained_in_batch(rows, tl), n)
+    want = o.batch_contained_in(host, lens, threads=4)
+    assert (got == want).all()
+    if not ragged:
+        assert abs(want.mean() - 0.5) < 0.01
+    fw, fs, fe = p.find_batch(rows, tl)
+    of, ofs, ofe = o.batch_find(host, lens, threads=4)
+    assert (unpack_bitmap(fw, n) == of).all() and (fs.cpu().numpy() == ofs).all() and (fe.cpu().numpy() == ofe).all()
+    assert (unpack_bitmap(p.matches_batch(rows, tl), n) == o.batch_matches(host, lens, threads=4)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ragged", [False, True])
+def test_c3_keyword_union_find(ragged):
+    import torch
+    from needle_amd import workload as W
+    from needle_amd.pattern import unpack_bitmap
+    words = W.keywords(1000)
+    p, o = compiled("|".join(words))
+    assert p.info()["n_states"]["forwards"] > 1000  # LDS table stress: uint16 table mode
+    n = 100_000
+    rows = W.keyword_batch(torch, words, 777, n, 256, device="cuda")
+    host = rows.cpu().numpy()
+    lens = tl = None
+    if ragged:
+        lens = (np.arange(n, dtype=np.uint32) * 40503 % 257).astype(np.uint32)
+        tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    fw, fs, fe = p.find_batch(rows, tl)
+    of, ofs, ofe = o.batch_find(host, lens, threads=4)
+    assert (unpack_bitmap(fw, n) == of).all()
+    assert (fs.cpu().numpy() == ofs).all() and (fe.cpu().numpy() == ofe).all()
+    assert of.mean() > 0.25  # planted rows + chance hits
+    assert (unpack_bitmap(p.contained_in_batch(rows, tl), n) == o.batch_contained_in(host, lens, threads=4)).all()
+    assert (unpack_bitmap(p.matches_batch(rows, tl), n) == o.batch_matches(host, lens, threads=4)).all()
+
+
+@pytest.mark.gpu
+def test_c5_bmp_class_regex_utf16():
+    import torch
+    from needle_amd import workload as W
+    from needle_amd.pattern import unpack_bitmap
+    p, o = compiled(W.script_regex())
+    n = 100_000
+    rows = W.script_batch(torch, 99, n, 256, device="cuda")
+    host = rows.cpu().numpy().view(np.uint16)
+    assert (host == W.script_batch(np, 99, n, 256)).all()
+    fw, fs, fe = p.find_batch(rows)
+    of, ofs, ofe = o.batch_find(host, threads=4)
+    assert (unpack_bitmap(fw, n) == of).all()
+    assert (fs.cpu().numpy() == ofs).all() and (fe.cpu().numpy() == ofe).all()
+    assert 0.25 < of.mean() < 0.6
+    assert (unpack_bitmap(p.contained_in_batch(rows), n) == o.batch_contained_in(host, threads=4)).all()
+
+
+@pytest.mark.gpu
+def test_matches_txt_rows_through_gpu_matcher():
+    doc = json.load(open(os.path.join(GOLDEN, "matches.json")))
+    from needle_amd.pattern import DFACompiler
+    cache = {}
+    n = 0
+    for row in doc["rows"]:
+        flags = flag_sets(row)[0]
+        if needs_jdk_tables(row, flags):
+            continue
+        key = (row["pattern"], flags)
+        if key not in cache:
+            cache[key] = DFACompiler.compile(row["pattern"], "t", flags)
+        m = cache[key].matcher(row["haystack"])
+        assert m.find() == row["found"], row
+        if row["found"]:
+            assert (m.start(), m.end()) == (row["start"], row["end"]), row
+        n += 1
+    assert n > 180
+    for case in doc["inline"]:
+        p = DFACompiler.compile(case["pattern"], "t", case["flags"])
+        m = p.matcher(case["haystack"])
+        if "matches" in case:
+            assert m.matches() == case["matches"]
+        if "find" in case:
+            rng = case.get("find_range")
+            found = m.find(*rng) if rng else m.find()
+            assert [found, m.start(), m.end()][:1] == case["find"][:1]
+            if found:
+                assert [m.start(), m.end()] == case["find"][1:]
+
+
+@pytest.mark.gpu
+def test_host_buffer_entry_points_match_device_entry_points():
+    from needle_amd.pattern import unpack_bitmap
+    p, o = compiled("[0-9]+")
+    rng = np.random.default_rng(7)
+    rows = rng.choice(np.frombuffer(b"abc 019xyz", dtype=np.uint8), size=(5000, 100))  # stride not a multiple of 16
+    lens = rng.integers(0, 101, size=5000).astype(np.uint32)
+    w = p.contained_in_batch(rows, lens)
+    assert (unpack_bitmap(w, 5000) == o.batch_contained_in(rows, lens)).all()
+    fw, fs, fe = p.find_batch(rows, lens)
+    of, ofs, ofe = o.batch_find(rows, lens)
+    assert (unpack_bitmap(fw, 5000) == of).all() and (fs == ofs).all() and (fe == ofe).all()
