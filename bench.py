@@ -59,6 +59,18 @@ def make_rows(workload, words, row0, n_rows, device):
     return out
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(workload, pattern, rows_dev, budget_s=12.0):
     """Times the CPU oracle on a bounded sample of the same rows (rank 0, N = 1 only)."""
     import numpy as np
@@ -66,7 +78,7 @@ def cpu_baseline(workload, pattern, rows_dev, budget_s=12.0):
     t = pattern.tables()
     d = {k: Dfa(t["class_map"], t["stride"], v["table"], v["accepting"], v["max_char"]) for k, v in t["dfas"].items()}
     o = OraclePattern(d["matches"], d["contained_in"], d["forwards"], d["backwards"], t["fixed_len"], -1)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = min(rows_dev.shape[0], 1 << 20)
     host = rows_dev[:n].cpu().numpy()
     if host.dtype == np.int16:
@@ -184,6 +196,18 @@ def main():
                      "frac": bytes_gpu / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "needle::scan_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_gpu},
     }
+    # HBM traffic per launch comes from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per
+    # MI355X_MICROARCH.md) committed under profiles/ for this exact workload and size; null if none was taken.
+    if args.rows == 10_000_000:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % args.workload)), reverse=True):
+            try:
+                prof = json.load(open(f))
+                out["roofline"]["traffic"] = prof["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
+                break
+            except (OSError, KeyError, ValueError):
+                pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, pattern, rows)
     if rank == 0:

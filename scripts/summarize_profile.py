@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condenses a scripts/profile_c2.sh output directory (gpurun_out/prof_<w>) into profiles/r<NN>_<w>.json + .md:
+kernel-trace stats of needle::scan_kernel and the HBM traffic counters, corrected as MI355X_MICROARCH.md
+prescribes (FETCH_SIZE is in KiB and reports exactly 1/2 of a wide coalesced stream on gfx950 -> x2; WRITE_SIZE
+in KiB, uncalibrated)."""
+import csv
+import json
+import os
+import sys
+
+src, rnd, w = sys.argv[1], sys.argv[2], sys.argv[3]
+out = {"workload": w, "round": rnd}
+for r in csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))):
+    if "scan_kernel" in r["Name"]:
+        out["kernel"] = r["Name"]
+        out["calls"] = int(r["Calls"])
+        out["avg_ns"] = float(r["AverageNs"])
+        out["min_ns"] = float(r["MinNs"])
+        out["max_ns"] = float(r["MaxNs"])
+        out["pct_of_gpu_time"] = float(r["Percentage"])
+for name, sub, f in (("FETCH_SIZE", "fetch", "f"), ("WRITE_SIZE", "write", "w")):
+    vals = []
+    for r in csv.DictReader(open(os.path.join(src, sub, f + "_counter_collection.csv"))):
+        if "scan_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            vals.append(float(r["Counter_Value"]))
+            out["vgpr"], out["sgpr"], out["workgroup"], out["grid"] = r["VGPR_Count"], r["SGPR_Count"], r["Workgroup_Size"], r["Grid_Size"]
+    out[name + "_KiB_per_launch"] = sum(vals) / len(vals)
+fetch_b = out["FETCH_SIZE_KiB_per_launch"] * 1024 * 2
+write_b = out["WRITE_SIZE_KiB_per_launch"] * 1024
+out["hbm_read_bytes_per_launch_corrected"] = fetch_b
+out["hbm_write_bytes_per_launch"] = write_b
+out["traffic_bytes_per_launch"] = fetch_b + write_b
+bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+out["bench_line_under_profiler"] = bench
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / alg
+out["achieved_GBs_from_trace_avg"] = alg / out["avg_ns"]
+os.makedirs("profiles", exist_ok=True)
+base = os.path.join("profiles", "r%s_%s" % (rnd, w))
+json.dump(out, open(base + ".json", "w"), indent=1)
+with open(base + ".md", "w") as f:
+    f.write("# rocprofv3 summary, round %s, workload %s\n\n" % (rnd, w))
+    f.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --steps 20 --warmup 3` (+ separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)\n\n" % w)
+    f.write("| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|\n")
+    f.write("| `%s` | %d | %.1f | %.1f | %.1f |\n\n" % (out["kernel"][:90], out["calls"], out["avg_ns"] / 1e3, out["min_ns"] / 1e3, out["max_ns"] / 1e3))
+    f.write("* algorithmic bytes per launch: %d -> %.0f GB/s at the trace's average duration (%.1f %% of 8 TB/s)\n" % (alg, out["achieved_GBs_from_trace_avg"], out["achieved_GBs_from_trace_avg"] / 80))
+    f.write("* HBM read  (2 x FETCH_SIZE x 1024): %.4g B per launch\n* HBM write (WRITE_SIZE x 1024, uncalibrated): %.4g B per launch\n" % (fetch_b, write_b))
+    f.write("* traffic / algorithmic = %.3f\n* VGPR %s, SGPR %s, workgroup %s, grid %s\n" % (out["traffic_over_algorithmic"], out["vgpr"], out["sgpr"], out["workgroup"], out["grid"]))
+print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_profiler"}, indent=1))
