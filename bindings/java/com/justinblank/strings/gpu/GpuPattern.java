@@ -1,0 +1,95 @@
+package com.justinblank.strings.gpu;
+
+import com.justinblank.strings.Matcher;
+import com.justinblank.strings.Pattern;
+import com.justinblank.strings.PatternClassCompilationException;
+import com.justinblank.strings.PatternSyntaxException;
+
+import java.nio.ByteBuffer;
+
+/**
+ * Drop-in implementation of com.justinblank.strings.Pattern (needle-types/.../Pattern.java:3-34) whose matchers
+ * run on the MI355X kernels, plus the batch entry points the reference lacks.  Immutable and shareable like the
+ * reference's generated Pattern classes (DFACompiler.createPatternClass, DFACompiler.java:96-111).
+ *
+ * NOT COMPILED IN THE BUILD CONTAINER (no JDK); shipped as source.
+ */
+public final class GpuPattern implements Pattern, AutoCloseable {
+    private long handle;
+
+    private GpuPattern(long handle) {
+        this.handle = handle;
+    }
+
+    /** The library builds the automata itself (needle_compile). */
+    public static GpuPattern compile(String regex, int flags) {
+        if ((flags & ~ALL_FLAGS) != 0) {
+            throw new IllegalArgumentException("Unknown flag bits"); // CompilerOptions.java:9-16
+        }
+        long[] h = new long[1];
+        check(Native.compile(regex.toCharArray(), flags, h), regex);
+        return new GpuPattern(h[0]);
+    }
+
+    /** needle's own DFACompiler built the automata; DFATableEmitter flattened them (see DFATableEmitter). */
+    public static GpuPattern fromTables(byte[] classMap, int stride, int[] nStates, int[] maxChar, short[][] tables,
+                                 byte[][] accepting, int fixedLen) {
+        long[] h = new long[1];
+        check(Native.fromTables(classMap, stride, nStates, maxChar, tables, accepting, fixedLen, h), null);
+        return new GpuPattern(h[0]);
+    }
+
+    @Override
+    public Matcher matcher(String s) {
+        return new GpuMatcher(handle, s);
+    }
+
+    /** bit (r &amp; 63) of word (r &gt;&gt; 6) = containedIn() of row r. */
+    public long[] containedInBatch(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
+                                   ByteBuffer lengths) {
+        long[] bitmap = new long[(int) ((nRows + 63) / 64)];
+        check(Native.containedInHost(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, bitmap), null);
+        return bitmap;
+    }
+
+    public long[] matchesBatch(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
+                               ByteBuffer lengths) {
+        long[] bitmap = new long[(int) ((nRows + 63) / 64)];
+        check(Native.matchesHost(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, bitmap), null);
+        return bitmap;
+    }
+
+    /** start/end receive the first find() of every row; unmatched rows get -1/-1. */
+    public long[] findBatch(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
+                            ByteBuffer lengths, int[] start, int[] end) {
+        long[] bitmap = new long[(int) ((nRows + 63) / 64)];
+        check(Native.findHost(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, bitmap, start, end), null);
+        return bitmap;
+    }
+
+    @Override
+    public void close() {
+        if (handle != 0) {
+            Native.destroyPattern(handle);
+            handle = 0;
+        }
+    }
+
+    /** Status code -> the exception the reference would have thrown at the same point. */
+    static void check(int status, String regex) {
+        switch (status) {
+            case 0:
+                return;
+            case 1:
+                throw new IllegalArgumentException(Native.lastError());
+            case 2:
+                throw new PatternSyntaxException(Native.lastError()); // RegexParser.java:86-98
+            case 3:
+            case 4:
+                throw new PatternClassCompilationException(
+                        "Failed to compile pattern from regex '" + regex + "': " + Native.lastError(), null);
+            default:
+                throw new IllegalStateException(Native.lastError()); // device errors
+        }
+    }
+}

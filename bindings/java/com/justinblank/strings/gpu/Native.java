@@ -1,0 +1,64 @@
+package com.justinblank.strings.gpu;
+
+/**
+ * JNI surface of libneedle_hip.so (include/needle_hip.h).  One-to-one with the C ABI; every method returns the
+ * library's status code except where noted, and the shim (bindings/jni/needle_jni.c) never throws -- exceptions
+ * are raised on the Java side from the status (see GpuPattern.check).
+ *
+ * NOT COMPILED IN THE BUILD CONTAINER (no JDK, no jni.h); shipped as source for a maintainer with a JDK.
+ */
+final class Native {
+    static {
+        System.loadLibrary("needle_jni"); // links libneedle_hip.so
+    }
+
+    private Native() {
+    }
+
+    static native String lastError();
+
+    static native int deviceCount();
+
+    /** needle_compile: regex as UTF-16 code units (String.toCharArray()). handleOut[0] receives the pattern handle. */
+    static native int compile(char[] regex, int flags, long[] handleOut);
+
+    /**
+     * needle_pattern_from_tables: what DFATableEmitter extracted from needle's own four DFAs.
+     * classMap: 65536 bytes (BYTE_CLASSES[0..65535]); tables[i]: flat short[nStates[i] * stride], -1 = none;
+     * accepting[i]: byte[nStates[i]]; order of i: matches, containedIn, forwards, backwards.
+     */
+    static native int fromTables(byte[] classMap, int stride, int[] nStates, int[] maxChar, short[][] tables,
+                                 byte[][] accepting, int fixedLen, long[] handleOut);
+
+    static native void destroyPattern(long handle);
+
+    /**
+     * Host-buffer batches.  rows: direct ByteBuffer of nRows * rowStride chars (charWidth 1 or 2, native order);
+     * lengths: direct buffer of nRows ints or null; bitmap: long[(nRows + 63) / 64]; start/end: int[nRows].
+     */
+    static native int matchesHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride,
+                                  int rowLen, java.nio.ByteBuffer lengths, long[] bitmap);
+
+    static native int containedInHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows,
+                                      long rowStride, int rowLen, java.nio.ByteBuffer lengths, long[] bitmap);
+
+    static native int findHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride,
+                               int rowLen, java.nio.ByteBuffer lengths, long[] bitmap, int[] start, int[] end);
+
+    // one Matcher (reference cursor semantics)
+    static native int matcherCreate(long pattern, char[] s, long[] handleOut);
+
+    static native void matcherDestroy(long matcher);
+
+    static native int matcherMatches(long matcher, int[] result);
+
+    static native int matcherContainedIn(long matcher, int[] result);
+
+    static native int matcherFind(long matcher, int[] result);
+
+    static native int matcherFindRange(long matcher, int from, int to, int[] result);
+
+    static native int matcherStart(long matcher);
+
+    static native int matcherEnd(long matcher);
+}

@@ -1,0 +1,144 @@
+/*
+ * JNI shim: com.justinblank.strings.gpu.Native -> libneedle_hip.so (include/needle_hip.h).
+ * Thin by design: unpack Java arrays / direct buffers, call the C ABI, return its status code.  No exception is
+ * raised here; GpuPattern.check() maps status codes to the reference's exception types.
+ *
+ * NOT COMPILED IN THE BUILD CONTAINER: the image has no JDK (no jni.h).  Build on a box with a JDK:
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude bindings/jni/needle_jni.c \
+ *       -Lneedle_amd -lneedle_hip -o libneedle_jni.so
+ * The same entry points are exercised without a JVM by tests/ through ctypes (needle_amd/_lib.py).
+ */
+#include <jni.h>
+#include <stdint.h>
+#include <string.h>
+#include "needle_hip.h"
+
+#define NATIVE(ret, name) JNIEXPORT ret JNICALL Java_com_justinblank_strings_gpu_Native_##name
+
+NATIVE(jstring, lastError)(JNIEnv *env, jclass c) { return (*env)->NewStringUTF(env, needle_last_error()); }
+NATIVE(jint, deviceCount)(JNIEnv *env, jclass c) { return needle_device_count(); }
+
+NATIVE(jint, compile)(JNIEnv *env, jclass c, jcharArray regex, jint flags, jlongArray out) {
+    jsize n = (*env)->GetArrayLength(env, regex);
+    jchar *u = (*env)->GetCharArrayElements(env, regex, NULL);
+    needle_pattern *p = NULL;
+    int rc = needle_compile((const uint16_t *)u, (size_t)n, flags, &p);
+    (*env)->ReleaseCharArrayElements(env, regex, u, JNI_ABORT);
+    jlong h = (jlong)(intptr_t)p;
+    (*env)->SetLongArrayRegion(env, out, 0, 1, &h);
+    return rc;
+}
+
+NATIVE(jint, fromTables)(JNIEnv *env, jclass c, jbyteArray classMap, jint stride, jintArray nStates, jintArray maxChar,
+                         jobjectArray tables, jobjectArray accepting, jint fixedLen, jlongArray out) {
+    needle_table_desc d;
+    memset(&d, 0, sizeof(d));
+    jint ns[4], mc[4];
+    (*env)->GetIntArrayRegion(env, nStates, 0, 4, ns);
+    (*env)->GetIntArrayRegion(env, maxChar, 0, 4, mc);
+    jbyte *cm = (*env)->GetByteArrayElements(env, classMap, NULL);
+    needle_dfa_desc *ds[4] = {&d.matches, &d.contained_in, &d.forwards, &d.backwards};
+    jshortArray ta[4];
+    jbyteArray aa[4];
+    jshort *tp[4];
+    jbyte *ap[4];
+    for (int i = 0; i < 4; i++) {
+        ta[i] = (jshortArray)(*env)->GetObjectArrayElement(env, tables, i);
+        aa[i] = (jbyteArray)(*env)->GetObjectArrayElement(env, accepting, i);
+        tp[i] = (*env)->GetShortArrayElements(env, ta[i], NULL);
+        ap[i] = (*env)->GetByteArrayElements(env, aa[i], NULL);
+        ds[i]->n_states = ns[i];
+        ds[i]->max_char = mc[i];
+        ds[i]->table = (const int16_t *)tp[i];
+        ds[i]->accepting = (const uint8_t *)ap[i];
+    }
+    d.class_map = (const uint8_t *)cm;
+    d.stride = stride;
+    d.fixed_len = fixedLen;
+    needle_pattern *p = NULL;
+    int rc = needle_pattern_from_tables(&d, &p); /* copies everything it needs */
+    for (int i = 0; i < 4; i++) {
+        (*env)->ReleaseShortArrayElements(env, ta[i], tp[i], JNI_ABORT);
+        (*env)->ReleaseByteArrayElements(env, aa[i], ap[i], JNI_ABORT);
+    }
+    (*env)->ReleaseByteArrayElements(env, classMap, cm, JNI_ABORT);
+    jlong h = (jlong)(intptr_t)p;
+    (*env)->SetLongArrayRegion(env, out, 0, 1, &h);
+    return rc;
+}
+
+NATIVE(void, destroyPattern)(JNIEnv *env, jclass c, jlong h) { needle_pattern_destroy((needle_pattern *)(intptr_t)h); }
+
+static void view_of(JNIEnv *env, needle_batch_view *v, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths) {
+    memset(v, 0, sizeof(*v));
+    v->rows = (*env)->GetDirectBufferAddress(env, rows);
+    v->char_width = (uint32_t)cw;
+    v->n_rows = (uint64_t)n;
+    v->row_stride = (uint64_t)stride;
+    v->row_len = (uint32_t)rowLen;
+    v->lengths = lengths ? (const uint32_t *)(*env)->GetDirectBufferAddress(env, lengths) : NULL;
+}
+
+static jint bitmap_call(JNIEnv *env, int which, jlong h, needle_batch_view *v, jlongArray bitmap, jintArray start, jintArray end) {
+    jlong *bm = (*env)->GetLongArrayElements(env, bitmap, NULL);
+    jint *s = start ? (*env)->GetIntArrayElements(env, start, NULL) : NULL;
+    jint *e = end ? (*env)->GetIntArrayElements(env, end, NULL) : NULL;
+    const needle_pattern *p = (const needle_pattern *)(intptr_t)h;
+    int rc = which == 0 ? needle_matches_host(p, v, (uint64_t *)bm)
+           : which == 1 ? needle_contained_in_host(p, v, (uint64_t *)bm)
+                        : needle_find_host(p, v, (uint64_t *)bm, (int32_t *)s, (int32_t *)e);
+    (*env)->ReleaseLongArrayElements(env, bitmap, bm, 0);
+    if (s) (*env)->ReleaseIntArrayElements(env, start, s, 0);
+    if (e) (*env)->ReleaseIntArrayElements(env, end, e, 0);
+    return rc;
+}
+
+NATIVE(jint, matchesHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jlongArray bitmap) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    return bitmap_call(env, 0, h, &v, bitmap, NULL, NULL);
+}
+NATIVE(jint, containedInHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jlongArray bitmap) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    return bitmap_call(env, 1, h, &v, bitmap, NULL, NULL);
+}
+NATIVE(jint, findHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jlongArray bitmap, jintArray start, jintArray end) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    return bitmap_call(env, 2, h, &v, bitmap, start, end);
+}
+
+NATIVE(jint, matcherCreate)(JNIEnv *env, jclass c, jlong pattern, jcharArray s, jlongArray out) {
+    jsize n = (*env)->GetArrayLength(env, s);
+    jchar *u = (*env)->GetCharArrayElements(env, s, NULL);
+    needle_matcher *m = NULL;
+    int rc = needle_matcher_create((const needle_pattern *)(intptr_t)pattern, (const uint16_t *)u, (size_t)n, &m);
+    (*env)->ReleaseCharArrayElements(env, s, u, JNI_ABORT);
+    jlong h = (jlong)(intptr_t)m;
+    (*env)->SetLongArrayRegion(env, out, 0, 1, &h);
+    return rc;
+}
+NATIVE(void, matcherDestroy)(JNIEnv *env, jclass c, jlong m) { needle_matcher_destroy((needle_matcher *)(intptr_t)m); }
+
+#define BOOL_CALL(jname, cname)                                                        \
+    NATIVE(jint, jname)(JNIEnv *env, jclass c, jlong m, jintArray r) {                 \
+        int v = 0;                                                                     \
+        int rc = cname((needle_matcher *)(intptr_t)m, &v);                             \
+        jint jv = v;                                                                   \
+        (*env)->SetIntArrayRegion(env, r, 0, 1, &jv);                                  \
+        return rc;                                                                     \
+    }
+BOOL_CALL(matcherMatches, needle_matcher_matches)
+BOOL_CALL(matcherContainedIn, needle_matcher_contained_in)
+BOOL_CALL(matcherFind, needle_matcher_find)
+
+NATIVE(jint, matcherFindRange)(JNIEnv *env, jclass c, jlong m, jint from, jint to, jintArray r) {
+    int v = 0;
+    int rc = needle_matcher_find_range((needle_matcher *)(intptr_t)m, from, to, &v);
+    jint jv = v;
+    (*env)->SetIntArrayRegion(env, r, 0, 1, &jv);
+    return rc;
+}
+NATIVE(jint, matcherStart)(JNIEnv *env, jclass c, jlong m) { return needle_matcher_start((const needle_matcher *)(intptr_t)m); }
+NATIVE(jint, matcherEnd)(JNIEnv *env, jclass c, jlong m) { return needle_matcher_end((const needle_matcher *)(intptr_t)m); }

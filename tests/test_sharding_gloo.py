@@ -1,0 +1,89 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo process groups exercising needle_amd/sharding.py -- contiguous
+row blocks on 64-row boundaries, the bitmap / per-row gathers to rank 0 -- against the unsharded CPU oracle.
+(The per-shard verdicts come from the oracle here; on the GPU box the same code path carries kernel output.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_snapshot
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _pack(bits):
+    pad = (-len(bits)) % 64
+    b = np.concatenate([bits.astype(np.uint8), np.zeros(pad, dtype=np.uint8)])
+    return torch.from_numpy(np.packbits(b, bitorder="little").view(np.int64).copy())
+
+
+def _worker(rank, world, port, total_rows, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from needle_amd import workload as W
+        from needle_amd.sharding import gather_bitmap, gather_rows, shard_range
+        from oracle.walker import OraclePattern
+        o = OraclePattern.from_fixture(load_snapshot("DigitPlus"), backwards_as_dfa=True)
+        row0, n = shard_range(total_rows, world, rank)
+        assert row0 % 64 == 0 or n == 0
+        rows = W.digits_batch(np, row0, n, 64) if n else np.zeros((0, 64), dtype=np.uint8)
+        bits = o.batch_contained_in(rows) if n else np.zeros(0, dtype=bool)
+        m, s, e = o.batch_find(rows) if n else (bits, np.zeros(0, np.int32), np.zeros(0, np.int32))
+        full = gather_bitmap(_pack(bits), total_rows, world, rank)
+        ends = gather_rows(torch.from_numpy(e.astype(np.int32)), total_rows, world, rank)
+        if rank == 0:
+            q.put((full.numpy().copy(), ends.numpy().copy()))
+        else:
+            assert full is None and ends is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total_rows", [(2, 1000), (3, 64 * 7 + 5), (2, 1)])
+def test_row_sharding_and_gather(world, total_rows, oracle_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total_rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, ends = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    from needle_amd import workload as W
+    from needle_amd.pattern import unpack_bitmap
+    from oracle.walker import OraclePattern
+    o = OraclePattern.from_fixture(load_snapshot("DigitPlus"), backwards_as_dfa=True)
+    rows = W.digits_batch(np, 0, total_rows, 64)
+    want = o.batch_contained_in(rows)
+    assert full.shape[0] == (total_rows + 63) // 64
+    assert (unpack_bitmap(full, total_rows) == want).all()
+    _, _, e = o.batch_find(rows)
+    assert (ends == e).all()
+
+
+def test_shard_ranges_partition_the_batch():
+    from needle_amd.sharding import shard_range
+    for total in (0, 1, 63, 64, 65, 1000, 10_000_000, 80_000_000):
+        for world in (1, 2, 4, 8):
+            nxt = 0
+            for r in range(world):
+                row0, n = shard_range(total, world, r)
+                assert row0 == min(nxt, total) and n >= 0
+                assert row0 % 64 == 0 or n == 0
+                nxt = row0 + n
+            assert nxt == total
