@@ -15,7 +15,7 @@
 
 namespace needle {
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
-int waves_for_lds_bytes(uint32_t prog_lds_bytes);
+bool shape_for_lds_bytes(uint32_t prog_lds_bytes, int *waves, int *chb);
 } // namespace needle
 
 using namespace needle;
@@ -45,7 +45,8 @@ struct DevProgram {
 struct needle_pattern {
     RefTables t;
     std::mutex mu;
-    // (device, which, char_width, global_walk) -> program resident in that device's HBM
+    // (device, which, char_width, variant) -> program resident in that device's HBM
+    // variant: 0 plain, 1 global-walk layout (backward automaton of find), 2 forward + backward column maps
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
     ~needle_pattern() {
@@ -54,9 +55,9 @@ struct needle_pattern {
     }
 };
 
-static constexpr size_t kMaxProgLds = 160u * 1024u - 4u * kTileBytes; // smallest workgroup shape: 4 waves
+static constexpr size_t kMaxProgLds = kMaxProgLdsBytes;
 
-static int get_program(needle_pattern *p, int which, int cw, bool global_walk, const DevProgram **out, int *n_cus) {
+static int get_program(needle_pattern *p, int which, int cw, int variant, const DevProgram **out, int *n_cus) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(p->mu);
@@ -66,11 +67,11 @@ static int get_program(needle_pattern *p, int which, int cw, bool global_walk, c
         p->cus[dev] = prop.multiProcessorCount;
     }
     if (n_cus) *n_cus = p->cus[dev];
-    auto key = std::make_tuple(dev, which, cw, global_walk ? 1 : 0);
+    auto key = std::make_tuple(dev, which, cw, variant);
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        dp.prog = lower(p->t, (Which)which, cw, kMaxProgLds, global_walk);
+        dp.prog = lower(p->t, (Which)which, cw, kMaxProgLds, variant == 1, variant == 2);
         HIP_TRY(hipMalloc((void **)&dp.d_blob, dp.prog.blob.size()));
         HIP_TRY(hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice));
         it = p->cache.emplace(key, std::move(dp)).first;
@@ -106,7 +107,8 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     const int which = op == OP_MATCHES ? W_MATCHES : op == OP_CONTAINED_IN ? W_CONTAINED_IN : W_FORWARDS;
     const DevProgram *fp = nullptr, *bp = nullptr;
     int n_cus = 0;
-    rc = get_program(p, which, (int)v->char_width, false, &fp, &n_cus);
+    const bool need_backward = op == OP_FIND && p->t.fixed_len < 0;
+    rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
     ScanArgs a;
     memset(&a, 0, sizeof(a));
@@ -122,7 +124,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     if (op == OP_FIND) {
         a.fixed_len = p->t.fixed_len;
         if (a.fixed_len < 0) {
-            rc = get_program(p, W_BACKWARDS, (int)v->char_width, true, &bp, nullptr);
+            rc = get_program(p, W_BACKWARDS, (int)v->char_width, 1, &bp, nullptr);
             if (rc) return rc;
             a.bprog = bp->d_blob;
             a.bhdr = bp->prog.hdr;

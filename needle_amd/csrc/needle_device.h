@@ -9,7 +9,8 @@ enum Op : int { OP_MATCHES = 0, OP_CONTAINED_IN = 1, OP_FIND = 2 };
 
 // How a lowered automaton is walked on the device.
 enum Mode : int {
-    MODE_NIBBLE = 0,  // <= 8 states: per-char transition FUNCTION packed 4 bits/state in one dword (no dependent LDS lookup)
+    MODE_PACK = 0,    // <= 6 states: per-char transition FUNCTION packed 5 bits/state in one dword; the state IS the
+                      // bit offset of its field, so a transition is one v_bfe_u32 and no dependent LDS lookup
     MODE_TABLE8 = 1,  // [state][column] uint8 next-state table in LDS
     MODE_TABLE16 = 2, // [state][column] uint16 next-state table in LDS
     MODE_GLOBAL = 3,  // uint16 table too large for LDS: walked out of HBM/L2
@@ -29,14 +30,19 @@ struct ProgHeader {
     uint32_t root_accepting;
     uint32_t lds_bytes;  // bytes of the blob that the kernel stages in LDS (0 for MODE_GLOBAL table part)
     // byte offsets inside the blob (all 16-byte aligned); 0xFFFFFFFF = absent
-    uint32_t off_f;      // MODE_NIBBLE: uint32 F[] -- char_width 1: 257 entries indexed by byte (256 = PAD);
+    uint32_t off_f;      // MODE_NIBBLE: uint32 F[] -- char_width 1: F[byte][32], one copy per LDS bank so that lane l
+                         //              always reads bank l & 31 (no bank conflicts whatever the text);
                          //              char_width 2: n_cols entries indexed by column
+    uint32_t pad_f;      // MODE_NIBBLE: F of the PAD column (selected in registers for chars past the row length)
     uint32_t off_cmap;   // char_width 1 table modes: uint8 column[256]
     uint32_t off_ptab;   // char_width 2: uint8 page_of[256] (high byte -> page)
     uint32_t off_pages;  // char_width 2: uint8 column[n_pages][256]
     uint32_t off_table;  // table modes: next-state table [n_states][n_cols]
     uint32_t n_pages;
     uint32_t pad_col;    // column index of PAD (= n_cols - 1)
+    // OP_FIND forward programs also carry the BACKWARD automaton's char -> column maps (staged in LDS with the
+    // rest; the backward table itself is walked out of HBM/L2)
+    uint32_t off_bcmap, off_bptab, off_bpages;
 };
 
 struct ScanArgs {
@@ -56,8 +62,17 @@ struct ScanArgs {
     int32_t *end;
 };
 
+// Fixed LDS byte offsets of the forward automaton (compile-time so that they fold into ds_read immediates).
+//   char_width 1:  packed: F[256] u32 at 0                      table modes: cmap16[256] at 0, table at 512
+//   char_width 2:  ptab16[256] at 0 (page * 256);  packed: F[64] u32 at 512, pages8 (col * 4) at 768
+//                                                  table modes: pages8 (col * elem) at 512, table at hdr.off_table
+constexpr uint32_t kLdsF1 = 0, kLdsCmap1 = 0, kLdsTable1 = 512;
+constexpr uint32_t kLdsPtab2 = 0, kLdsF2 = 512;
+// pages base differs by mode; the kernel selects with kLdsPages2 below through the MODE it is instantiated for
+constexpr uint32_t kLdsPages2Pack = 768, kLdsPages2Table = 512;
+
 constexpr int kWavesPerBlock = 16;     // 1024 threads: one workgroup per CU shares one LDS copy of the tables
-constexpr int kChunkBytes = 128;       // bytes of each row staged per step (one full 128-B line per row)
-constexpr int kTileBytes = 64 * kChunkBytes;  // 64 rows (one per lane) x 128 B = 8 KiB per wave
+// Largest automaton footprint that still leaves room for the smallest workgroup shape (4 waves x 64 rows x 64 B).
+constexpr uint32_t kMaxProgLdsBytes = 160u * 1024u - 4u * 64u * 64u;
 
 } // namespace needle

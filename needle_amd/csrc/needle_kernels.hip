@@ -1,18 +1,22 @@
 // Hand-written gfx950 (CDNA4) kernels for needle's DFA table-walk hot path.
 //
-// One haystack ("row") per lane, 64 rows per wavefront step, 16 wavefronts per workgroup sharing one
-// LDS copy of the lowered automaton.  Per step a wave stages a 64-row x 128-byte tile with eight
-// `global_load_lds_dwordx4` (HBM -> LDS DMA, 16 B/lane, each 8 lanes covering one full 128-B line of one
-// row => fully coalesced), with the SOURCE address XOR-swizzled so that the following per-lane row reads
-// (ds_read_b128, row stride 128 B) are bank-conflict free.  Latency is hidden by occupancy: 16 waves x
-// 8 KiB tiles per CU in flight, no intra-wave software pipeline (hipcc drains an LDS-DMA with vmcnt(0)
-// before any may-alias ds_read anyway).
+// One haystack ("row") per lane, 64 rows per wavefront step, up to 16 wavefronts per workgroup sharing ONE LDS
+// copy of the lowered automaton, one workgroup per CU, persistent over 64-row groups.
+//
+// Data movement per wave and step ("tile" = 64 rows x CHB bytes, CHB = 128 or 64):
+//   HBM --global_load_dwordx4 (16 B/lane; CHB/16 adjacent lanes cover one contiguous CHB-byte piece of one row,
+//        i.e. whole 128-B lines for CHB = 128: fully coalesced)--> VGPRs (the NEXT tile, prefetched while the
+//        current one is walked) --ds_write_b128 (lane-linear, conflict-free)--> LDS tile
+//        --ds_read_b128 (each lane its own row; the global SOURCE piece index is XOR-swizzled so that these
+//        row-strided reads hit 16 distinct 16-B bank slots per 16-lane service group)--> per-char walk.
+// Register staging (instead of global_load_lds DMA) is what lets a wave keep a full tile of HBM reads in flight
+// while it walks the previous one: in-flight bytes are not capped by the LDS tile buffers.
 //
 // The loops restated here (reference: needle-compiler/src/main/java/com/justinblank/strings/
 // DFAClassBuilder.java): matches() :892-910, containedIn() :1004-1022, indexForwards() :438-468,
-// indexBackwards() :565-583, find() :629-657.  Dead state (-1), the `c > maxChar` exits and "index
-// past the row length" are folded into the lowered tables on the host (needle_lower.cpp): sink state 0,
-// OVER and PAD columns -- so the inner loops here are branch-free lookups.
+// indexBackwards() :565-583, find() :629-657.  Dead state (-1), the `c > maxChar` exits and "index past the row
+// length" are folded into the lowered tables on the host (needle_lower.cpp): sink state 0, OVER and PAD columns
+// -- so the inner loops here are branch-free lookups.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
@@ -22,25 +26,45 @@ namespace needle {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-typedef __attribute__((address_space(1))) const void gvoid_t;
-typedef __attribute__((address_space(3))) void lvoid_t;
+// native 16-byte vector (a first-class SSA value: tiles held across loop iterations stay in VGPRs; HIP's uint4
+// wrapper struct gets demoted to scratch when it is conditionally re-assigned)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void stage_tile(const uint8_t *rows, uint64_t row0, uint64_t n_rows, uint64_t stride_bytes,
-                                           uint64_t total_bytes, uint32_t byte_off, unsigned char *buf, int lane) {
+template <int CHB>
+struct Geom {
+    static constexpr int kPieces = CHB / 16;         // 16-B pieces per row chunk: 8 | 4
+    static constexpr int kRowsPerInstr = 64 / kPieces; // rows covered by one wave-wide 16 B/lane load: 8 | 16
+    static constexpr int kInstrs = 64 / kRowsPerInstr; // loads per lane per tile: 8 | 4
+    static constexpr int kTileBytes = 64 * CHB;
+    // bank-slot swizzle of tile row r (see header comment): distinct for the rows one ds_read_b128 lane group touches
+    __device__ static __forceinline__ int swz(int r) { return CHB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+};
+
+template <int CHB>
+__device__ __forceinline__ void load_tile(u32x4 (&R)[Geom<CHB>::kInstrs], const uint8_t *rows, uint64_t row0, uint64_t n_rows,
+                                          uint64_t stride_bytes, uint64_t total_bytes, uint32_t byte_off, int lane) {
+    using G = Geom<CHB>;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = j * 8 + (lane >> 3);          // tile row this lane's 16 B land in
-        const int kk = (lane & 7) ^ ((r >> 1) & 7); // which 16-B piece of the row's 128-B chunk goes there
+    for (int j = 0; j < G::kInstrs; ++j) {
+        const int r = j * G::kRowsPerInstr + lane / G::kPieces;   // tile row this lane's 16 B belong to
+        const int kk = (lane % G::kPieces) ^ G::swz(r);           // which piece of the row chunk it fetches
         uint64_t row = row0 + (uint64_t)r;
         if (row >= n_rows) row = n_rows - 1;
         uint64_t off = row * stride_bytes + byte_off + (uint32_t)(kk * 16);
         if (off > total_bytes - 16) off = total_bytes - 16;
-        __builtin_amdgcn_global_load_lds((gvoid_t *)(rows + off), (lvoid_t *)(buf + j * 1024), 16, 0, 0);
+        R[j] = *(const u32x4 *)(rows + off);
     }
 }
 
-__device__ __forceinline__ uint4 tile_piece(const unsigned char *buf, int lane, int kk) {
-    return *(const uint4 *)(buf + lane * kChunkBytes + ((kk ^ ((lane >> 1) & 7)) << 4));
+template <int CHB>
+__device__ __forceinline__ void store_tile(const u32x4 (&R)[Geom<CHB>::kInstrs], unsigned char *buf, int lane) {
+#pragma unroll
+    for (int j = 0; j < Geom<CHB>::kInstrs; ++j) *(u32x4 *)(buf + j * 1024 + lane * 16) = R[j];
+}
+
+template <int CHB>
+__device__ __forceinline__ u32x4 tile_piece(const unsigned char *buf, int lane, int kk) {
+    return *(const u32x4 *)(buf + lane * CHB + ((kk ^ Geom<CHB>::swz(lane)) << 4));
 }
 
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
@@ -52,119 +76,197 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
-// Pointers into the LDS (or global) copy of a lowered automaton.
-struct ProgView {
-    const uint32_t *f;
-    const uint8_t *cmap;
-    const uint8_t *ptab;
-    const uint8_t *pages;
-    const uint8_t *t8;
-    const uint16_t *t16;
-    uint32_t n_cols, pad_col, accept_lo;
+// ---- one-instruction byte/word extraction (SDWA operand selects): the walk is VALU-issue bound (one wave
+// instruction per ~4 cycles per SIMD), so every per-char VALU instruction saved is throughput.
+template <int K>
+__device__ __forceinline__ uint32_t shl_byte(uint32_t w, uint32_t sh) { // (byte K of w) << sh
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh), "v"(w));
+    if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(sh), "v"(w));
+    if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(sh), "v"(w));
+    if (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(sh), "v"(w));
+    return r;
+}
+template <int K>
+__device__ __forceinline__ uint32_t or_byte(uint32_t a, uint32_t w) { // a | (byte K of w)
+    uint32_t r;
+    if (K == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(w));
+    if (K == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(w));
+    if (K == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(w));
+    if (K == 3) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+
+// LDS reads at an ABSOLUTE LDS byte address through address-space-3 pointers.  The dynamic segment starts at LDS
+// address 0 (this file declares no static __shared__; scan_kernel traps if that ever changes), so table offsets
+// are plain immediates: going through `smem` costs a `v_add 0` (late-resolved symbol) per access, going through
+// generic pointers a null-check v_cndmask on top.
+#define NEEDLE_LDS(T) __attribute__((address_space(3))) const T *
+__device__ __forceinline__ uint32_t lds_u8(uint32_t a) { return *(NEEDLE_LDS(uint8_t))(uintptr_t)(a); }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *(NEEDLE_LDS(uint16_t))(uintptr_t)(a); }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(NEEDLE_LDS(uint32_t))(uintptr_t)(a); }
+
+// Walk constants a lane keeps in registers (see the fixed LDS layout in needle_device.h).
+struct Walk {
+    uint32_t ncols_e;   // table modes: row stride in BYTES of the next-state table (n_cols * element size)
+    uint32_t pad_e;     // table modes: PAD column * element size;  packed mode: F of the PAD column
+    uint32_t table_off; // char_width 2 table modes: LDS byte offset of the table
+    const uint16_t *gtable; // MODE_GLOBAL
 };
 
 template <int CW>
-__device__ __forceinline__ uint32_t column_of(const ProgView &pv, uint32_t c) {
-    if (CW == 1) return pv.cmap[c];
-    return pv.pages[((uint32_t)pv.ptab[c >> 8] << 8) | (c & 255u)];
+__device__ __forceinline__ uint32_t column_of(const uint8_t *cmap, const uint8_t *ptab, const uint8_t *pages, uint32_t c) {
+    if (CW == 1) return cmap[c];
+    return pages[((uint32_t)ptab[c >> 8] << 8) | (c & 255u)];
 }
 
-// One transition.  `st` is 4*state in MODE_NIBBLE, the state id otherwise.
-template <int MODE, int CW, bool GUARD>
-__device__ __forceinline__ uint32_t step(const ProgView &pv, uint32_t st, uint32_t c, bool in_row) {
-    if (MODE == MODE_NIBBLE) {
-        uint32_t F;
-        if (CW == 1) {
-            uint32_t i = GUARD ? (in_row ? c : 256u) : c;
-            F = pv.f[i];
-        } else {
-            uint32_t col = column_of<2>(pv, c);
-            if (GUARD) col = in_row ? col : pv.pad_col;
-            F = pv.f[col];
-        }
-        return __builtin_amdgcn_ubfe(F, st, 4) << 2;
+// One transition on char number K (0..3 for bytes, 0..1 for UTF-16 units) of dword w.
+// st: 5 * state in MODE_PACK (the bit offset of the state's field), the state id otherwise.
+template <int MODE, int CW, bool GUARD, int K>
+__device__ __forceinline__ uint32_t step(const Walk &wk, uint32_t st, uint32_t w, bool in_row) {
+    uint32_t col; // packed mode: F;  table modes: column * element size
+    if (CW == 1) {
+        if (MODE == MODE_PACK) col = lds_u32(shl_byte<K>(w, 2) + kLdsF1);
+        else col = lds_u16(shl_byte<K>(w, 1) + kLdsCmap1);
     } else {
-        uint32_t col = column_of<CW>(pv, c);
-        if (GUARD) col = in_row ? col : pv.pad_col;
-        const uint32_t i = st * pv.n_cols + col;
-        if (MODE == MODE_TABLE8) return pv.t8[i];
-        return pv.t16[i];
+        const uint32_t pg = lds_u16(shl_byte<(2 * K + 1) & 3>(w, 1) + kLdsPtab2);  // page base = page * 256
+        const uint32_t ce = lds_u8(or_byte<(2 * K) & 3>(pg, w) + (MODE == MODE_PACK ? kLdsPages2Pack : kLdsPages2Table));        // column * 4 (packed) | * element size
+        col = (MODE == MODE_PACK) ? lds_u32(ce + kLdsF2) : ce;
     }
+    if (GUARD) col = in_row ? col : wk.pad_e;
+    if (MODE == MODE_PACK) return __builtin_amdgcn_ubfe(col, st, 5);
+    const uint32_t i = __umul24(st, wk.ncols_e) + col;
+    if (MODE == MODE_GLOBAL) return wk.gtable[i];
+    const uint32_t addr = i + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off);
+    return MODE == MODE_TABLE8 ? lds_u8(addr) : lds_u16(addr);
 }
 
-template <int OP, int CW, int MODE, bool GUARD>
+template <int OP, int CW, int MODE, bool GUARD, int CHB>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArgs a) {
+    using G = Geom<CHB>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    // ---- stage the automaton in LDS (once per workgroup)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_waves = blockDim.x >> 6; // 16, 8 or 4: chosen by the launcher from the automaton's LDS footprint
+
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    // ---- stage the automaton in LDS (once per workgroup)
     for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u)
-        *(uint4 *)(smem + i) = *(const uint4 *)(a.prog + i);
+        *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
     __syncthreads();
 
-    ProgView pv;
-    pv.f = (const uint32_t *)(smem + a.hdr.off_f);
-    pv.cmap = smem + a.hdr.off_cmap;
-    pv.ptab = smem + a.hdr.off_ptab;
-    pv.pages = smem + a.hdr.off_pages;
-    pv.t8 = smem + a.hdr.off_table;
-    pv.t16 = (MODE == MODE_GLOBAL) ? (const uint16_t *)(a.prog + a.hdr.off_table) : (const uint16_t *)(smem + a.hdr.off_table);
-    pv.n_cols = a.hdr.n_cols;
-    pv.pad_col = a.hdr.pad_col;
-    pv.accept_lo = a.hdr.accept_lo;
-    constexpr uint32_t SCALE = (MODE == MODE_NIBBLE) ? 4u : 1u; // state representation scale
+    Walk wk;
+    constexpr uint32_t ELEM = (MODE == MODE_TABLE16) ? 2u : 1u;
+    wk.ncols_e = a.hdr.n_cols * ELEM;
+    wk.pad_e = (MODE == MODE_PACK) ? a.hdr.pad_f : a.hdr.pad_col * ELEM;
+    wk.table_off = a.hdr.off_table;
+    wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
+    constexpr uint32_t SCALE = (MODE == MODE_PACK) ? 5u : 1u; // state representation scale
     const uint32_t accept_lo = a.hdr.accept_lo * SCALE;
     const uint32_t start_state = a.hdr.start * SCALE;
 
-    unsigned char *buf = smem + ((a.hdr.lds_bytes + 15u) & ~15u) + wave * kTileBytes;
+    unsigned char *buf = smem + ((a.hdr.lds_bytes + 15u) & ~15u) + wave * G::kTileBytes;
 
     const uint64_t n_groups = (a.n_rows + 63) >> 6;
-    const uint64_t wave_gid = (uint64_t)blockIdx.x * n_waves + wave;
     const uint64_t wave_cnt = (uint64_t)gridDim.x * n_waves;
-    constexpr int CPP = 16 / CW; // chars per 16-B piece
+    uint64_t g = (uint64_t)blockIdx.x * n_waves + wave;
+    if (g >= n_groups) return;
 
-    for (uint64_t g = wave_gid; g < n_groups; g += wave_cnt) {
-        const uint64_t row0 = g << 6;
-        const uint64_t my_row = row0 + lane;
-        const bool row_ok = my_row < a.n_rows;
-        uint32_t len = 0;
+    // per-lane byte offsets of this lane's 16-B pieces inside a tile's source rows (fixed for the whole launch)
+    uint32_t voff[G::kInstrs];
+#pragma unroll
+    for (int j = 0; j < G::kInstrs; ++j) {
+        const int r = j * G::kRowsPerInstr + lane / G::kPieces;
+        const int kk = (lane % G::kPieces) ^ G::swz(r);
+        voff[j] = (uint32_t)r * (uint32_t)a.stride_bytes + (uint32_t)(kk * 16);
+    }
+    u32x4 R[G::kInstrs];
+    // issue the loads of tile (grp, chunk); the last group clamps rows / the buffer end, all others are 1 SGPR base +
+    // precomputed 32-bit lane offsets (no per-load VALU address math)
+    auto fetch = [&](uint64_t grp, uint32_t chunk) {
+        if (grp + 1 < n_groups) {
+            const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + chunk * CHB;
+#pragma unroll
+            for (int j = 0; j < G::kInstrs; ++j) R[j] = *(const u32x4 *)(base + voff[j]);
+        } else {
+            load_tile<CHB>(R, a.rows, grp << 6, a.n_rows, a.stride_bytes, a.total_bytes, chunk * CHB, lane);
+        }
+    };
+
+    // per-group state
+    uint64_t my_row;
+    bool row_ok;
+    uint32_t len, n_chunks, st;
+    int32_t last;
+    auto begin_group = [&](uint64_t grp) {
+        my_row = (grp << 6) + lane;
+        row_ok = my_row < a.n_rows;
+        len = 0;
         if (row_ok) len = a.lengths ? a.lengths[my_row] : a.row_len;
         const uint32_t max_len = GUARD ? wave_max(len) : a.row_len;
-        const uint32_t n_chunks = (max_len * CW + kChunkBytes - 1) / kChunkBytes;
+        n_chunks = (max_len * CW + CHB - 1) / CHB;
+        if (n_chunks == 0) n_chunks = 1; // empty rows still take one (fully PAD-guarded) step
+        st = start_state;
+        last = -1; // OP_FIND: lastMatch of indexForwards
+        if (OP == OP_FIND && a.hdr.root_accepting) last = 0; // DFAClassBuilder.java:356 (+ first-iteration check :440)
+    };
 
-        uint32_t st = start_state;
-        int32_t last = -1; // OP_FIND: lastMatch of indexForwards
-        if (OP == OP_FIND && a.hdr.root_accepting) last = 0; // DFAClassBuilder.java:356 (+ first-iteration check :440 with index == 0)
+    uint32_t ck = 0;
+    uint32_t pred_exit = 0xFFFFFFFFu; // chunk index after which the previous group left early (prefetch predictor)
+    begin_group(g);
+    fetch(g, 0);
 
-        for (uint32_t ck = 0; ck < n_chunks; ++ck) {
-            stage_tile(a.rows, row0, a.n_rows, a.stride_bytes, a.total_bytes, ck * kChunkBytes, buf, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            uint32_t idx = ck * (kChunkBytes / CW);
+    for (;;) {
+        store_tile<CHB>(R, buf, lane);
+        // prefetch the tile we expect to need next while this one is walked
+        const bool pf_same = (ck + 1 < n_chunks) && (ck < pred_exit);
+        const uint64_t pf_g = pf_same ? g : g + wave_cnt;
+        if (pf_g < n_groups) fetch(pf_g, pf_same ? ck + 1 : 0u);
+        asm volatile("" ::: "memory"); // keep the prefetch issued ahead of the walk
+
+        const uint32_t idx0 = ck * (CHB / CW);           // index of the tile's first char
+        const uint32_t rem = len > idx0 ? len - idx0 : 0; // GUARD: chars of this row inside the tile and beyond
+        int32_t last_rel = -1;                            // OP_FIND: last accepting position inside this tile
+        // ragged find keeps the most live values per char: unroll less there or it spills
+        constexpr int kUnroll = (GUARD && OP == OP_FIND) ? 1 : G::kPieces;
+#pragma unroll kUnroll
+        for (int kk = 0; kk < G::kPieces; ++kk) {
+            const u32x4 v = tile_piece<CHB>(buf, lane, kk);
+            const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
+            const uint32_t p0 = kk * (16 / CW);
+#define NEEDLE_STEP(D, K)                                                                               \
+    {                                                                                                   \
+        const uint32_t pos = p0 + (D) * (4 / CW) + (K);                                                 \
+        st = step<MODE, CW, GUARD, K>(wk, st, w[D], pos < rem);                                         \
+        if (OP == OP_FIND) last_rel = (st >= accept_lo) ? (int32_t)(pos + 1) : last_rel;                \
+    }
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const uint4 v = tile_piece(buf, lane, kk);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-#pragma unroll
-                    for (int b = 0; b < 4 / CW; ++b) {
-                        const uint32_t c = (CW == 1) ? ((w[d] >> (8 * b)) & 0xFFu) : ((w[d] >> (16 * b)) & 0xFFFFu);
-                        st = step<MODE, CW, GUARD>(pv, st, c, idx < len);
-                        ++idx;
-                        if (OP == OP_FIND) last = (st >= accept_lo) ? (int32_t)idx : last;
-                    }
+            for (int d = 0; d < 4; ++d) {
+                NEEDLE_STEP(d, 0)
+                NEEDLE_STEP(d, 1)
+                if (CW == 1) {
+                    NEEDLE_STEP(d, 2)
+                    NEEDLE_STEP(d, 3)
                 }
             }
-            // wave-uniform early exit: every lane has an absorbing verdict (sink, or accepted for containedIn)
-            bool live;
-            if (OP == OP_CONTAINED_IN) live = st < accept_lo;
-            else live = st != 0;
-            if (GUARD) live = live && (idx < len);
-            if (__ballot(live) == 0ull) break;
+#undef NEEDLE_STEP
+        }
+        if (OP == OP_FIND) last = last_rel >= 0 ? (int32_t)idx0 + last_rel : last;
+        const uint32_t idx = idx0 + CHB / CW;
+        // wave-uniform early exit: every lane has an absorbing verdict (sink, or accepted for containedIn)
+        bool live;
+        if (OP == OP_CONTAINED_IN) live = st < accept_lo;
+        else live = st != 0;
+        if (GUARD) live = live && (idx < len);
+        const bool group_done = (__ballot(live) == 0ull) || (ck + 1 >= n_chunks);
+        if (!group_done) {
+            if (!pf_same) // predicted an early exit that did not happen
+                load_tile<CHB>(R, a.rows, g << 6, a.n_rows, a.stride_bytes, a.total_bytes, (ck + 1) * CHB, lane);
+            ++ck;
+            continue;
         }
 
+        // ---- group verdicts
         bool res;
         if (OP == OP_FIND) res = row_ok && (last >= 0);
         else res = row_ok && (st >= accept_lo);
@@ -172,33 +274,43 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         if (lane == 0) a.bitmap[g] = word;
 
         if (OP == OP_FIND) {
-            int32_t s = -1, e = res ? last : -1;
+            int32_t s = -1;
+            const int32_t e = res ? last : -1;
             if (a.fixed_len >= 0) {
                 s = res ? last - a.fixed_len : -1; // DFAClassBuilder.java:640-646
             } else {
-                // indexBackwards(end - 1, 0): DFAClassBuilder.java:536-583, automaton walked out of HBM/L2
-                const uint8_t *bp = a.bprog;
-                const uint8_t *bcmap = bp + a.bhdr.off_cmap, *bptab = bp + a.bhdr.off_ptab, *bpages = bp + a.bhdr.off_pages;
-                const uint16_t *bt = (const uint16_t *)(bp + a.bhdr.off_table);
+                // indexBackwards(end - 1, 0): DFAClassBuilder.java:536-583.  Column map in LDS, row bytes (L2-hot)
+                // fetched 8 at a time, backward table walked out of HBM/L2.
+                const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
+                const uint16_t *bt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
                 const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo;
-                const uint8_t *rowp = a.rows + my_row * a.stride_bytes;
-                int32_t idx = last - 1;
+                const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
+                int32_t idx_b = last - 1;
                 uint32_t bs = a.bhdr.start;
                 int32_t lastb = a.bhdr.root_accepting ? 0 : INT_MAX;
                 bool active = res;
                 while (__ballot(active) != 0ull) {
-                    if (active) {
-                        if (idx < 0) {
-                            active = false;
-                        } else {
-                            const uint32_t c = (CW == 1) ? rowp[idx] : ((const uint16_t *)rowp)[idx];
-                            const uint32_t col = (CW == 1) ? bcmap[c] : bpages[((uint32_t)bptab[c >> 8] << 8) | (c & 255u)];
-                            bs = bt[bs * bcols + col];
-                            if (bs == 0) {
+                    uint32_t cs[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int32_t p = idx_b - k;
+                        cs[k] = 0;
+                        if (active && p >= 0) cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (active) {
+                            if (idx_b < 0) {
                                 active = false;
                             } else {
-                                if (bs >= bacc) lastb = idx;
-                                --idx;
+                                const uint32_t col = column_of<CW>(bcmap, bptab, bpages, cs[k]);
+                                bs = bt[bs * bcols + col];
+                                if (bs == 0) {
+                                    active = false;
+                                } else {
+                                    if (bs >= bacc) lastb = idx_b;
+                                    --idx_b;
+                                }
                             }
                         }
                     }
@@ -210,6 +322,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                 a.end[my_row] = e;
             }
         }
+
+        // ---- next group
+        pred_exit = (ck + 1 < n_chunks) ? ck : 0xFFFFFFFFu;
+        const uint64_t ng = g + wave_cnt;
+        if (ng >= n_groups) break;
+        if (pf_same) // the prefetch went to this group's next chunk: redirect
+            load_tile<CHB>(R, a.rows, ng << 6, a.n_rows, a.stride_bytes, a.total_bytes, 0, lane);
+        g = ng;
+        ck = 0;
+        begin_group(g);
     }
 }
 
@@ -217,34 +339,37 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
 // launcher
 // ------------------------------------------------------------------------------------------------
 struct LaunchShape {
-    int grid, waves;
+    int grid, waves, chb;
     size_t lds;
 };
 
-template <int OP, int CW, int MODE, bool GUARD>
+template <int OP, int CW, int MODE, bool GUARD, int CHB>
 static hipError_t launch_one(const ScanArgs &a, LaunchShape sh, hipStream_t stream) {
-    const int grid = sh.grid;
-    const size_t lds = sh.lds;
-    auto k = scan_kernel<OP, CW, MODE, GUARD>;
-    static thread_local size_t configured = 0;
-    if (lds > configured) {
+    auto k = scan_kernel<OP, CW, MODE, GUARD, CHB>;
+    static thread_local bool configured = false;
+    if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
-        configured = 160 * 1024;
+        configured = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(sh.waves * 64), lds, stream, a);
+    hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.waves * 64), sh.lds, stream, a);
     return hipGetLastError();
+}
+
+template <int OP, int CW, int MODE, bool GUARD>
+static hipError_t launch_h(const ScanArgs &a, LaunchShape sh, hipStream_t s) {
+    return sh.chb == 128 ? launch_one<OP, CW, MODE, GUARD, 128>(a, sh, s) : launch_one<OP, CW, MODE, GUARD, 64>(a, sh, s);
 }
 
 template <int OP, int CW, int MODE>
 static hipError_t launch_g(const ScanArgs &a, bool guard, LaunchShape sh, hipStream_t s) {
-    return guard ? launch_one<OP, CW, MODE, true>(a, sh, s) : launch_one<OP, CW, MODE, false>(a, sh, s);
+    return guard ? launch_h<OP, CW, MODE, true>(a, sh, s) : launch_h<OP, CW, MODE, false>(a, sh, s);
 }
 
 template <int OP, int CW>
 static hipError_t launch_m(const ScanArgs &a, bool guard, LaunchShape sh, hipStream_t s) {
     switch (a.hdr.mode) {
-    case MODE_NIBBLE: return launch_g<OP, CW, MODE_NIBBLE>(a, guard, sh, s);
+    case MODE_PACK: return launch_g<OP, CW, MODE_PACK>(a, guard, sh, s);
     case MODE_TABLE8: return launch_g<OP, CW, MODE_TABLE8>(a, guard, sh, s);
     case MODE_TABLE16: return launch_g<OP, CW, MODE_TABLE16>(a, guard, sh, s);
     default: return launch_g<OP, CW, MODE_GLOBAL>(a, guard, sh, s);
@@ -256,26 +381,32 @@ static hipError_t launch_c(const ScanArgs &a, int cw, bool guard, LaunchShape sh
     return cw == 1 ? launch_m<OP, 1>(a, guard, sh, s) : launch_m<OP, 2>(a, guard, sh, s);
 }
 
-// Workgroup shape: as many waves as the 160 KiB LDS admits next to the automaton (16 -> 8 -> 4), one
-// workgroup per CU, persistent over 64-row groups.
-int waves_for_lds_bytes(uint32_t prog_lds_bytes) {
+// Workgroup shape from the automaton's LDS footprint: keep 16 waves per CU (the latency-hiding budget) and
+// shrink the tile from 128 to 64 bytes per row before giving up waves.
+bool shape_for_lds_bytes(uint32_t prog_lds_bytes, int *waves, int *chb) {
     const size_t p = (prog_lds_bytes + 15u) & ~15u;
-    for (int w = kWavesPerBlock; w >= 4; w >>= 1)
-        if (p + (size_t)w * kTileBytes <= 160u * 1024u) return w;
-    return 0;
+    const size_t cap = 160u * 1024u;
+    const int cand[4][2] = {{16, 128}, {16, 64}, {8, 64}, {4, 64}};
+    for (const auto &c : cand) {
+        if (p + (size_t)c[0] * 64 * c[1] <= cap) {
+            *waves = c[0];
+            *chb = c[1];
+            return true;
+        }
+    }
+    return false;
 }
 
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream) {
     if (a.n_rows == 0) return hipSuccess;
     LaunchShape sh;
-    sh.waves = waves_for_lds_bytes(a.hdr.lds_bytes);
-    if (sh.waves == 0) return hipErrorInvalidValue;
+    if (!shape_for_lds_bytes(a.hdr.lds_bytes, &sh.waves, &sh.chb)) return hipErrorInvalidValue;
     const uint64_t n_groups = (a.n_rows + 63) >> 6;
     uint64_t blocks = (n_groups + sh.waves - 1) / sh.waves;
     if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
     sh.grid = (int)blocks;
-    sh.lds = ((a.hdr.lds_bytes + 15u) & ~15u) + (size_t)sh.waves * kTileBytes;
-    const bool guard = a.lengths != nullptr || ((uint64_t)a.row_len * char_width) % kChunkBytes != 0;
+    sh.lds = ((a.hdr.lds_bytes + 15u) & ~15u) + (size_t)sh.waves * 64 * sh.chb;
+    const bool guard = a.lengths != nullptr || ((uint64_t)a.row_len * char_width) % sh.chb != 0;
     switch (op) {
     case OP_MATCHES: return launch_c<OP_MATCHES>(a, char_width, guard, sh, stream);
     case OP_CONTAINED_IN: return launch_c<OP_CONTAINED_IN>(a, char_width, guard, sh, stream);

@@ -79,7 +79,35 @@ static uint32_t append(std::vector<uint8_t> &blob, const void *src, size_t n) {
     return off;
 }
 
-Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk) {
+// char -> column maps of one automaton: flat uint8[256] for 8-bit rows; page_of[256] + deduplicated pages for UTF-16
+struct ColumnMaps {
+    std::vector<uint8_t> cmap8, ptab, pages;
+};
+static ColumnMaps column_maps(const RefTables &t, const RefDfa &d, int char_width) {
+    const int OVER = t.stride;
+    auto col_of = [&](int c) -> uint8_t { return (uint8_t)(c > d.max_char ? OVER : t.class_map[c]); };
+    ColumnMaps m;
+    m.cmap8.resize(256);
+    m.ptab.resize(256);
+    for (int c = 0; c < 256; ++c) m.cmap8[c] = col_of(c);
+    if (char_width == 2) {
+        std::map<std::vector<uint8_t>, int> seen;
+        for (int hi = 0; hi < 256; ++hi) {
+            std::vector<uint8_t> pg(256);
+            for (int lo = 0; lo < 256; ++lo) pg[lo] = col_of((hi << 8) | lo);
+            auto it = seen.find(pg);
+            if (it == seen.end()) {
+                it = seen.emplace(pg, (int)seen.size()).first;
+                m.pages.insert(m.pages.end(), pg.begin(), pg.end());
+            }
+            m.ptab[hi] = (uint8_t)it->second;
+        }
+    }
+    return m;
+}
+
+Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
+              bool with_backward_maps) {
     const RefDfa &d = t.dfa[which];
     const int N = t.stride;
     const int n_ref = d.n_states;
@@ -121,77 +149,93 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     p.hdr.root_accepting = d.accepting[0] ? 1 : 0;
     p.hdr.pad_col = PAD;
 
-    auto col_of = [&](int c) -> uint8_t { return (uint8_t)(c > d.max_char ? OVER : t.class_map[c]); };
+    const ColumnMaps cm = column_maps(t, d, char_width);
+    p.hdr.n_pages = (uint32_t)(cm.pages.size() / 256);
+
+    if (global_walk) {
+        // backward automaton of find(): only the uint16 table, read from HBM/L2 (its column maps travel inside the
+        // forward program, see below)
+        p.hdr.mode = MODE_GLOBAL;
+        p.hdr.off_table = append(p.blob, next.data(), next.size() * 2);
+        p.hdr.lds_bytes = 0;
+        while (p.blob.size() % 16) p.blob.push_back(0);
+        return p;
+    }
 
     Mode mode;
-    if (global_walk) mode = MODE_GLOBAL;
-    else if (n_dev <= 8) mode = MODE_NIBBLE;
+    if (n_dev <= 6 && (char_width == 1 || n_cols <= 64)) mode = MODE_PACK;
     else if (n_dev <= 256) mode = MODE_TABLE8;
     else mode = MODE_TABLE16;
 
-    // char -> column maps
-    std::vector<uint8_t> cmap8(256), ptab(256), pages;
-    for (int c = 0; c < 256; ++c) cmap8[c] = col_of(c);
-    if (char_width == 2) {
-        std::map<std::vector<uint8_t>, int> seen;
-        for (int hi = 0; hi < 256; ++hi) {
-            std::vector<uint8_t> pg(256);
-            for (int lo = 0; lo < 256; ++lo) pg[lo] = col_of((hi << 8) | lo);
-            auto it = seen.find(pg);
-            if (it == seen.end()) {
-                it = seen.emplace(pg, (int)seen.size()).first;
-                pages.insert(pages.end(), pg.begin(), pg.end());
-            }
-            ptab[hi] = (uint8_t)it->second;
-        }
-        p.hdr.n_pages = (uint32_t)(pages.size() / 256);
-    }
-
-    const size_t maps_bytes = char_width == 1 ? 256 : 256 + pages.size();
-    if (mode == MODE_TABLE8 && maps_bytes + next.size() + 64 > lds_table_budget) mode = MODE_TABLE16; // -> MODE_GLOBAL below
-
-    auto emit_maps = [&]() {
+    ColumnMaps bm;
+    if (with_backward_maps) bm = column_maps(t, t.dfa[W_BACKWARDS], char_width);
+    auto emit_backward_maps = [&]() {
+        if (!with_backward_maps) return;
         if (char_width == 1) {
-            p.hdr.off_cmap = append(p.blob, cmap8.data(), 256);
+            p.hdr.off_bcmap = append(p.blob, bm.cmap8.data(), 256);
         } else {
-            p.hdr.off_ptab = append(p.blob, ptab.data(), 256);
-            p.hdr.off_pages = append(p.blob, pages.data(), pages.size());
+            p.hdr.off_bptab = append(p.blob, bm.ptab.data(), 256);
+            p.hdr.off_bpages = append(p.blob, bm.pages.data(), bm.pages.size());
         }
     };
+    auto put16 = [&](size_t off, uint32_t v) { p.blob[off] = (uint8_t)(v & 255); p.blob[off + 1] = (uint8_t)(v >> 8); };
+    auto put32 = [&](size_t off, uint32_t v) { put16(off, v & 0xFFFF); put16(off + 2, v >> 16); };
 
-    if (mode == MODE_NIBBLE) {
+    if (mode == MODE_PACK) {
+        // F: 5-bit field per state at bit 5*s holding 5*next(s): a transition is v_bfe_u32(F, state_field_offset, 5)
         auto pack = [&](int col) {
             uint32_t F = 0;
-            for (int s = 0; s < n_dev; ++s) F |= (uint32_t)next[(size_t)s * n_cols + col] << (4 * s);
+            for (int s = 0; s < n_dev; ++s) F |= (uint32_t)(5 * next[(size_t)s * n_cols + col]) << (5 * s);
             return F;
         };
-        std::vector<uint32_t> f;
+        p.hdr.pad_f = pack(PAD);
         if (char_width == 1) {
-            f.resize(257);
-            for (int c = 0; c < 256; ++c) f[c] = pack(cmap8[c]);
-            f[256] = pack(PAD);
+            p.blob.assign(1024, 0); // kLdsF1 = 0
+            for (int c = 0; c < 256; ++c) put32(kLdsF1 + 4 * c, pack(cm.cmap8[c]));
         } else {
-            f.resize(n_cols);
-            for (int k = 0; k < n_cols; ++k) f[k] = pack(k);
+            p.blob.assign(kLdsPages2Pack + cm.pages.size(), 0);
+            for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
+            for (int k = 0; k < n_cols; ++k) put32(kLdsF2 + 4 * k, pack(k));
+            for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Pack + i] = (uint8_t)(cm.pages[i] * 4);
         }
-        p.hdr.off_f = append(p.blob, f.data(), f.size() * 4);
-        if (char_width == 2) emit_maps();
-        p.hdr.lds_bytes = (uint32_t)p.blob.size();
-    } else if (mode == MODE_TABLE8) {
-        emit_maps();
-        std::vector<uint8_t> t8(next.size());
-        for (size_t i = 0; i < next.size(); ++i) t8[i] = (uint8_t)next[i];
-        p.hdr.off_table = append(p.blob, t8.data(), t8.size());
+        emit_backward_maps();
         p.hdr.lds_bytes = (uint32_t)p.blob.size();
     } else {
-        emit_maps();
-        const uint32_t maps_end = (uint32_t)((p.blob.size() + 15) & ~(size_t)15);
-        p.hdr.off_table = append(p.blob, next.data(), next.size() * 2);
-        if (mode == MODE_TABLE16 && p.blob.size() <= lds_table_budget) {
-            p.hdr.lds_bytes = (uint32_t)p.blob.size();
-        } else {
+        // table modes: element size 1 (uint8 table, or the HBM-resident uint16 table) or 2 (uint16 table in LDS)
+        auto build = [&](Mode m) {
+            const uint32_t elem = (m == MODE_TABLE16) ? 2u : 1u;
+            p.blob.clear();
+            if (char_width == 1) {
+                p.blob.assign(512, 0); // cmap16 at kLdsCmap1 = 0
+                for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, cm.cmap8[c] * elem);
+            } else {
+                p.blob.assign(kLdsPages2Table + cm.pages.size(), 0);
+                for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
+                for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Table + i] = (uint8_t)(cm.pages[i] * elem);
+            }
+            if (m == MODE_GLOBAL) {
+                emit_backward_maps();
+                while (p.blob.size() % 16) p.blob.push_back(0);
+                p.hdr.lds_bytes = (uint32_t)p.blob.size();
+                p.hdr.off_table = append(p.blob, next.data(), next.size() * 2);
+            } else {
+                if (m == MODE_TABLE8) {
+                    std::vector<uint8_t> t8(next.size());
+                    for (size_t i = 0; i < next.size(); ++i) t8[i] = (uint8_t)next[i];
+                    p.hdr.off_table = append(p.blob, t8.data(), t8.size());
+                } else {
+                    p.hdr.off_table = append(p.blob, next.data(), next.size() * 2);
+                }
+                emit_backward_maps();
+                p.hdr.lds_bytes = (uint32_t)p.blob.size();
+            }
+        };
+        const uint32_t elem = (mode == MODE_TABLE16) ? 2u : 1u;
+        if (char_width == 2 && (uint32_t)n_cols * elem > 255u) mode = MODE_GLOBAL; // pages hold column * elem in a byte
+        build(mode);
+        if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget) {
             mode = MODE_GLOBAL;
-            p.hdr.lds_bytes = global_walk ? 0 : maps_end; // maps stay in LDS, the table is read from HBM/L2
+            build(mode);
         }
     }
     while (p.blob.size() % 16) p.blob.push_back(0);

@@ -41,6 +41,8 @@ bool validate_tables(const RefTables &t, std::string &err);
 // Lower one automaton for `char_width`-byte haystacks.  `lds_table_budget`: bytes of LDS the automaton may
 // take (tables above it are walked out of HBM: MODE_GLOBAL).  `global_walk`: build the plain uint16 layout
 // read from global memory (used for the backward automaton of find()).
-Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk);
+// `with_backward_maps` (W_FORWARDS only): append the backward automaton's char -> column maps to the blob.
+Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
+              bool with_backward_maps = false);
 
 } // namespace needle
