@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libneedle_hip.so")
+LIB_PATH = os.environ.get("NEEDLE_LIB", os.path.join(_HERE, "libneedle_hip.so"))  # NEEDLE_LIB: kernel-variant A/B runs only
 
 NEEDLE_OK, ERR_INVALID, ERR_SYNTAX, ERR_COMPILE, ERR_UNSUPPORTED, ERR_DEVICE = 0, 1, 2, 3, 4, 5
 

@@ -15,7 +15,7 @@
 
 namespace needle {
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
-bool shape_for_lds_bytes(uint32_t prog_lds_bytes, int *waves, int *chb);
+bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows);
 } // namespace needle
 
 using namespace needle;

@@ -57,13 +57,14 @@ struct ScanArgs {
     const uint8_t *bprog;   // OP_FIND: backward program blob (device, walked out of global memory), or nullptr
     ProgHeader bhdr;
     int32_t fixed_len;      // OP_FIND: >= 0 => start = end - fixed_len
+    uint32_t tiles_in_f_rows; // packed mode, 8-bit rows: waves 0..3 keep their tiles inside the F rows' upper halves
     uint64_t *bitmap;
     int32_t *start;
     int32_t *end;
 };
 
 // Fixed LDS byte offsets of the forward automaton (compile-time so that they fold into ds_read immediates).
-//   char_width 1:  packed: F[256] u32 at 0                      table modes: cmap16[256] at 0, table at 512
+//   char_width 1:  packed: F[256][64] u32 at 0 (one copy per lane) table modes: cmap16[256] at 0, table at 512
 //   char_width 2:  ptab16[256] at 0 (page * 256);  packed: F[64] u32 at 512, pages8 (col * 4) at 768
 //                                                  table modes: pages8 (col * elem) at 512, table at hdr.off_table
 constexpr uint32_t kLdsF1 = 0, kLdsCmap1 = 0, kLdsTable1 = 512;

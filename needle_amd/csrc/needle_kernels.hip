@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "needle_device.h"
 
 namespace needle {
@@ -40,31 +42,23 @@ struct Geom {
     __device__ static __forceinline__ int swz(int r) { return CHB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 };
 
-template <int CHB>
-__device__ __forceinline__ void load_tile(u32x4 (&R)[Geom<CHB>::kInstrs], const uint8_t *rows, uint64_t row0, uint64_t n_rows,
-                                          uint64_t stride_bytes, uint64_t total_bytes, uint32_t byte_off, int lane) {
-    using G = Geom<CHB>;
-#pragma unroll
-    for (int j = 0; j < G::kInstrs; ++j) {
-        const int r = j * G::kRowsPerInstr + lane / G::kPieces;   // tile row this lane's 16 B belong to
-        const int kk = (lane % G::kPieces) ^ G::swz(r);           // which piece of the row chunk it fetches
-        uint64_t row = row0 + (uint64_t)r;
-        if (row >= n_rows) row = n_rows - 1;
-        uint64_t off = row * stride_bytes + byte_off + (uint32_t)(kk * 16);
-        if (off > total_bytes - 16) off = total_bytes - 16;
-        R[j] = *(const u32x4 *)(rows + off);
-    }
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+// A wave's LDS tile: 64 rows of CHB bytes at `row_stride` bytes apart (row_stride == CHB for the plain layout; 256
+// when the rows live in the unused upper halves of the packed-mode F rows, see shape_for_program).
+struct Tile {
+    uint32_t store_addr;  // this lane's first store slot: base + (lane / pieces) * row_stride + (lane % pieces) * 16
+    uint32_t store_step;  // rows-per-instruction * row_stride
+    uint32_t row_addr;    // base + lane * row_stride: this lane's own row
+};
+
+__device__ __forceinline__ void store_piece(const Tile &t, int j, u32x4 v) {
+    *(lds_u32x4 *)(uintptr_t)(t.store_addr + j * t.store_step) = v;
 }
 
 template <int CHB>
-__device__ __forceinline__ void store_tile(const u32x4 (&R)[Geom<CHB>::kInstrs], unsigned char *buf, int lane) {
-#pragma unroll
-    for (int j = 0; j < Geom<CHB>::kInstrs; ++j) *(u32x4 *)(buf + j * 1024 + lane * 16) = R[j];
-}
-
-template <int CHB>
-__device__ __forceinline__ u32x4 tile_piece(const unsigned char *buf, int lane, int kk) {
-    return *(const u32x4 *)(buf + lane * CHB + ((kk ^ Geom<CHB>::swz(lane)) << 4));
+__device__ __forceinline__ u32x4 tile_piece(const Tile &t, int lane, int kk) {
+    return *(const lds_u32x4 *)(uintptr_t)(t.row_addr + ((kk ^ Geom<CHB>::swz(lane)) << 4));
 }
 
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
@@ -111,6 +105,7 @@ struct Walk {
     uint32_t ncols_e;   // table modes: row stride in BYTES of the next-state table (n_cols * element size)
     uint32_t pad_e;     // table modes: PAD column * element size;  packed mode: F of the PAD column
     uint32_t table_off; // char_width 2 table modes: LDS byte offset of the table
+    uint32_t lane4;     // lane * 4 (byte 0 of the packed-mode F address)
     const uint16_t *gtable; // MODE_GLOBAL
 };
 
@@ -126,7 +121,9 @@ template <int MODE, int CW, bool GUARD, int K>
 __device__ __forceinline__ uint32_t step(const Walk &wk, uint32_t st, uint32_t w, bool in_row) {
     uint32_t col; // packed mode: F;  table modes: column * element size
     if (CW == 1) {
-        if (MODE == MODE_PACK) col = lds_u32(shl_byte<K>(w, 2) + kLdsF1);
+        // packed mode: F[byte][64 lane copies]: address = byte << 8 | lane * 4, formed by ONE v_perm_b32; every lane
+        // reads its own LDS bank, so the lookup is conflict-free whatever the text looks like
+        if (MODE == MODE_PACK) col = lds_u32(__builtin_amdgcn_perm(w, wk.lane4, 0x0C0C0400u + ((uint32_t)K << 8)) + kLdsF1);
         else col = lds_u16(shl_byte<K>(w, 1) + kLdsCmap1);
     } else {
         const uint32_t pg = lds_u16(shl_byte<(2 * K + 1) & 3>(w, 1) + kLdsPtab2);  // page base = page * 256
@@ -147,7 +144,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_waves = blockDim.x >> 6; // 16, 8 or 4: chosen by the launcher from the automaton's LDS footprint
+    const int n_waves = blockDim.x >> 6; // 16, 12, 8 or 4: chosen by the launcher from the automaton's LDS footprint
 
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
     // ---- stage the automaton in LDS (once per workgroup)
@@ -160,36 +157,81 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     wk.ncols_e = a.hdr.n_cols * ELEM;
     wk.pad_e = (MODE == MODE_PACK) ? a.hdr.pad_f : a.hdr.pad_col * ELEM;
     wk.table_off = a.hdr.off_table;
+    wk.lane4 = (uint32_t)(lane & 31) * 4u; // lanes l and l+32 are served in different LDS passes: 32 copies suffice
     wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
     constexpr uint32_t SCALE = (MODE == MODE_PACK) ? 5u : 1u; // state representation scale
     const uint32_t accept_lo = a.hdr.accept_lo * SCALE;
     const uint32_t start_state = a.hdr.start * SCALE;
 
-    unsigned char *buf = smem + ((a.hdr.lds_bytes + 15u) & ~15u) + wave * G::kTileBytes;
+    // ---- this wave's LDS tile
+    Tile tile;
+    {
+        uint32_t base, row_stride;
+        if (a.tiles_in_f_rows && wave < 4) { // rows in the upper 128 B of F rows wave*64 .. wave*64+63
+            base = kLdsF1 + (uint32_t)wave * 64u * 256u + 128u;
+            row_stride = 256u;
+        } else {
+            const uint32_t first = a.tiles_in_f_rows ? 4u : 0u;
+            base = ((a.hdr.lds_bytes + 15u) & ~15u) + ((uint32_t)wave - first) * G::kTileBytes;
+            row_stride = CHB;
+        }
+        tile.store_addr = base + (uint32_t)(lane / G::kPieces) * row_stride + (uint32_t)(lane % G::kPieces) * 16u;
+        tile.store_step = G::kRowsPerInstr * row_stride;
+        tile.row_addr = base + (uint32_t)lane * row_stride;
+    }
 
     const uint64_t n_groups = (a.n_rows + 63) >> 6;
     const uint64_t wave_cnt = (uint64_t)gridDim.x * n_waves;
     uint64_t g = (uint64_t)blockIdx.x * n_waves + wave;
     if (g >= n_groups) return;
 
-    // per-lane byte offsets of this lane's 16-B pieces inside a tile's source rows (fixed for the whole launch)
-    uint32_t voff[G::kInstrs];
-#pragma unroll
-    for (int j = 0; j < G::kInstrs; ++j) {
-        const int r = j * G::kRowsPerInstr + lane / G::kPieces;
-        const int kk = (lane % G::kPieces) ^ G::swz(r);
-        voff[j] = (uint32_t)r * (uint32_t)a.stride_bytes + (uint32_t)(kk * 16);
-    }
+    // Global address of load j of a tile = uniform base (SGPRs: group start + chunk offset + j * rows-per-load *
+    // stride) + one of TWO per-lane 32-bit offsets: with the XOR swizzle the piece index only depends on the parity
+    // of j (CHB 128) or not on j at all (CHB 64).  No per-load 64-bit VALU math, 2 VGPRs of addressing state.
+    const uint32_t q = (uint32_t)lane >> 4;
+    const uint32_t p_in_row = (uint32_t)(lane % G::kPieces);
+    const uint32_t row_in_instr = (uint32_t)(lane / G::kPieces);
+    const uint32_t o_even = row_in_instr * (uint32_t)a.stride_bytes + 16u * (p_in_row ^ q);
+    const uint32_t o_odd = CHB == 128 ? (row_in_instr * (uint32_t)a.stride_bytes + 16u * (p_in_row ^ q ^ 4u)) : o_even;
+    const uint64_t load_step = (uint64_t)G::kRowsPerInstr * a.stride_bytes;
+
     u32x4 R[G::kInstrs];
-    // issue the loads of tile (grp, chunk); the last group clamps rows / the buffer end, all others are 1 SGPR base +
-    // precomputed 32-bit lane offsets (no per-load VALU address math)
-    auto fetch = [&](uint64_t grp, uint32_t chunk) {
-        if (grp + 1 < n_groups) {
-            const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + chunk * CHB;
+    // Move the tile held in R to LDS and, piece by piece, re-issue each register's load for tile (grp, chunk): the
+    // wave keeps ~kInstrs loads in flight at all times instead of draining to zero at every tile boundary.
+    auto stage_and_fetch = [&](bool do_fetch, uint64_t grp, uint32_t chunk) {
+        if (!do_fetch) {
 #pragma unroll
-            for (int j = 0; j < G::kInstrs; ++j) R[j] = *(const u32x4 *)(base + voff[j]);
-        } else {
-            load_tile<CHB>(R, a.rows, grp << 6, a.n_rows, a.stride_bytes, a.total_bytes, chunk * CHB, lane);
+            for (int j = 0; j < G::kInstrs; ++j) store_piece(tile, j, R[j]);
+            return;
+        }
+        const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + chunk * CHB;
+#pragma unroll
+        for (int j = 0; j < G::kInstrs; ++j) {
+            store_piece(tile, j, R[j]);
+            asm volatile("" ::: "memory"); // keep store j ahead of load j (else all loads hoist: two tiles live)
+            R[j] = *(const u32x4 *)(base + j * load_step + ((j & 1) ? o_odd : o_even));
+            asm volatile("" ::: "memory");
+        }
+    };
+    auto fetch = [&](uint64_t grp, uint32_t chunk) { // plain (re)load of R, no staging
+        const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + chunk * CHB;
+#pragma unroll
+        for (int j = 0; j < G::kInstrs; ++j) R[j] = *(const u32x4 *)(base + j * load_step + ((j & 1) ? o_odd : o_even));
+    };
+    // The last 64-row group may hold fewer than 64 rows and its last chunk may reach past the end of the buffer:
+    // it is fetched with every clamp applied, by the one wave that owns it, outside the pipelined loop.
+    auto fetch_clamped = [&](uint64_t grp, uint32_t chunk) {
+        const uint32_t last_r = (uint32_t)(a.n_rows - 1 - (grp << 6));
+        const uint32_t stride = (uint32_t)a.stride_bytes;
+        const uint8_t *gbase = a.rows + (grp << 6) * a.stride_bytes;
+#pragma unroll
+        for (int j = 0; j < G::kInstrs; ++j) {
+            uint32_t r = (uint32_t)(j * G::kRowsPerInstr) + row_in_instr;
+            const uint32_t kk = p_in_row ^ (uint32_t)G::swz((int)r);
+            r = r < last_r ? r : last_r;
+            uint32_t pb = chunk * CHB + kk * 16u;     // byte offset of the piece inside its row
+            if (pb + 16u > stride) pb = stride - 16u; // keep the 16-byte read inside the row (stride >= 16)
+            R[j] = *(const u32x4 *)(gbase + (r * stride + pb));
         }
     };
 
@@ -211,27 +253,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         if (OP == OP_FIND && a.hdr.root_accepting) last = 0; // DFAClassBuilder.java:356 (+ first-iteration check :440)
     };
 
-    uint32_t ck = 0;
-    uint32_t pred_exit = 0xFFFFFFFFu; // chunk index after which the previous group left early (prefetch predictor)
-    begin_group(g);
-    fetch(g, 0);
-
-    for (;;) {
-        store_tile<CHB>(R, buf, lane);
-        // prefetch the tile we expect to need next while this one is walked
-        const bool pf_same = (ck + 1 < n_chunks) && (ck < pred_exit);
-        const uint64_t pf_g = pf_same ? g : g + wave_cnt;
-        if (pf_g < n_groups) fetch(pf_g, pf_same ? ck + 1 : 0u);
-        asm volatile("" ::: "memory"); // keep the prefetch issued ahead of the walk
-
+    // Walk the tile in LDS (chunk ck of the current group).  Returns true when no lane needs a further chunk.
+    auto walk_tile = [&](uint32_t ck) -> bool {
         const uint32_t idx0 = ck * (CHB / CW);           // index of the tile's first char
         const uint32_t rem = len > idx0 ? len - idx0 : 0; // GUARD: chars of this row inside the tile and beyond
         int32_t last_rel = -1;                            // OP_FIND: last accepting position inside this tile
-        // ragged find keeps the most live values per char: unroll less there or it spills
-        constexpr int kUnroll = (GUARD && OP == OP_FIND) ? 1 : G::kPieces;
+        // ragged rows keep more values live per char: unroll less there or it spills
+        constexpr int kUnroll = GUARD ? (OP == OP_FIND ? 1 : 2) : G::kPieces;
 #pragma unroll kUnroll
         for (int kk = 0; kk < G::kPieces; ++kk) {
-            const u32x4 v = tile_piece<CHB>(buf, lane, kk);
+            const u32x4 v = tile_piece<CHB>(tile, lane, kk);
             const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
             const uint32_t p0 = kk * (16 / CW);
 #define NEEDLE_STEP(D, K)                                                                               \
@@ -252,86 +283,112 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
 #undef NEEDLE_STEP
         }
         if (OP == OP_FIND) last = last_rel >= 0 ? (int32_t)idx0 + last_rel : last;
-        const uint32_t idx = idx0 + CHB / CW;
         // wave-uniform early exit: every lane has an absorbing verdict (sink, or accepted for containedIn)
         bool live;
         if (OP == OP_CONTAINED_IN) live = st < accept_lo;
         else live = st != 0;
-        if (GUARD) live = live && (idx < len);
-        const bool group_done = (__ballot(live) == 0ull) || (ck + 1 >= n_chunks);
-        if (!group_done) {
-            if (!pf_same) // predicted an early exit that did not happen
-                load_tile<CHB>(R, a.rows, g << 6, a.n_rows, a.stride_bytes, a.total_bytes, (ck + 1) * CHB, lane);
-            ++ck;
-            continue;
-        }
+        if (GUARD) live = live && (idx0 + CHB / CW < len);
+        return __ballot(live) == 0ull;
+    };
 
-        // ---- group verdicts
+    // Verdicts of the finished group: bitmap word, and for find() the start index (DFAClassBuilder.java:640-656).
+    auto finish_group = [&](uint64_t grp) {
         bool res;
         if (OP == OP_FIND) res = row_ok && (last >= 0);
         else res = row_ok && (st >= accept_lo);
         const uint64_t word = __ballot(res);
-        if (lane == 0) a.bitmap[g] = word;
-
-        if (OP == OP_FIND) {
-            int32_t s = -1;
-            const int32_t e = res ? last : -1;
-            if (a.fixed_len >= 0) {
-                s = res ? last - a.fixed_len : -1; // DFAClassBuilder.java:640-646
-            } else {
-                // indexBackwards(end - 1, 0): DFAClassBuilder.java:536-583.  Column map in LDS, row bytes (L2-hot)
-                // fetched 8 at a time, backward table walked out of HBM/L2.
-                const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
-                const uint16_t *bt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
-                const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo;
-                const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
-                int32_t idx_b = last - 1;
-                uint32_t bs = a.bhdr.start;
-                int32_t lastb = a.bhdr.root_accepting ? 0 : INT_MAX;
-                bool active = res;
-                while (__ballot(active) != 0ull) {
-                    uint32_t cs[8];
+        if (lane == 0) a.bitmap[grp] = word;
+        if (OP != OP_FIND) return;
+        int32_t s = -1;
+        const int32_t e = res ? last : -1;
+        if (a.fixed_len >= 0) {
+            s = res ? last - a.fixed_len : -1; // :640-646
+        } else {
+            // indexBackwards(end - 1, 0), :536-583.  Column map in LDS, row bytes (L2-hot) fetched 8 at a time,
+            // backward table walked out of HBM/L2.
+            const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
+            const uint16_t *bt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
+            const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo;
+            const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
+            int32_t idx_b = last - 1;
+            uint32_t bs = a.bhdr.start;
+            int32_t lastb = a.bhdr.root_accepting ? 0 : INT_MAX;
+            bool active = res;
+            while (__ballot(active) != 0ull) {
+                uint32_t cs[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int32_t p = idx_b - k;
-                        cs[k] = 0;
-                        if (active && p >= 0) cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
-                    }
+                for (int k = 0; k < 8; ++k) {
+                    const int32_t p = idx_b - k;
+                    cs[k] = 0;
+                    if (active && p >= 0) cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
+                }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (active) {
-                            if (idx_b < 0) {
+                for (int k = 0; k < 8; ++k) {
+                    if (active) {
+                        if (idx_b < 0) {
+                            active = false;
+                        } else {
+                            const uint32_t col = column_of<CW>(bcmap, bptab, bpages, cs[k]);
+                            bs = bt[bs * bcols + col];
+                            if (bs == 0) {
                                 active = false;
                             } else {
-                                const uint32_t col = column_of<CW>(bcmap, bptab, bpages, cs[k]);
-                                bs = bt[bs * bcols + col];
-                                if (bs == 0) {
-                                    active = false;
-                                } else {
-                                    if (bs >= bacc) lastb = idx_b;
-                                    --idx_b;
-                                }
+                                if (bs >= bacc) lastb = idx_b;
+                                --idx_b;
                             }
                         }
                     }
                 }
-                s = res ? lastb : -1;
             }
-            if (row_ok) {
-                a.start[my_row] = s;
-                a.end[my_row] = e;
-            }
+            s = res ? lastb : -1;
         }
+        if (row_ok) {
+            a.start[my_row] = s;
+            a.end[my_row] = e;
+        }
+    };
 
-        // ---- next group
-        pred_exit = (ck + 1 < n_chunks) ? ck : 0xFFFFFFFFu;
-        const uint64_t ng = g + wave_cnt;
-        if (ng >= n_groups) break;
-        if (pf_same) // the prefetch went to this group's next chunk: redirect
-            load_tile<CHB>(R, a.rows, ng << 6, a.n_rows, a.stride_bytes, a.total_bytes, 0, lane);
-        g = ng;
-        ck = 0;
+    // ---- pipelined main loop over every group but the batch's last one
+    const uint64_t last_group = n_groups - 1;
+    if (g < last_group) {
+        uint32_t ck = 0;
+        uint32_t pred_exit = 0xFFFFFFFFu; // chunk after which the previous group left early (prefetch predictor)
         begin_group(g);
+        fetch(g, 0);
+        for (;;) {
+            // stage this tile and prefetch the one we expect to need next while this one is walked
+            const bool pf_same = (ck + 1 < n_chunks) && (ck < pred_exit);
+            const uint64_t pf_g = pf_same ? g : g + wave_cnt;
+            stage_and_fetch(pf_g < last_group, pf_g, pf_same ? ck + 1 : 0u);
+            asm volatile("" ::: "memory"); // keep the prefetch issued ahead of the walk
+            const bool group_done = walk_tile(ck) || (ck + 1 >= n_chunks);
+            if (!group_done) {
+                if (!pf_same) fetch(g, ck + 1); // predicted an early exit that did not happen
+                ++ck;
+                continue;
+            }
+            finish_group(g);
+            pred_exit = (ck + 1 < n_chunks) ? ck : 0xFFFFFFFFu;
+            const uint64_t ng = g + wave_cnt;
+            if (ng >= last_group) {
+                g = ng;
+                break;
+            }
+            if (pf_same) fetch(ng, 0); // the prefetch went to this group's next chunk: redirect
+            g = ng;
+            ck = 0;
+            begin_group(g);
+        }
+    }
+    // ---- the batch's last group (one wave in the grid): clamped loads, no pipelining
+    if (g == last_group) {
+        begin_group(g);
+        for (uint32_t ck = 0; ck < n_chunks; ++ck) {
+            fetch_clamped(g, ck);
+            stage_and_fetch(false, 0, 0);
+            if (walk_tile(ck)) break;
+        }
+        finish_group(g);
     }
 }
 
@@ -381,12 +438,30 @@ static hipError_t launch_c(const ScanArgs &a, int cw, bool guard, LaunchShape sh
     return cw == 1 ? launch_m<OP, 1>(a, guard, sh, s) : launch_m<OP, 2>(a, guard, sh, s);
 }
 
-// Workgroup shape from the automaton's LDS footprint: keep 16 waves per CU (the latency-hiding budget) and
-// shrink the tile from 128 to 64 bytes per row before giving up waves.
-bool shape_for_lds_bytes(uint32_t prog_lds_bytes, int *waves, int *chb) {
-    const size_t p = (prog_lds_bytes + 15u) & ~15u;
+// Workgroup shape from the automaton's LDS footprint: keep 16 waves per CU (the latency-hiding budget) as long as
+// possible.  Packed mode on 8-bit rows is special: its F table is 256 rows x 256 B of which only the lower 128 B
+// (32 lane-bank copies) are used, so the first 4 waves keep their tiles in the upper halves of those rows and the
+// whole 160 KiB holds F + 16 tiles of 8 KiB.
+bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows) {
+    const size_t p = (h.lds_bytes + 15u) & ~15u;
     const size_t cap = 160u * 1024u;
-    const int cand[4][2] = {{16, 128}, {16, 64}, {8, 64}, {4, 64}};
+    *tiles_in_f_rows = 0;
+    static const char *force = getenv("NEEDLE_SHAPE"); // e.g. "16x64" (tuning experiments only)
+    if (force) {
+        int w = 0, c = 0;
+        if (sscanf(force, "%dx%d", &w, &c) == 2 && (c == 64 || c == 128) && w >= 1 && w <= 16 && p + (size_t)w * 64 * c <= cap) {
+            *waves = w;
+            *chb = c;
+            return true;
+        }
+    }
+    if (h.mode == MODE_PACK && char_width == 1 && p + 12u * 8192u <= cap) {
+        *waves = 16;
+        *chb = 128;
+        *tiles_in_f_rows = 1;
+        return true;
+    }
+    static const int cand[6][2] = {{16, 128}, {12, 128}, {16, 64}, {12, 64}, {8, 64}, {4, 64}};
     for (const auto &c : cand) {
         if (p + (size_t)c[0] * 64 * c[1] <= cap) {
             *waves = c[0];
@@ -397,15 +472,18 @@ bool shape_for_lds_bytes(uint32_t prog_lds_bytes, int *waves, int *chb) {
     return false;
 }
 
-hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream) {
-    if (a.n_rows == 0) return hipSuccess;
+hipError_t launch_scan(int op, int char_width, const ScanArgs &a_in, int n_cus, hipStream_t stream) {
+    if (a_in.n_rows == 0) return hipSuccess;
+    ScanArgs a = a_in;
     LaunchShape sh;
-    if (!shape_for_lds_bytes(a.hdr.lds_bytes, &sh.waves, &sh.chb)) return hipErrorInvalidValue;
+    int in_f = 0;
+    if (!shape_for_program(a.hdr, char_width, &sh.waves, &sh.chb, &in_f)) return hipErrorInvalidValue;
+    a.tiles_in_f_rows = (uint32_t)in_f;
     const uint64_t n_groups = (a.n_rows + 63) >> 6;
     uint64_t blocks = (n_groups + sh.waves - 1) / sh.waves;
     if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
     sh.grid = (int)blocks;
-    sh.lds = ((a.hdr.lds_bytes + 15u) & ~15u) + (size_t)sh.waves * 64 * sh.chb;
+    sh.lds = ((a.hdr.lds_bytes + 15u) & ~15u) + (size_t)(sh.waves - (in_f ? 4 : 0)) * 64 * sh.chb;
     const bool guard = a.lengths != nullptr || ((uint64_t)a.row_len * char_width) % sh.chb != 0;
     switch (op) {
     case OP_MATCHES: return launch_c<OP_MATCHES>(a, char_width, guard, sh, stream);

@@ -190,8 +190,9 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         };
         p.hdr.pad_f = pack(PAD);
         if (char_width == 1) {
-            p.blob.assign(1024, 0); // kLdsF1 = 0
-            for (int c = 0; c < 256; ++c) put32(kLdsF1 + 4 * c, pack(cm.cmap8[c]));
+            p.blob.assign(256 * 256, 0); // F[byte][64 lane copies] at kLdsF1 = 0: one private LDS bank per lane
+            for (int c = 0; c < 256; ++c)
+                for (int l = 0; l < 64; ++l) put32(kLdsF1 + 256 * c + 4 * l, pack(cm.cmap8[c]));
         } else {
             p.blob.assign(kLdsPages2Pack + cm.pages.size(), 0);
             for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
