@@ -119,11 +119,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # also under `torch.distributed.run --nproc-per-node 1`
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from needle_amd.sharding import shard_range, gather_bitmap
+    from needle_amd.sharding import shard_range, gather_bitmap_async
     pattern, what, words = make_pattern(args.workload)
     total_rows = args.rows * world if args.scaling == "weak" else args.rows
     row0, n_rows = shard_range(total_rows, world, rank)
@@ -138,13 +140,18 @@ def main():
         res = op(rows)
         ev1.record()
         words_ = res[0] if is_find else res
-        if world > 1:
-            gather_bitmap(words_, total_rows, world, rank)
+        if use_dist:  # async on RCCL's stream, ordered after the kernel: the next step's kernel overlaps with it
+            pending.append(gather_bitmap_async(words_, total_rows, world, rank))
         return res, (ev0, ev1)
 
+    pending = []
+
     def fence():
+        for h in pending:  # every step's bitmap has landed on every rank before the clock stops
+            h.wait()
+        del pending[:]
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -158,7 +165,7 @@ def main():
         events.append(ev)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -212,7 +219,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.workload, pattern, rows)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

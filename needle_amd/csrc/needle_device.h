@@ -43,6 +43,7 @@ struct ProgHeader {
     // OP_FIND forward programs also carry the BACKWARD automaton's char -> column maps (staged in LDS with the
     // rest; the backward table itself is walked out of HBM/L2)
     uint32_t off_bcmap, off_bptab, off_bpages;
+    uint32_t off_btable; // != 0: the backward uint16 table is small and staged in LDS too (else read bprog from HBM/L2)
 };
 
 struct ScanArgs {

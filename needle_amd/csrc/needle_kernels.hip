@@ -307,7 +307,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             // indexBackwards(end - 1, 0), :536-583.  Column map in LDS, row bytes (L2-hot) fetched 8 at a time,
             // backward table walked out of HBM/L2.
             const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
-            const uint16_t *bt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
+            const uint16_t *bt = a.hdr.off_btable ? (const uint16_t *)(smem + a.hdr.off_btable)
+                                                   : (const uint16_t *)(a.bprog + a.bhdr.off_table);
             const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo;
             const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
             int32_t idx_b = last - 1;

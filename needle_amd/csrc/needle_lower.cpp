@@ -177,6 +177,10 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             p.hdr.off_bptab = append(p.blob, bm.ptab.data(), 256);
             p.hdr.off_bpages = append(p.blob, bm.pages.data(), bm.pages.size());
         }
+        // a small backward table rides along in LDS (same layout as the global-walk program: uint16 [n_dev][n_cols])
+        const Program bp = lower(t, W_BACKWARDS, char_width, lds_table_budget, true, false);
+        const size_t tbytes = bp.blob.size() - bp.hdr.off_table;
+        if (tbytes <= 2048) p.hdr.off_btable = append(p.blob, bp.blob.data() + bp.hdr.off_table, tbytes);
     };
     auto put16 = [&](size_t off, uint32_t v) { p.blob[off] = (uint8_t)(v & 255); p.blob[off + 1] = (uint8_t)(v >> 8); };
     auto put32 = [&](size_t off, uint32_t v) { put16(off, v & 0xFFFF); put16(off + 2, v >> 16); };
