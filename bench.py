@@ -120,6 +120,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ  # also under `torch.distributed.run --nproc-per-node 1`
+    if world > 1:
+        # the scan kernel is one persistent workgroup per CU that owns the CU's whole LDS; leave a few CUs free so
+        # that the RCCL kernel gathering the PREVIOUS step's bitmap can run next to it instead of behind it
+        os.environ.setdefault("NEEDLE_RESERVE_CUS", "4")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -482,6 +482,11 @@ hipError_t launch_scan(int op, int char_width, const ScanArgs &a_in, int n_cus, 
     a.tiles_in_f_rows = (uint32_t)in_f;
     const uint64_t n_groups = (a.n_rows + 63) >> 6;
     uint64_t blocks = (n_groups + sh.waves - 1) / sh.waves;
+    // One persistent workgroup per CU owns the whole CU (LDS); NEEDLE_RESERVE_CUS=k leaves k CUs to kernels that
+    // must run CONCURRENTLY (the RCCL gather of the previous step's bitmap): otherwise that kernel steals a CU
+    // from a statically partitioned launch and the whole step finishes late.
+    static const int reserve = getenv("NEEDLE_RESERVE_CUS") ? atoi(getenv("NEEDLE_RESERVE_CUS")) : 0;
+    if (reserve > 0 && n_cus > reserve + 8) n_cus -= reserve;
     if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
     sh.grid = (int)blocks;
     sh.lds = ((a.hdr.lds_bytes + 15u) & ~15u) + (size_t)(sh.waves - (in_f ? 4 : 0)) * 64 * sh.chb;
