@@ -9,7 +9,12 @@ import os
 import sys
 
 src, rnd, w = sys.argv[1], sys.argv[2], sys.argv[3]
-out = {"workload": w, "round": rnd}
+# FETCH_SIZE -> bytes factor (x 1024 x factor).  2.0 for the 128-byte row pieces (guide value, re-measured here:
+# a known 2.560 GB read reports 1.250e6 KiB).  The 16 x 64-byte shape used when a big table leaves less LDS issues
+# 64-byte requests, for which the same known read reports 1.818e6 KiB -> factor 1.375 (assumes that calibration run
+# itself has no over-fetch; gpurun_out/pmc_c2_cal64 on the build box, numbers quoted in DESIGN.md).
+fetch_factor = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
+out = {"workload": w, "round": rnd, "fetch_size_to_bytes_factor": fetch_factor}
 for r in csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))):
     if "scan_kernel" in r["Name"]:
         out["kernel"] = r["Name"]
@@ -25,7 +30,7 @@ for name, sub, f in (("FETCH_SIZE", "fetch", "f"), ("WRITE_SIZE", "write", "w"))
             vals.append(float(r["Counter_Value"]))
             out["vgpr"], out["sgpr"], out["workgroup"], out["grid"] = r["VGPR_Count"], r["SGPR_Count"], r["Workgroup_Size"], r["Grid_Size"]
     out[name + "_KiB_per_launch"] = sum(vals) / len(vals)
-fetch_b = out["FETCH_SIZE_KiB_per_launch"] * 1024 * 2
+fetch_b = out["FETCH_SIZE_KiB_per_launch"] * 1024 * fetch_factor
 write_b = out["WRITE_SIZE_KiB_per_launch"] * 1024
 out["hbm_read_bytes_per_launch_corrected"] = fetch_b
 out["hbm_write_bytes_per_launch"] = write_b
@@ -44,6 +49,6 @@ with open(base + ".md", "w") as f:
     f.write("| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|\n")
     f.write("| `%s` | %d | %.1f | %.1f | %.1f |\n\n" % (out["kernel"][:90], out["calls"], out["avg_ns"] / 1e3, out["min_ns"] / 1e3, out["max_ns"] / 1e3))
     f.write("* algorithmic bytes per launch: %d -> %.0f GB/s at the trace's average duration (%.1f %% of 8 TB/s)\n" % (alg, out["achieved_GBs_from_trace_avg"], out["achieved_GBs_from_trace_avg"] / 80))
-    f.write("* HBM read  (2 x FETCH_SIZE x 1024): %.4g B per launch\n* HBM write (WRITE_SIZE x 1024, uncalibrated): %.4g B per launch\n" % (fetch_b, write_b))
+    f.write("* HBM read  (%.3f x FETCH_SIZE x 1024): %.4g B per launch\n* HBM write (WRITE_SIZE x 1024, uncalibrated): %.4g B per launch\n" % (fetch_factor, fetch_b, write_b))
     f.write("* traffic / algorithmic = %.3f\n* VGPR %s, SGPR %s, workgroup %s, grid %s\n" % (out["traffic_over_algorithmic"], out["vgpr"], out["sgpr"], out["workgroup"], out["grid"]))
 print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_profiler"}, indent=1))
