@@ -1,6 +1,7 @@
 // C ABI of libneedle_hip.so (include/needle_hip.h): pattern objects, per-device program cache, batch entry
 // points, and the single-haystack Matcher mirror.  No CPU matching path exists in this library.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -55,7 +56,11 @@ struct needle_pattern {
     }
 };
 
-static constexpr size_t kMaxProgLds = kMaxProgLdsBytes;
+// Automaton LDS budget.  NEEDLE_MAX_PROG_LDS (bytes) lowers it: tests use that to force the HBM-table mode.
+static size_t max_prog_lds() {
+    static const size_t v = getenv("NEEDLE_MAX_PROG_LDS") ? (size_t)atol(getenv("NEEDLE_MAX_PROG_LDS")) : (size_t)kMaxProgLdsBytes;
+    return v < kMaxProgLdsBytes ? v : (size_t)kMaxProgLdsBytes;
+}
 
 static int get_program(needle_pattern *p, int which, int cw, int variant, const DevProgram **out, int *n_cus) {
     int dev = 0;
@@ -71,7 +76,7 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        dp.prog = lower(p->t, (Which)which, cw, kMaxProgLds, variant == 1, variant == 2);
+        dp.prog = lower(p->t, (Which)which, cw, max_prog_lds(), variant == 1, variant == 2);
         HIP_TRY(hipMalloc((void **)&dp.d_blob, dp.prog.blob.size()));
         HIP_TRY(hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice));
         it = p->cache.emplace(key, std::move(dp)).first;
@@ -297,7 +302,7 @@ int needle_pattern_get_info(const needle_pattern *p, needle_pattern_info *o) {
     for (int w = 0; w < 4; ++w) {
         o->n_states[w] = p->t.dfa[w].n_states;
         o->max_char[w] = p->t.dfa[w].max_char;
-        o->kernel_mode[w] = (int)lower(p->t, (Which)w, 1, kMaxProgLds, false).hdr.mode;
+        o->kernel_mode[w] = (int)lower(p->t, (Which)w, 1, max_prog_lds(), false).hdr.mode;
     }
     return NEEDLE_OK;
 }

@@ -154,3 +154,40 @@ def test_host_buffer_entry_points_match_device_entry_points():
     fw, fs, fe = p.find_batch(rows, lens)
     of, ofs, ofe = o.batch_find(rows, lens)
     assert (unpack_bitmap(fw, 5000) == of).all() and (fs == ofs).all() and (fe == ofe).all()
+
+
+@pytest.mark.gpu
+def test_hbm_resident_table_mode_matches_oracle():
+    """MODE_GLOBAL (automaton too large for the 160 KiB LDS): forced through NEEDLE_MAX_PROG_LDS in a child process
+    on the 1k-keyword pattern; same parity bar as the LDS-table mode."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from needle_amd import workload as W
+from needle_amd.pattern import DFACompiler, unpack_bitmap
+from test_compile_matches_txt import oracle_for
+words = W.keywords(300)
+rx = "|".join(words)
+p = DFACompiler.compile(rx, "t", 0)
+assert p.info()["kernel_mode"]["forwards"] == 3, p.info()
+o, _ = oracle_for(rx, 0)
+n = 20000
+rows = W.keyword_batch(torch, words, 5, n, 256, device="cuda")
+host = rows.cpu().numpy()
+fw, fs, fe = p.find_batch(rows)
+of, ofs, ofe = o.batch_find(host, threads=4)
+assert (unpack_bitmap(fw, n) == of).all() and (fs.cpu().numpy() == ofs).all() and (fe.cpu().numpy() == ofe).all()
+assert (unpack_bitmap(p.contained_in_batch(rows), n) == o.batch_contained_in(host, threads=4)).all()
+assert (unpack_bitmap(p.matches_batch(rows), n) == o.batch_matches(host, threads=4)).all()
+rows16 = rows.to(torch.int16)
+fw, fs, fe = p.find_batch(rows16)
+assert (unpack_bitmap(fw, n) == of).all() and (fs.cpu().numpy() == ofs).all() and (fe.cpu().numpy() == ofe).all()
+print("GLOBAL-MODE-OK")
+'''
+    import os
+    env = dict(os.environ, NEEDLE_MAX_PROG_LDS="4096")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "GLOBAL-MODE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
