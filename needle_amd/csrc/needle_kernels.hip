@@ -24,6 +24,10 @@
 #include <stdlib.h>
 #include "needle_device.h"
 
+#ifndef NEEDLE_PIECE_FENCE
+#define NEEDLE_PIECE_FENCE 1
+#endif
+
 namespace needle {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -115,22 +119,28 @@ __device__ __forceinline__ uint32_t column_of(const uint8_t *cmap, const uint8_t
     return pages[((uint32_t)ptab[c >> 8] << 8) | (c & 255u)];
 }
 
-// One transition on char number K (0..3 for bytes, 0..1 for UTF-16 units) of dword w.
-// st: 5 * state in MODE_PACK (the bit offset of the state's field), the state id otherwise.
+// A transition in two halves so that a whole 16-byte piece can be batched: `lookup` is everything that does not
+// depend on the automaton state (char -> F, or char -> column * element size); `apply` is the dependent part.
+// K: char number inside dword w (0..3 for bytes, 0..1 for UTF-16 units).
 template <int MODE, int CW, bool GUARD, int K>
-__device__ __forceinline__ uint32_t step(const Walk &wk, uint32_t st, uint32_t w, bool in_row) {
+__device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_row) {
     uint32_t col; // packed mode: F;  table modes: column * element size
     if (CW == 1) {
-        // packed mode: F[byte][64 lane copies]: address = byte << 8 | lane * 4, formed by ONE v_perm_b32; every lane
-        // reads its own LDS bank, so the lookup is conflict-free whatever the text looks like
+        // packed mode: F[byte][32 lane copies]: address = byte << 8 | (lane & 31) * 4, formed by ONE v_perm_b32;
+        // every lane reads its own LDS bank, so the lookup is conflict-free whatever the text looks like
         if (MODE == MODE_PACK) col = lds_u32(__builtin_amdgcn_perm(w, wk.lane4, 0x0C0C0400u + ((uint32_t)K << 8)) + kLdsF1);
         else col = lds_u16(shl_byte<K>(w, 1) + kLdsCmap1);
     } else {
         const uint32_t pg = lds_u16(shl_byte<(2 * K + 1) & 3>(w, 1) + kLdsPtab2);  // page base = page * 256
-        const uint32_t ce = lds_u8(or_byte<(2 * K) & 3>(pg, w) + (MODE == MODE_PACK ? kLdsPages2Pack : kLdsPages2Table));        // column * 4 (packed) | * element size
-        col = (MODE == MODE_PACK) ? lds_u32(ce + kLdsF2) : ce;
+        const uint32_t ce = lds_u8(or_byte<(2 * K) & 3>(pg, w) + (MODE == MODE_PACK ? kLdsPages2Pack : kLdsPages2Table));
+        col = (MODE == MODE_PACK) ? lds_u32(ce + kLdsF2) : ce; // pages hold column * 4 (packed) | * element size
     }
     if (GUARD) col = in_row ? col : wk.pad_e;
+    return col;
+}
+// st: 5 * state in MODE_PACK (the bit offset of the state's field in F), the state id otherwise.
+template <int MODE, int CW>
+__device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t col) {
     if (MODE == MODE_PACK) return __builtin_amdgcn_ubfe(col, st, 5);
     const uint32_t i = __umul24(st, wk.ncols_e) + col;
     if (MODE == MODE_GLOBAL) return wk.gtable[i];
@@ -260,27 +270,38 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         int32_t last_rel = -1;                            // OP_FIND: last accepting position inside this tile
         // ragged rows keep more values live per char: unroll less there or it spills
         constexpr int kUnroll = GUARD ? (OP == OP_FIND ? 1 : 2) : G::kPieces;
+        constexpr int CPP = 16 / CW; // chars per 16-byte piece
+        u32x4 v = tile_piece<CHB>(tile, lane, 0);
 #pragma unroll kUnroll
         for (int kk = 0; kk < G::kPieces; ++kk) {
-            const u32x4 v = tile_piece<CHB>(tile, lane, kk);
             const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
-            const uint32_t p0 = kk * (16 / CW);
-#define NEEDLE_STEP(D, K)                                                                               \
-    {                                                                                                   \
-        const uint32_t pos = p0 + (D) * (4 / CW) + (K);                                                 \
-        st = step<MODE, CW, GUARD, K>(wk, st, w[D], pos < rem);                                         \
-        if (OP == OP_FIND) last_rel = (st >= accept_lo) ? (int32_t)(pos + 1) : last_rel;                \
-    }
+            if (kk + 1 < G::kPieces) v = tile_piece<CHB>(tile, lane, kk + 1); // next piece: its latency hides below
+            const uint32_t p0 = kk * CPP;
+            // all state-independent lookups of the piece first (they pipeline in the LDS) ...
+            uint32_t col[CPP];
+#define NEEDLE_LOOKUP(D, K) col[(D) * (4 / CW) + (K)] = lookup<MODE, CW, GUARD, K>(wk, w[D], p0 + (D) * (4 / CW) + (K) < rem);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                NEEDLE_STEP(d, 0)
-                NEEDLE_STEP(d, 1)
+                NEEDLE_LOOKUP(d, 0)
+                NEEDLE_LOOKUP(d, 1)
                 if (CW == 1) {
-                    NEEDLE_STEP(d, 2)
-                    NEEDLE_STEP(d, 3)
+                    NEEDLE_LOOKUP(d, 2)
+                    NEEDLE_LOOKUP(d, 3)
                 }
             }
-#undef NEEDLE_STEP
+#undef NEEDLE_LOOKUP
+            // ... then ONE wait for all of them instead of one s_waitcnt per char (the walk is issue-bound), ...
+            if (MODE == MODE_PACK && NEEDLE_PIECE_FENCE) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ... then the dependent chain
+#pragma unroll
+            for (int i = 0; i < CPP; ++i) {
+                st = apply<MODE, CW>(wk, st, col[i]);
+                if (OP == OP_FIND) last_rel = (st >= accept_lo) ? (int32_t)(p0 + i + 1) : last_rel;
+            }
         }
         if (OP == OP_FIND) last = last_rel >= 0 ? (int32_t)idx0 + last_rel : last;
         // wave-uniform early exit: every lane has an absorbing verdict (sink, or accepted for containedIn)
