@@ -10,7 +10,7 @@ NEEDLE_OK, ERR_INVALID, ERR_SYNTAX, ERR_COMPILE, ERR_UNSUPPORTED, ERR_DEVICE = 0
 
 EXPORTS = [
     "needle_version", "needle_last_error", "needle_device_count", "needle_compile", "needle_pattern_from_tables",
-    "needle_pattern_destroy", "needle_pattern_get_info", "needle_pattern_get_class_map", "needle_pattern_get_table",
+    "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_get_class_map", "needle_pattern_get_table",
     "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_matches_host",
     "needle_contained_in_host", "needle_find_host", "needle_matcher_create", "needle_matcher_destroy",
     "needle_matcher_matches", "needle_matcher_contained_in", "needle_matcher_find", "needle_matcher_find_range",
@@ -66,6 +66,8 @@ def lib():
     L.needle_pattern_from_tables.argtypes = [P(TableDesc), P(VP)]
     L.needle_pattern_destroy.argtypes = [VP]
     L.needle_pattern_destroy.restype = None
+    L.needle_pattern_serialize.argtypes = [VP, VP, ctypes.c_size_t, P(ctypes.c_size_t)]
+    L.needle_pattern_deserialize.argtypes = [VP, ctypes.c_size_t, P(VP)]
     L.needle_pattern_get_info.argtypes = [VP, P(PatternInfo)]
     L.needle_pattern_get_class_map.argtypes = [VP, VP]
     L.needle_pattern_get_table.argtypes = [VP, I, VP, VP]

@@ -321,6 +321,84 @@ int needle_pattern_get_table(const needle_pattern *p, int which, int16_t *table,
     return NEEDLE_OK;
 }
 
+// ---- precompiled-pattern blob ("NDLT" v1)
+static void put_i32(std::vector<uint8_t> &b, int32_t v) {
+    for (int i = 0; i < 4; ++i) b.push_back((uint8_t)((uint32_t)v >> (8 * i)));
+}
+static bool get_i32(const uint8_t *&p, const uint8_t *end, int32_t &v) {
+    if (end - p < 4) return false;
+    v = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+    p += 4;
+    return true;
+}
+
+int needle_pattern_serialize(const needle_pattern *p, void *buf, size_t cap, size_t *needed) {
+    if (!p || !needed) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    std::vector<uint8_t> b;
+    const char magic[4] = {'N', 'D', 'L', 'T'};
+    b.insert(b.end(), magic, magic + 4);
+    put_i32(b, 1);
+    put_i32(b, p->t.stride);
+    put_i32(b, p->t.fixed_len);
+    put_i32(b, p->t.min_len);
+    put_i32(b, p->t.max_len);
+    for (int w = 0; w < 4; ++w) {
+        put_i32(b, p->t.dfa[w].n_states);
+        put_i32(b, p->t.dfa[w].max_char);
+    }
+    b.insert(b.end(), p->t.class_map.begin(), p->t.class_map.end());
+    for (int w = 0; w < 4; ++w) {
+        for (int16_t v : p->t.dfa[w].table) {
+            b.push_back((uint8_t)((uint16_t)v & 255));
+            b.push_back((uint8_t)((uint16_t)v >> 8));
+        }
+        b.insert(b.end(), p->t.dfa[w].accepting.begin(), p->t.dfa[w].accepting.end());
+    }
+    *needed = b.size();
+    if (cap == 0) return NEEDLE_OK;
+    if (!buf || cap < b.size()) return fail(NEEDLE_ERR_INVALID, "buffer too small");
+    memcpy(buf, b.data(), b.size());
+    return NEEDLE_OK;
+}
+
+int needle_pattern_deserialize(const void *buf, size_t n, needle_pattern **out) {
+    if (!out) return fail(NEEDLE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!buf) return fail(NEEDLE_ERR_INVALID, "buf is NULL");
+    const uint8_t *q = (const uint8_t *)buf, *end = q + n;
+    if (n < 8 || memcmp(q, "NDLT", 4) != 0) return fail(NEEDLE_ERR_INVALID, "not a needle table blob");
+    q += 4;
+    int32_t ver = 0;
+    needle_pattern *p = new needle_pattern();
+    bool ok = get_i32(q, end, ver) && ver == 1 && get_i32(q, end, p->t.stride) && get_i32(q, end, p->t.fixed_len) &&
+              get_i32(q, end, p->t.min_len) && get_i32(q, end, p->t.max_len);
+    for (int w = 0; ok && w < 4; ++w) ok = get_i32(q, end, p->t.dfa[w].n_states) && get_i32(q, end, p->t.dfa[w].max_char);
+    ok = ok && p->t.stride >= 1 && p->t.stride <= 255 && (size_t)(end - q) >= 65536;
+    if (ok) {
+        p->t.class_map.assign(q, q + 65536);
+        q += 65536;
+    }
+    for (int w = 0; ok && w < 4; ++w) {
+        RefDfa &d = p->t.dfa[w];
+        ok = d.n_states >= 1 && d.n_states <= 16383;
+        const size_t cells = ok ? (size_t)d.n_states * p->t.stride : 0;
+        ok = ok && (size_t)(end - q) >= cells * 2 + (size_t)d.n_states;
+        if (!ok) break;
+        d.table.resize(cells);
+        for (size_t i = 0; i < cells; ++i) d.table[i] = (int16_t)((uint16_t)q[2 * i] | ((uint16_t)q[2 * i + 1] << 8));
+        q += cells * 2;
+        d.accepting.assign(q, q + d.n_states);
+        q += d.n_states;
+    }
+    std::string err = "truncated or malformed table blob";
+    if (!ok || q != end || !validate_tables(p->t, err)) {
+        delete p;
+        return fail(NEEDLE_ERR_INVALID, err);
+    }
+    *out = p;
+    return NEEDLE_OK;
+}
+
 int needle_matches_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, void *s) {
     return run_dev(p, OP_MATCHES, v, bm, nullptr, nullptr, s);
 }

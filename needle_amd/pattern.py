@@ -154,6 +154,21 @@ class Pattern:
         del keep
         return cls(h)
 
+    # ---- precompiled-pattern blob (the analogue of Precompile.precompile, NC/precompile/Precompile.java:19-53)
+    def to_bytes(self):
+        need = ctypes.c_size_t(0)
+        _check(_lib.lib().needle_pattern_serialize(self._h, None, 0, ctypes.byref(need)))
+        buf = (ctypes.c_ubyte * need.value)()
+        _check(_lib.lib().needle_pattern_serialize(self._h, buf, need.value, ctypes.byref(need)))
+        return bytes(buf)
+
+    @classmethod
+    def from_bytes(cls, blob):
+        h = ctypes.c_void_p()
+        b = (ctypes.c_ubyte * len(blob)).from_buffer_copy(blob)
+        _check(_lib.lib().needle_pattern_deserialize(b, len(blob), ctypes.byref(h)))
+        return cls(h)
+
     # ---- introspection
     def info(self):
         i = PatternInfo()

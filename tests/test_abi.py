@@ -71,3 +71,23 @@ def test_small_automata_lower_to_nibble_mode(lib):
     from test_gpu_parity import pattern_from_fixture
     p = pattern_from_fixture(load_snapshot("DigitPlus"))
     assert set(p.info()["kernel_mode"].values()) == {0}
+
+
+def test_precompiled_blob_roundtrip(lib):
+    """needle_pattern_serialize / deserialize (the Precompile analogue): tables survive bit for bit; damaged blobs
+    are rejected, not crashed on."""
+    from needle_amd.pattern import DFACompiler, Pattern
+    p = DFACompiler.compile("Sherlock|Holmes|Watson|Irene|Adler|John|Baker", "UnionOfManyNames", 0)
+    blob = p.to_bytes()
+    assert blob[:4] == b"NDLT" and len(blob) > 65536
+    q = Pattern.from_bytes(blob)
+    a, b = p.tables(), q.tables()
+    assert a["stride"] == b["stride"] and a["fixed_len"] == b["fixed_len"] and (a["class_map"] == b["class_map"]).all()
+    assert (a["min_len"], a["max_len"]) == (b["min_len"], b["max_len"]) == (4, 8)
+    for k in a["dfas"]:
+        assert (a["dfas"][k]["table"] == b["dfas"][k]["table"]).all()
+        assert a["dfas"][k]["accepting"] == b["dfas"][k]["accepting"] and a["dfas"][k]["max_char"] == b["dfas"][k]["max_char"]
+    assert q.to_bytes() == blob
+    for bad in (blob[:100], blob[:-1], b"XXXX" + blob[4:], blob + b"\0", blob[:8] + b"\xff\xff\xff\x7f" + blob[12:]):
+        with pytest.raises(ValueError):
+            Pattern.from_bytes(bad)
