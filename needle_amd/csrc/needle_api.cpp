@@ -100,7 +100,7 @@ static int check_view(const needle_batch_view *v, bool device) {
 }
 
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
-                   int32_t *d_end, void *stream) {
+                   int32_t *d_end, void *stream, const int32_t *d_from = nullptr) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
     int rc = check_view(v, true);
@@ -123,6 +123,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     a.total_bytes = a.n_rows * a.stride_bytes;
     a.row_len = v->row_len;
     a.lengths = v->lengths;
+    a.from = d_from;
     a.prog = fp->d_blob;
     a.hdr = fp->prog.hdr;
     a.fixed_len = -1;
@@ -407,6 +408,11 @@ int needle_contained_in_dev(const needle_pattern *p, const needle_batch_view *v,
 }
 int needle_find_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, int32_t *st, int32_t *en, void *s) {
     return run_dev(p, OP_FIND, v, bm, st, en, s);
+}
+int needle_find_next_dev(const needle_pattern *p, const needle_batch_view *v, const int32_t *cur, uint64_t *bm, int32_t *st,
+                         int32_t *en, void *s) {
+    if (!cur) return fail(NEEDLE_ERR_INVALID, "cursor is NULL");
+    return run_dev(p, OP_FIND, v, bm, st, en, s, cur);
 }
 int needle_matches_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm) {
     return run_host(p, OP_MATCHES, v, bm, nullptr, nullptr);

@@ -20,11 +20,12 @@ enum Mode : int {
 //   0            sink (dead, absorbing, non-accepting)
 //   1 .. A0-1    non-accepting states
 //   A0 .. n-1    accepting states          => accepted(s) == (s >= A0)
-// Column layout of a row: reference classes 0..N-1, then OVER (char > maxChar), then PAD (index >= row length).
+// Column layout of a row: reference classes 0..N-1, then OVER (char > maxChar), PAD (index >= row length) and
+// PRE (index < the row's find() cursor: identity, the walk has not started yet).
 struct ProgHeader {
     uint32_t mode;       // Mode
     uint32_t n_states;   // incl. sink
-    uint32_t n_cols;     // N + 2
+    uint32_t n_cols;     // N + 3
     uint32_t start;      // device id of the reference's state 0
     uint32_t accept_lo;  // A0
     uint32_t root_accepting;
@@ -33,13 +34,14 @@ struct ProgHeader {
     uint32_t off_f;      // MODE_NIBBLE: uint32 F[] -- char_width 1: F[byte][32], one copy per LDS bank so that lane l
                          //              always reads bank l & 31 (no bank conflicts whatever the text);
                          //              char_width 2: n_cols entries indexed by column
-    uint32_t pad_f;      // MODE_NIBBLE: F of the PAD column (selected in registers for chars past the row length)
+    uint32_t pad_f;      // packed mode: F of the PAD column (selected in registers for chars past the row length)
+    uint32_t pre_f;      // packed mode: F of the PRE column (identity)
     uint32_t off_cmap;   // char_width 1 table modes: uint8 column[256]
     uint32_t off_ptab;   // char_width 2: uint8 page_of[256] (high byte -> page)
     uint32_t off_pages;  // char_width 2: uint8 column[n_pages][256]
     uint32_t off_table;  // table modes: next-state table [n_states][n_cols]
     uint32_t n_pages;
-    uint32_t pad_col;    // column index of PAD (= n_cols - 1)
+    uint32_t pad_col;    // column index of PAD (= n_cols - 2); PRE = n_cols - 1
     // OP_FIND forward programs also carry the BACKWARD automaton's char -> column maps (staged in LDS with the
     // rest; the backward table itself is walked out of HBM/L2)
     uint32_t off_bcmap, off_bptab, off_bpages;
@@ -53,6 +55,7 @@ struct ScanArgs {
     uint64_t total_bytes;   // n_rows * stride_bytes (clamp for tail reads)
     uint32_t row_len;       // chars, when lengths == nullptr
     const uint32_t *lengths;
+    const int32_t *from;    // OP_FIND: optional per-row cursor (Matcher.nextStart): walk starts there; < 0 = row exhausted
     const uint8_t *prog;    // forward program blob (device)
     ProgHeader hdr;
     const uint8_t *bprog;   // OP_FIND: backward program blob (device, walked out of global memory), or nullptr

@@ -108,6 +108,7 @@ __device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(NEEDLE_LDS(ui
 struct Walk {
     uint32_t ncols_e;   // table modes: row stride in BYTES of the next-state table (n_cols * element size)
     uint32_t pad_e;     // table modes: PAD column * element size;  packed mode: F of the PAD column
+    uint32_t pre_e;     // same for the PRE column (identity: chars before the row's find() cursor)
     uint32_t table_off; // char_width 2 table modes: LDS byte offset of the table
     uint32_t lane4;     // lane * 4 (byte 0 of the packed-mode F address)
     const uint16_t *gtable; // MODE_GLOBAL
@@ -123,7 +124,7 @@ __device__ __forceinline__ uint32_t column_of(const uint8_t *cmap, const uint8_t
 // depend on the automaton state (char -> F, or char -> column * element size); `apply` is the dependent part.
 // K: char number inside dword w (0..3 for bytes, 0..1 for UTF-16 units).
 template <int MODE, int CW, bool GUARD, int K>
-__device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_row) {
+__device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_row, bool before_cursor) {
     uint32_t col; // packed mode: F;  table modes: column * element size
     if (CW == 1) {
         // packed mode: F[byte][32 lane copies]: address = byte << 8 | (lane & 31) * 4, formed by ONE v_perm_b32;
@@ -135,7 +136,10 @@ __device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_r
         const uint32_t ce = lds_u8(or_byte<(2 * K) & 3>(pg, w) + (MODE == MODE_PACK ? kLdsPages2Pack : kLdsPages2Table));
         col = (MODE == MODE_PACK) ? lds_u32(ce + kLdsF2) : ce; // pages hold column * 4 (packed) | * element size
     }
-    if (GUARD) col = in_row ? col : wk.pad_e;
+    if (GUARD) {
+        col = in_row ? col : wk.pad_e;
+        col = before_cursor ? wk.pre_e : col;
+    }
     return col;
 }
 // st: 5 * state in MODE_PACK (the bit offset of the state's field in F), the state id otherwise.
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     constexpr uint32_t ELEM = (MODE == MODE_TABLE16) ? 2u : 1u;
     wk.ncols_e = a.hdr.n_cols * ELEM;
     wk.pad_e = (MODE == MODE_PACK) ? a.hdr.pad_f : a.hdr.pad_col * ELEM;
+    wk.pre_e = (MODE == MODE_PACK) ? a.hdr.pre_f : (a.hdr.pad_col + 1u) * ELEM;
     wk.table_off = a.hdr.off_table;
     wk.lane4 = (uint32_t)(lane & 31) * 4u; // lanes l and l+32 are served in different LDS passes: 32 copies suffice
     wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
@@ -250,6 +255,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     bool row_ok;
     uint32_t len, n_chunks, st;
     int32_t last;
+    int32_t cursor = 0;  // OP_FIND with per-row cursors: Matcher.nextStart (FROM of find(FROM, TO)); < 0 = exhausted
+    bool dead = false;
     auto begin_group = [&](uint64_t grp) {
         my_row = (grp << 6) + lane;
         row_ok = my_row < a.n_rows;
@@ -259,14 +266,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         n_chunks = (max_len * CW + CHB - 1) / CHB;
         if (n_chunks == 0) n_chunks = 1; // empty rows still take one (fully PAD-guarded) step
         st = start_state;
+        if (GUARD && OP == OP_FIND && a.from) {
+            cursor = row_ok ? a.from[my_row] : -1;
+            dead = cursor < 0; // find(): `if nextStart == -1 return false`, DFAClassBuilder.java:629-630
+            if (dead) cursor = 0;
+        }
         last = -1; // OP_FIND: lastMatch of indexForwards
-        if (OP == OP_FIND && a.hdr.root_accepting) last = 0; // DFAClassBuilder.java:356 (+ first-iteration check :440)
+        // :356 literal 0, then the first loop iteration's wasAccepted check (:440) moves it to FROM if FROM < length
+        if (OP == OP_FIND && a.hdr.root_accepting) last = ((uint32_t)cursor < len) ? cursor : 0;
     };
 
     // Walk the tile in LDS (chunk ck of the current group).  Returns true when no lane needs a further chunk.
     auto walk_tile = [&](uint32_t ck) -> bool {
         const uint32_t idx0 = ck * (CHB / CW);           // index of the tile's first char
         const uint32_t rem = len > idx0 ? len - idx0 : 0; // GUARD: chars of this row inside the tile and beyond
+        const uint32_t skip = (uint32_t)cursor > idx0 ? (uint32_t)cursor - idx0 : 0; // GUARD: chars before the cursor
         int32_t last_rel = -1;                            // OP_FIND: last accepting position inside this tile
         // ragged rows keep more values live per char: unroll less there or it spills
         constexpr int kUnroll = GUARD ? (OP == OP_FIND ? 1 : 2) : G::kPieces;
@@ -279,7 +293,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             const uint32_t p0 = kk * CPP;
             // all state-independent lookups of the piece first (they pipeline in the LDS) ...
             uint32_t col[CPP];
-#define NEEDLE_LOOKUP(D, K) col[(D) * (4 / CW) + (K)] = lookup<MODE, CW, GUARD, K>(wk, w[D], p0 + (D) * (4 / CW) + (K) < rem);
+#define NEEDLE_LOOKUP(D, K)                                                                         \
+    col[(D) * (4 / CW) + (K)] = lookup<MODE, CW, GUARD, K>(wk, w[D], p0 + (D) * (4 / CW) + (K) < rem, \
+                                                           p0 + (D) * (4 / CW) + (K) < skip);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 NEEDLE_LOOKUP(d, 0)
@@ -300,7 +316,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
 #pragma unroll
             for (int i = 0; i < CPP; ++i) {
                 st = apply<MODE, CW>(wk, st, col[i]);
-                if (OP == OP_FIND) last_rel = (st >= accept_lo) ? (int32_t)(p0 + i + 1) : last_rel;
+                if (OP == OP_FIND) {
+                    bool acc = st >= accept_lo;
+                    if (GUARD) acc = acc && (p0 + i >= skip); // an accepting start state must not count before the cursor
+                    last_rel = acc ? (int32_t)(p0 + i + 1) : last_rel;
+                }
             }
         }
         if (OP == OP_FIND) last = last_rel >= 0 ? (int32_t)idx0 + last_rel : last;
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     // Verdicts of the finished group: bitmap word, and for find() the start index (DFAClassBuilder.java:640-656).
     auto finish_group = [&](uint64_t grp) {
         bool res;
-        if (OP == OP_FIND) res = row_ok && (last >= 0);
+        if (OP == OP_FIND) res = row_ok && !dead && (last >= 0);
         else res = row_ok && (st >= accept_lo);
         const uint64_t word = __ballot(res);
         if (lane == 0) a.bitmap[grp] = word;
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
             int32_t idx_b = last - 1;
             uint32_t bs = a.bhdr.start;
-            int32_t lastb = a.bhdr.root_accepting ? 0 : INT_MAX;
+            int32_t lastb = a.bhdr.root_accepting ? cursor : INT_MAX; // :543-547 (LENGTH var = FROM)
             bool active = res;
             while (__ballot(active) != 0ull) {
                 uint32_t cs[8];
@@ -342,12 +362,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                 for (int k = 0; k < 8; ++k) {
                     const int32_t p = idx_b - k;
                     cs[k] = 0;
-                    if (active && p >= 0) cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
+                    if (active && p >= cursor) cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (active) {
-                        if (idx_b < 0) {
+                        if (idx_b < cursor) { // loop bound `index >= FROM`, :549
                             active = false;
                         } else {
                             const uint32_t col = column_of<CW>(bcmap, bptab, bpages, cs[k]);
@@ -511,7 +531,7 @@ hipError_t launch_scan(int op, int char_width, const ScanArgs &a_in, int n_cus, 
     if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
     sh.grid = (int)blocks;
     sh.lds = ((a.hdr.lds_bytes + 15u) & ~15u) + (size_t)(sh.waves - (in_f ? 4 : 0)) * 64 * sh.chb;
-    const bool guard = a.lengths != nullptr || ((uint64_t)a.row_len * char_width) % sh.chb != 0;
+    const bool guard = a.lengths != nullptr || a.from != nullptr || ((uint64_t)a.row_len * char_width) % sh.chb != 0;
     switch (op) {
     case OP_MATCHES: return launch_c<OP_MATCHES>(a, char_width, guard, sh, stream);
     case OP_CONTAINED_IN: return launch_c<OP_CONTAINED_IN>(a, char_width, guard, sh, stream);

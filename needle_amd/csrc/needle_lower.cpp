@@ -112,7 +112,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     const int N = t.stride;
     const int n_ref = d.n_states;
     const int n_dev = n_ref + 1;
-    const int n_cols = N + 2, OVER = N, PAD = N + 1;
+    const int n_cols = N + 3, OVER = N, PAD = N + 1, PRE = N + 2;
 
     // device numbering: 0 sink | non-accepting | accepting
     std::vector<int> dev(n_ref);
@@ -132,12 +132,14 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             for (int k = 0; k < n_cols; ++k) row[k] = (uint16_t)dev[s];
             continue;
         }
+        (void)PRE;
         for (int k = 0; k < N; ++k) {
             const int16_t tgt = d.table[(size_t)s * N + k];
             row[k] = (uint16_t)(tgt < 0 ? dead : dev[tgt]);
         }
         row[OVER] = (uint16_t)dead;
         row[PAD] = (which == W_MATCHES || contained) ? (uint16_t)dev[s] : (uint16_t)0;
+        row[PRE] = (uint16_t)dev[s];
     }
 
     Program p;
@@ -193,6 +195,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             return F;
         };
         p.hdr.pad_f = pack(PAD);
+        p.hdr.pre_f = pack(PRE);
         if (char_width == 1) {
             p.blob.assign(256 * 256, 0); // F[byte][64 lane copies] at kLdsF1 = 0: one private LDS bank per lane
             for (int c = 0; c < 256; ++c)

@@ -245,6 +245,62 @@ class Pattern:
     def contained_in_batch(self, rows, lengths=None, stream=None):
         return self._run("contained_in", rows, lengths, stream)
 
+    def find_next_batch(self, rows, cursor, lengths=None, stream=None):
+        """One Matcher.find() step per row from the per-row cursor (int32 device tensor; < 0 = exhausted).
+        -> (bitmap words, start, end); `end` is the rows' next cursor (-1 where nothing was found)."""
+        import torch
+        L = _lib.lib()
+        assert isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dim() == 2 and rows.is_contiguous()
+        assert cursor.is_cuda and cursor.dtype == torch.int32 and cursor.shape == (rows.shape[0],) and cursor.is_contiguous()
+        v = BatchView()
+        n, stride = rows.shape
+        v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.data_ptr(), rows.element_size(), n, stride, stride
+        if lengths is not None:
+            assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.shape == (n,)
+            v.lengths = lengths.data_ptr()
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            words = torch.empty((n + 63) // 64, dtype=torch.int64, device=rows.device)
+            st = torch.empty(n, dtype=torch.int32, device=rows.device)
+            en = torch.empty(n, dtype=torch.int32, device=rows.device)
+            _check(L.needle_find_next_dev(self._h, ctypes.byref(v), cursor.data_ptr(), words.data_ptr(), st.data_ptr(),
+                                          en.data_ptr(), s))
+        return words, st, en
+
+    def find_all_batch(self, rows, lengths=None, max_rounds=None):
+        """Every non-overlapping match of every row, as the reference's repeated find() would report them
+        (DFACompilerTest.java:66-78,671-699): one launch per round over the rows that still have a cursor, results
+        compacted on the device.  -> (offsets int64[n_rows + 1], start int32[m], end int32[m]) in CSR form.
+        An EMPTY match is reported once and ends its row (the reference's cursor does not advance past it)."""
+        import torch
+        n = rows.shape[0]
+        dev = rows.device
+        cursor = torch.zeros(n, dtype=torch.int32, device=dev)
+        ids = torch.arange(n, dtype=torch.int64, device=dev)
+        out_rows, out_s, out_e = [], [], []
+        rounds = 0
+        while True:
+            _, st, en = self.find_next_batch(rows, cursor, lengths)
+            hit = en >= 0
+            if not bool(hit.any()):
+                break
+            out_rows.append(ids[hit])
+            out_s.append(st[hit])
+            out_e.append(en[hit])
+            empty = hit & (en == st)
+            cursor = torch.where(hit & ~empty, en, torch.full_like(en, -1))
+            rounds += 1
+            if max_rounds is not None and rounds >= max_rounds:
+                break
+        if not out_rows:
+            return torch.zeros(n + 1, dtype=torch.int64, device=dev), cursor[:0], cursor[:0]
+        r, s_, e_ = torch.cat(out_rows), torch.cat(out_s), torch.cat(out_e)
+        order = torch.argsort(r * (1 << 32) + s_.to(torch.int64), stable=True)
+        r, s_, e_ = r[order], s_[order], e_[order]
+        offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        offsets[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+        return offsets, s_, e_
+
     def find_batch(self, rows, lengths=None, stream=None):
         """(bitmap words, start int32[n], end int32[n]); unmatched rows have start = end = -1."""
         return self._run("find", rows, lengths, stream)

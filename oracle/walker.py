@@ -149,6 +149,20 @@ class OraclePattern:
             raise RuntimeError("reference would throw (ArrayIndexOutOfBounds)")
         return (True, s.value, e.value) if r == 1 else (False, None, e.value)
 
+    def find_all(self, h, limit=100000):
+        """Repeated find() on one Matcher (nextStart = end, DFAClassBuilder.java:616-659) -> [(start, end), ...].
+        An empty match is reported once and ends the enumeration (the reference's cursor would not advance)."""
+        out, cur = [], 0
+        while len(out) < limit:
+            found, s, e = self.find(h, start=cur)
+            if not found:
+                break
+            out.append((s, e))
+            if e == s:
+                break
+            cur = e
+        return out
+
     # -- batches: rows is a 2-D uint8/uint16 array [n_rows, stride]
     def _batch_args(self, rows, lengths):
         rows = np.ascontiguousarray(rows)

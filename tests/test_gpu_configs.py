@@ -191,3 +191,81 @@ print("GLOBAL-MODE-OK")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "GLOBAL-MODE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,regex", [("DigitPlus", "[0-9]+"), ("UnionOfManyNames", "Sherlock|Holmes|Watson|Irene|Adler|John|Baker"),
+                                        ("RepeatingUnionOfShortStrings", "(ab|a|bcdef|g)+"), ("aDotc", "a.c")])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_find_all_equals_repeated_reference_find(name, regex, ragged):
+    """the nextStart cursor (DFAClassBuilder.java:616-659).  Per row: every non-overlapping match, GPU
+    rounds of needle_find_next_dev vs the oracle's repeated find(); plus the second find() the reference's own
+    compiled classes produced (tests/golden/snapshots 'find2')."""
+    import torch
+    from conftest import load_snapshot
+    doc = load_snapshot(name)
+    p, o = compiled(regex)
+    hs = [v["h"] for v in doc["vectors"] if len(v["h"]) <= 64 and all(ord(c) < 256 for c in v["h"])]
+    rng = np.random.default_rng(5)
+    rows, lens = rows_from_strings(hs, np.uint8, stride=64)
+    if not ragged:  # fill the padding with text so that full-length rows carry several matches
+        alpha = np.frombuffer((regex + " xyz019").encode("latin-1", "ignore"), dtype=np.uint8)
+        alpha = alpha[(alpha >= 48)]
+        for i, h in enumerate(hs):
+            rows[i, len(h):] = rng.choice(alpha, size=64 - len(h))
+        lens = None
+    t = torch.from_numpy(rows).cuda()
+    tl = None if lens is None else torch.from_numpy(lens.astype(np.int32)).cuda()
+    offsets, st, en = p.find_all_batch(t, tl)
+    offsets, st, en = offsets.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+    total = 0
+    for i in range(len(hs)):
+        row = rows[i] if lens is None else rows[i, :lens[i]]
+        want = o.find_all(row)
+        got = list(zip(st[offsets[i]:offsets[i + 1]].tolist(), en[offsets[i]:offsets[i + 1]].tolist()))
+        assert got == want, (i, hs[i], got, want)
+        total += len(want)
+    assert total > len(hs) // 4
+    if ragged:  # the reference's own second find()
+        by_h = {h: i for i, h in enumerate(hs)}
+        for v in doc["vectors"]:
+            if v["h"] in by_h and "find2" in v:
+                i = by_h[v["h"]]
+                got = list(zip(st[offsets[i]:offsets[i + 1]].tolist(), en[offsets[i]:offsets[i + 1]].tolist()))
+                assert got[0] == (v["find"][1], v["find"][2])
+                if v["find2"][0]:
+                    assert got[1] == (v["find2"][1], v["find2"][2]), (v, got)
+                else:
+                    assert len(got) == 1, (v, got)
+
+
+@pytest.mark.gpu
+def test_find_next_with_cursor_edge_cases():
+    """Cursors < 0 (exhausted), == length, mid-row; root-accepting pattern (a*) keeps the reference's literal-0 quirk."""
+    import torch
+    p, o = compiled("[0-9]+")
+    hs = ["ab12cd345", "12", "", "x9", "99999999"]
+    rows, lens = rows_from_strings(hs, np.uint8, stride=16)
+    t = torch.from_numpy(rows).cuda()
+    tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    for cur in ([0, 0, 0, 0, 0], [4, 2, 0, 2, 3], [-1, 1, -1, 1, 8], [9, 5, 1, 0, 7]):
+        c = torch.tensor(cur, dtype=torch.int32, device="cuda")
+        _, st, en = p.find_next_batch(t, c, tl)
+        for i, h in enumerate(hs):
+            if cur[i] < 0:
+                want = (-1, -1)
+            else:
+                f, s, e = o.find(h, start=cur[i])
+                want = (s, e) if f else (-1, -1)
+            assert (int(st[i]), int(en[i])) == want, (h, cur[i], int(st[i]), int(en[i]), want)
+    p2, o2 = compiled("a*")
+    hs = ["baaa", "aab", "", "bbb"]
+    rows, lens = rows_from_strings(hs, np.uint8, stride=16)
+    t = torch.from_numpy(rows).cuda()
+    tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    for cur in ([0, 0, 0, 0], [1, 1, 0, 2], [4, 3, 0, 3]):
+        c = torch.tensor(cur, dtype=torch.int32, device="cuda")
+        _, st, en = p2.find_next_batch(t, c, tl)
+        for i, h in enumerate(hs):
+            f, s, e = o2.find(h, start=cur[i])
+            assert f and (int(st[i]), int(en[i])) == (s, e), (h, cur[i], int(st[i]), int(en[i]), s, e)
