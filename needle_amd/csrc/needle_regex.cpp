@@ -28,6 +28,8 @@
 #include "needle_regex.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <climits>
 #include <cstdint>
 #include <map>
@@ -1143,6 +1145,16 @@ int compile_regex(const std::u16string &regex, int flags, RefTables &out, std::s
         const bool lml = (flags & NEEDLE_LEFTMOST_LONGEST) != 0;
         const std::vector<Instr> fwd = ProgramBuilder(lml).build(ast);
         const std::vector<Instr> rev = ProgramBuilder(lml).build(reversed(ast));
+        if (getenv("NEEDLE_DEBUG_NFA")) { // developer aid: dump the forward Thompson program
+            for (size_t i = 0; i < fwd.size(); ++i) {
+                const Instr &in = fwd[i];
+                fprintf(stderr, "%3zu: %s", i, in.op == OP_CHAR ? "CHAR" : in.op == OP_JUMP ? "JUMP" : in.op == OP_SPLIT ? "SPLIT" : "MATCH");
+                if (in.op == OP_CHAR) fprintf(stderr, " %04x-%04x", in.start, in.end);
+                if (in.op == OP_JUMP) fprintf(stderr, " ->%d", in.target);
+                for (int t : in.targets) fprintf(stderr, " %d", t);
+                fprintf(stderr, "  prio=%d\n", in.priority);
+            }
+        }
         Dfa dfas[4];
         dfas[W_MATCHES] = build(fwd, BASIC);
         dfas[W_CONTAINED_IN] = build(fwd, CONTAINED_IN);
