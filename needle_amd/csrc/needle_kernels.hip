@@ -531,7 +531,9 @@ hipError_t launch_scan(int op, int char_width, const ScanArgs &a_in, int n_cus, 
     if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
     sh.grid = (int)blocks;
     sh.lds = ((a.hdr.lds_bytes + 15u) & ~15u) + (size_t)(sh.waves - (in_f ? 4 : 0)) * 64 * sh.chb;
-    const bool guard = a.lengths != nullptr || a.from != nullptr || ((uint64_t)a.row_len * char_width) % sh.chb != 0;
+    // unguarded kernels assume every row fills a whole number of tiles
+    const bool guard = a.lengths != nullptr || a.from != nullptr || a.row_len == 0 ||
+                       ((uint64_t)a.row_len * char_width) % sh.chb != 0;
     switch (op) {
     case OP_MATCHES: return launch_c<OP_MATCHES>(a, char_width, guard, sh, stream);
     case OP_CONTAINED_IN: return launch_c<OP_CONTAINED_IN>(a, char_width, guard, sh, stream);

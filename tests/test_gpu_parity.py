@@ -130,3 +130,20 @@ def test_matcher_mirror_single_strings():
     assert p.matcher("xx9").containedIn() and not p.matcher("").containedIn()
     m = p.matcher("12 34")
     assert m.find(3, 5) and (m.start(), m.end()) == (3, 5)
+
+
+@pytest.mark.gpu
+def test_zero_length_rows():
+    """row_len == 0 (and the Matcher mirror on ""): the verdict is the start state's, no char is consumed."""
+    import torch
+    from needle_amd.pattern import DFACompiler, unpack_bitmap
+    star = DFACompiler.compile("[0-9A-Za-z]*", "s", 0)
+    plus = DFACompiler.compile("[0-9]+", "p", 0)
+    assert star.matcher("").matches() and star.matcher("").containedIn() and star.matcher("").find()
+    assert not plus.matcher("").matches() and not plus.matcher("").containedIn() and not plus.matcher("").find()
+    rows = torch.zeros((130, 16), dtype=torch.uint8, device="cuda")
+    lens = torch.zeros(130, dtype=torch.int32, device="cuda")
+    assert unpack_bitmap(star.matches_batch(rows, lens), 130).all()
+    assert not unpack_bitmap(plus.matches_batch(rows, lens), 130).any()
+    fw, fs, fe = star.find_batch(rows, lens)
+    assert unpack_bitmap(fw, 130).all() and (fs == 0).all() and (fe == 0).all()
