@@ -390,8 +390,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         }
     };
 
-    // ---- pipelined main loop over every group but the batch's last one
-    const uint64_t last_group = n_groups - 1;
+    // ---- pipelined main loop over every group whose unclamped tile reads provably stay inside the buffer: a tile
+    // read of group g ends before (g + 1) * 64 * stride + CHB, so all groups but the last are safe when rows are at
+    // least CHB bytes apart, and a few more trailing groups are excluded for narrower rows
+    uint64_t last_group = n_groups - 1; // first group handled by the clamped tail below
+    {
+        const uint64_t group_bytes = 64 * a.stride_bytes;
+        const uint64_t safe = a.total_bytes >= (uint64_t)CHB ? (a.total_bytes - CHB) / group_bytes : 0;
+        if (safe < last_group) last_group = safe;
+    }
     if (g < last_group) {
         uint32_t ck = 0;
         uint32_t pred_exit = 0xFFFFFFFFu; // chunk after which the previous group left early (prefetch predictor)
@@ -422,8 +429,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             begin_group(g);
         }
     }
-    // ---- the batch's last group (one wave in the grid): clamped loads, no pipelining
-    if (g == last_group) {
+    // ---- the batch's last group(s): clamped loads, no pipelining (at most a couple of waves in the whole grid)
+    for (; g < n_groups; g += wave_cnt) {
         begin_group(g);
         for (uint32_t ck = 0; ck < n_chunks; ++ck) {
             fetch_clamped(g, ck);

@@ -147,3 +147,23 @@ def test_zero_length_rows():
     assert not unpack_bitmap(plus.matches_batch(rows, lens), 130).any()
     fw, fs, fe = star.find_batch(rows, lens)
     assert unpack_bitmap(fw, 130).all() and (fs == 0).all() and (fe == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows", [1, 65, 70, 129, 1000])
+@pytest.mark.parametrize("stride", [16, 32, 48])
+def test_narrow_rows_near_the_buffer_end(n_rows, stride, oracle_lib):
+    """Rows narrower than a 128-byte tile chunk: the unclamped fast path must leave the trailing groups to the
+    clamped tail (reads may not cross the end of the caller's buffer) and results stay bit-exact."""
+    from oracle.walker import OraclePattern
+    doc = load_snapshot("DigitPlus")
+    p = pattern_from_fixture(doc)
+    o = OraclePattern.from_fixture(doc, backwards_as_dfa=True)
+    rng = np.random.default_rng(n_rows * 131 + stride)
+    rows = rng.choice(np.frombuffer(b"ab 0123456789xyz", dtype=np.uint8), size=(n_rows, stride)).astype(np.uint8)
+    lens = rng.integers(0, stride + 1, size=n_rows).astype(np.uint32)
+    for l in (None, lens):
+        m, c, f, fs, fe = gpu_run(p, rows, l)
+        assert (m == o.batch_matches(rows, l)).all() and (c == o.batch_contained_in(rows, l)).all()
+        of, ofs, ofe = o.batch_find(rows, l)
+        assert (f == of).all() and (fs == ofs).all() and (fe == ofe).all()
