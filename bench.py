@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+ENGINE_CLOCK_MHZ = 2400.0  # MI355X peak engine clock (same guide); chars/clk/CU is quoted against it
 
 
 def make_pattern(workload):
@@ -99,6 +100,53 @@ def cpu_baseline(workload, pattern, rows_dev, budget_s=12.0):
                       "CPU restatement of the generated loops, not the JVM bytecode path" % (passes, n, workload)}
 
 
+def measured_read_ceiling(buf):
+    """This GPU's streaming-READ ceiling on the bench's own resident buffer: a trivial coalesced read-reduce kernel
+    (needle_amd/csrc/stream_probe.hip, a measurement aid outside the product ABI), best of a few launch shapes."""
+    import ctypes
+    import torch
+    from needle_amd.build import PROBE_LIB
+    if not os.path.exists(PROBE_LIB):
+        return None
+    L = ctypes.CDLL(PROBE_LIB)
+    L.stream_read_launch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    n = buf.numel() * buf.element_size()
+    out = torch.zeros(4, dtype=torch.int32, device=buf.device)
+    s = torch.cuda.current_stream().cuda_stream
+    best = 0.0
+    for blocks, unroll in ((2048, 4), (4096, 4), (4096, 8), (8192, 8)):
+        for _ in range(2):
+            L.stream_read_launch(buf.data_ptr(), n, out.data_ptr(), blocks, unroll, s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            L.stream_read_launch(buf.data_ptr(), n, out.data_ptr(), blocks, unroll, s)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
+
+
+def must_read_bytes(workload, pattern, rows, cw):
+    """Secondary, stricter denominator: sum over rows of the number of chars the reference loop
+    touches before it stops, x bytes/char.  containedIn stops at the first accepting state = the END of the
+    shortest-ending match prefix, which for C2 is the first digit (find().start + 1); unmatched rows are read whole.
+    For find() (C3/C5) the forward walk runs to the char after `end` (where the search DFA dies) and the backward
+    walk re-reads [start, end): an estimate, labelled as such."""
+    import torch
+    from needle_amd.pattern import unpack_bitmap
+    n, L = rows.shape
+    fw, fs, fe = pattern.find_batch(rows)
+    m = torch.from_numpy(unpack_bitmap(fw, n)).to(rows.device)
+    if workload == "c2":
+        chars = torch.where(m, fs.long() + 1, torch.full_like(fs, L, dtype=torch.long))
+        exact = True
+    else:
+        chars = torch.where(m, (fe.long() + 1).clamp(max=L) + (fe - fs).long(), torch.full_like(fs, L, dtype=torch.long))
+        exact = False
+    return int(chars.sum().item()) * cw, exact
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +156,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (weak) or in total (strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the read-ceiling probe and the must-read byte count")
     args = ap.parse_args()
 
     import torch
@@ -219,6 +268,18 @@ def main():
                 break
             except (OSError, KeyError, ValueError):
                 pass
+    props = torch.cuda.get_device_properties(dev)
+    clk_hz = ENGINE_CLOCK_MHZ * 1e6
+    out["roofline"]["chars_per_clk_per_cu"] = n_rows * 256 / (kernel_ms * 1e-3) / clk_hz / props.multi_processor_count
+    out["roofline"]["device"] = {"name": props.name, "cus": props.multi_processor_count, "clock_mhz_nominal": ENGINE_CLOCK_MHZ}
+    if rank == 0 and world == 1 and not args.no_extras:
+        ceil = measured_read_ceiling(rows)
+        if ceil:
+            out["roofline"]["measured_read_ceiling"] = ceil
+            out["roofline"]["frac_of_measured_ceiling"] = out["roofline"]["achieved"] / ceil
+        mr, exact = must_read_bytes(args.workload, pattern, rows, cw)
+        out["must_read"] = {"bytes_per_step": mr, "GB/s": mr / (elapsed / args.steps) / 1e9, "exact": exact,
+                            "note": "chars the reference loop touches before it stops x bytes/char (SURVEY.md s8d secondary denominator)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, pattern, rows)
     if rank == 0:

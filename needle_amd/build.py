@@ -10,6 +10,18 @@ SOURCES = ["needle_kernels.hip", "needle_api.cpp", "needle_lower.cpp", "needle_r
 HEADERS = ["needle_device.h", "needle_lower.h", "needle_regex.h", os.path.join("..", "..", "include", "needle_hip.h")]
 
 
+PROBE_LIB = os.path.join(HERE, "libneedle_probe.so")  # measurement aid for bench.py, not part of the product ABI
+PROBE_SRC = os.path.join(CSRC, "stream_probe.hip")
+
+
+def build_probe(force=False):
+    """The trivial read-reduce kernel bench.py uses to measure this GPU's streaming-read ceiling."""
+    if force or not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_SRC) > os.path.getmtime(PROBE_LIB):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", PROBE_LIB, PROBE_SRC])
+    return PROBE_LIB
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -18,6 +30,7 @@ def _stale():
 
 
 def build(force=False, verbose=False):
+    build_probe(force)
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -22,8 +22,12 @@
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "needle_device.h"
 
+#ifndef NEEDLE_MASK_DONE_LANES
+#define NEEDLE_MASK_DONE_LANES 1
+#endif
 #ifndef NEEDLE_PIECE_FENCE
 #define NEEDLE_PIECE_FENCE 1
 #endif
@@ -210,32 +214,42 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     const uint32_t o_odd = CHB == 128 ? (row_in_instr * (uint32_t)a.stride_bytes + 16u * (p_in_row ^ q ^ 4u)) : o_even;
     const uint64_t load_step = (uint64_t)G::kRowsPerInstr * a.stride_bytes;
 
-    u32x4 R[G::kInstrs];
-    // Move the tile held in R to LDS and, piece by piece, re-issue each register's load for tile (grp, chunk): the
-    // wave keeps ~kInstrs loads in flight at all times instead of draining to zero at every tile boundary.
-    auto stage_and_fetch = [&](bool do_fetch, uint64_t grp, uint32_t chunk) {
+    // A "fetch unit" is NT consecutive tiles of one group: one tile of 128-byte pieces, or TWO tiles of 64-byte
+    // pieces = the two halves of the same 128-byte lines, requested back to back.  L2 lines are 128 B and every miss
+    // fetches the whole line, so asking for the second half one tile-walk later (by when the XCD has streamed its
+    // whole 4 MiB L2 once) would fetch every line twice (measured: TCC_EA0_RDREQ_128B x 128 B = 2.18x the batch).
+    constexpr int NT = (CHB == 64) ? 2 : 1;
+    u32x4 R[NT][G::kInstrs];
+    // Store tile T of the unit held in R to LDS; with do_fetch, re-issue the loads of ALL the unit's registers for
+    // unit `unit` of group grp piece by piece (every register of the unit is free once its last tile is staged): the
+    // wave keeps loads in flight at all times instead of draining to zero at every tile boundary.
+    auto stage_and_fetch = [&](auto tc, bool do_fetch, uint64_t grp, uint32_t unit) __attribute__((always_inline)) {
+        constexpr int T = decltype(tc)::value;
         if (!do_fetch) {
 #pragma unroll
-            for (int j = 0; j < G::kInstrs; ++j) store_piece(tile, j, R[j]);
+            for (int j = 0; j < G::kInstrs; ++j) store_piece(tile, j, R[T][j]);
             return;
         }
-        const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + chunk * CHB;
+        const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + unit * (NT * CHB);
 #pragma unroll
         for (int j = 0; j < G::kInstrs; ++j) {
-            store_piece(tile, j, R[j]);
+            store_piece(tile, j, R[T][j]);
             asm volatile("" ::: "memory"); // keep store j ahead of load j (else all loads hoist: two tiles live)
-            R[j] = *(const u32x4 *)(base + j * load_step + ((j & 1) ? o_odd : o_even));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) R[t][j] = *(const u32x4 *)(base + t * CHB + j * load_step + ((j & 1) ? o_odd : o_even));
             asm volatile("" ::: "memory");
         }
     };
-    auto fetch = [&](uint64_t grp, uint32_t chunk) { // plain (re)load of R, no staging
-        const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + chunk * CHB;
+    auto fetch = [&](uint64_t grp, uint32_t unit) __attribute__((always_inline)) { // plain (re)load of a unit, no staging
+        const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + unit * (NT * CHB);
 #pragma unroll
-        for (int j = 0; j < G::kInstrs; ++j) R[j] = *(const u32x4 *)(base + j * load_step + ((j & 1) ? o_odd : o_even));
+        for (int j = 0; j < G::kInstrs; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) R[t][j] = *(const u32x4 *)(base + t * CHB + j * load_step + ((j & 1) ? o_odd : o_even));
     };
     // The last 64-row group may hold fewer than 64 rows and its last chunk may reach past the end of the buffer:
     // it is fetched with every clamp applied, by the one wave that owns it, outside the pipelined loop.
-    auto fetch_clamped = [&](uint64_t grp, uint32_t chunk) {
+    auto fetch_clamped = [&](uint64_t grp, uint32_t chunk) __attribute__((always_inline)) {
         const uint32_t last_r = (uint32_t)(a.n_rows - 1 - (grp << 6));
         const uint32_t stride = (uint32_t)a.stride_bytes;
         const uint8_t *gbase = a.rows + (grp << 6) * a.stride_bytes;
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             r = r < last_r ? r : last_r;
             uint32_t pb = chunk * CHB + kk * 16u;     // byte offset of the piece inside its row
             if (pb + 16u > stride) pb = stride - 16u; // keep the 16-byte read inside the row (stride >= 16)
-            R[j] = *(const u32x4 *)(gbase + (r * stride + pb));
+            R[0][j] = *(const u32x4 *)(gbase + (r * stride + pb));
         }
     };
 
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     int32_t last;
     int32_t cursor = 0;  // OP_FIND with per-row cursors: Matcher.nextStart (FROM of find(FROM, TO)); < 0 = exhausted
     bool dead = false;
-    auto begin_group = [&](uint64_t grp) {
+    auto begin_group = [&](uint64_t grp) __attribute__((always_inline)) {
         my_row = (grp << 6) + lane;
         row_ok = my_row < a.n_rows;
         len = 0;
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     };
 
     // Walk the tile in LDS (chunk ck of the current group).  Returns true when no lane needs a further chunk.
-    auto walk_tile = [&](uint32_t ck) -> bool {
+    auto walk_tile = [&](uint32_t ck) __attribute__((always_inline)) -> bool {
         const uint32_t idx0 = ck * (CHB / CW);           // index of the tile's first char
         const uint32_t rem = len > idx0 ? len - idx0 : 0; // GUARD: chars of this row inside the tile and beyond
         const uint32_t skip = (uint32_t)cursor > idx0 ? (uint32_t)cursor - idx0 : 0; // GUARD: chars before the cursor
@@ -291,6 +305,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
             if (kk + 1 < G::kPieces) v = tile_piece<CHB>(tile, lane, kk + 1); // next piece: its latency hides below
             const uint32_t p0 = kk * CPP;
+            // Table modes are bound by LDS cycles, not by issue: a lane whose verdict is already final (sink, or
+            // accepted for containedIn) is masked out of the piece's lookups, so its LDS passes and the bank
+            // conflicts it would cause disappear.  (Packed mode is conflict-free by construction: no masking.)
+            bool lane_live = true;
+            if (MODE != MODE_PACK && NEEDLE_MASK_DONE_LANES)
+                lane_live = (OP == OP_CONTAINED_IN) ? (st - 1u < accept_lo - 1u) : (st != 0u);
+            if (lane_live) {
             // all state-independent lookups of the piece first (they pipeline in the LDS) ...
             uint32_t col[CPP];
 #define NEEDLE_LOOKUP(D, K)                                                                         \
@@ -322,6 +343,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                     last_rel = acc ? (int32_t)(p0 + i + 1) : last_rel;
                 }
             }
+            } // lane_live
         }
         if (OP == OP_FIND) last = last_rel >= 0 ? (int32_t)idx0 + last_rel : last;
         // wave-uniform early exit: every lane has an absorbing verdict (sink, or accepted for containedIn)
@@ -333,7 +355,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     };
 
     // Verdicts of the finished group: bitmap word, and for find() the start index (DFAClassBuilder.java:640-656).
-    auto finish_group = [&](uint64_t grp) {
+    auto finish_group = [&](uint64_t grp) __attribute__((always_inline)) {
         bool res;
         if (OP == OP_FIND) res = row_ok && !dead && (last >= 0);
         else res = row_ok && (st >= accept_lo);
@@ -390,13 +412,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         }
     };
 
-    // ---- pipelined main loop over every group whose unclamped tile reads provably stay inside the buffer: a tile
-    // read of group g ends before (g + 1) * 64 * stride + CHB, so all groups but the last are safe when rows are at
-    // least CHB bytes apart, and a few more trailing groups are excluded for narrower rows
+    // ---- pipelined main loop over every group whose unclamped unit reads provably stay inside the buffer: a unit
+    // read of group g ends before (g + 1) * 64 * stride + NT * CHB, so all groups but the last are safe when rows are
+    // at least that far apart, and a few more trailing groups are excluded for narrower rows
     uint64_t last_group = n_groups - 1; // first group handled by the clamped tail below
     {
         const uint64_t group_bytes = 64 * a.stride_bytes;
-        const uint64_t safe = a.total_bytes >= (uint64_t)CHB ? (a.total_bytes - CHB) / group_bytes : 0;
+        const uint64_t safe = a.total_bytes >= (uint64_t)(NT * CHB) ? (a.total_bytes - NT * CHB) / group_bytes : 0;
         if (safe < last_group) last_group = safe;
     }
     if (g < last_group) {
@@ -404,29 +426,37 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         uint32_t pred_exit = 0xFFFFFFFFu; // chunk after which the previous group left early (prefetch predictor)
         begin_group(g);
         fetch(g, 0);
-        for (;;) {
-            // stage this tile and prefetch the one we expect to need next while this one is walked
-            const bool pf_same = (ck + 1 < n_chunks) && (ck < pred_exit);
+        // One tile: stage it, prefetch, walk it.  Returns 0 = same group continues with the next tile, 1 = a new
+        // group was begun (its unit 0 is in R or in flight), 2 = no safe group left for this wave.
+        auto step = [&](auto tc) __attribute__((always_inline)) -> int {
+            constexpr int T = decltype(tc)::value;
+            // Prefetch while this tile is walked whenever the unit's registers are all free after staging it: at
+            // the unit's last tile, at the group's last chunk, or where the previous group left early.
+            const bool do_pf = (T == NT - 1) || (ck + 1 >= n_chunks) || (ck >= pred_exit);
+            const bool pf_same = (T == NT - 1) && (ck + 1 < n_chunks) && (ck < pred_exit);
             const uint64_t pf_g = pf_same ? g : g + wave_cnt;
-            stage_and_fetch(pf_g < last_group, pf_g, pf_same ? ck + 1 : 0u);
+            stage_and_fetch(tc, do_pf && pf_g < last_group, pf_g, pf_same ? (ck + 1) / NT : 0u);
             asm volatile("" ::: "memory"); // keep the prefetch issued ahead of the walk
             const bool group_done = walk_tile(ck) || (ck + 1 >= n_chunks);
             if (!group_done) {
-                if (!pf_same) fetch(g, ck + 1); // predicted an early exit that did not happen
+                if (do_pf && !pf_same) fetch(g, (ck + 1) / NT); // predicted an exit that did not happen
                 ++ck;
-                continue;
+                return 0;
             }
             finish_group(g);
             pred_exit = (ck + 1 < n_chunks) ? ck : 0xFFFFFFFFu;
             const uint64_t ng = g + wave_cnt;
-            if (ng >= last_group) {
-                g = ng;
-                break;
-            }
-            if (pf_same) fetch(ng, 0); // the prefetch went to this group's next chunk: redirect
             g = ng;
+            if (ng >= last_group) return 2;
+            if (!do_pf || pf_same) fetch(ng, 0); // nothing (or this group's next unit) was prefetched: (re)direct
             ck = 0;
             begin_group(g);
+            return 1;
+        };
+        for (;;) {
+            int r = step(std::integral_constant<int, 0>{});
+            if (NT == 2 && r == 0) r = step(std::integral_constant<int, NT - 1>{});
+            if (r == 2) break;
         }
     }
     // ---- the batch's last group(s): clamped loads, no pipelining (at most a couple of waves in the whole grid)
@@ -434,7 +464,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         begin_group(g);
         for (uint32_t ck = 0; ck < n_chunks; ++ck) {
             fetch_clamped(g, ck);
-            stage_and_fetch(false, 0, 0);
+            stage_and_fetch(std::integral_constant<int, 0>{}, false, 0, 0);
             if (walk_tile(ck)) break;
         }
         finish_group(g);

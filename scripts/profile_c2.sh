@@ -8,8 +8,8 @@ W=${1:-c2}
 OUT=gpurun_out/prof_$W
 mkdir -p $OUT
 nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; python -c "import os;print(len(os.sched_getaffinity(0)))"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_write.json 2> $OUT/write.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_trace.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_fetch.json 2> $OUT/fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_write.json 2> $OUT/write.log
 find $OUT -name "*.csv" | head -20
 ls -la $OUT/*/* | head -30

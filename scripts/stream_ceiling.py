@@ -5,7 +5,7 @@ import ctypes, json, os, subprocess, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
 so = "/tmp/stream_read.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, os.path.join(here, "stream_read.hip")])
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, os.path.join(here, "..", "needle_amd", "csrc", "stream_probe.hip")])
 L = ctypes.CDLL(so)
 L.stream_read_launch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 n = 2_560_000_000

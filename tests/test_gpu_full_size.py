@@ -1,0 +1,166 @@
+"""Parity at BASELINE.json's FULL sizes (10^7 rows x 256 chars per GPU), where the CPU oracle would take minutes:
+size-independent properties of the domain, each computed a second way with plain torch integer ops on the same
+resident batch, plus the oracle itself on a seeded sample of rows spread over the whole batch.
+
+  C2  [0-9]+      containedIn  <=>  the row holds a digit                 (torch compare + any)
+                  find start   ==   index of the first digit, end == end of that digit run   (torch argmax)
+                  matches      <=>  every char of the row is a digit
+  C3  keywords    find.matched ==   containedIn bitmap; [start, end) spells one of the 1000 keywords; nothing matches
+                  when the row is cut one char before `end` (lengths = end - 1): leftmost match really ends at `end`
+  C5  BMP runs    find.matched ==   containedIn; [start, end) is a maximal run of in-range chars of length >= 3
+  all             partition invariance: the bitmap of the whole batch == the bitmaps of two unequal shards, joined
+                  (what row sharding across GPUs relies on); a second launch gives identical bits"""
+import numpy as np
+import pytest
+
+N_FULL = 10_000_000
+
+
+def make(workload, n=N_FULL):
+    import bench
+    pattern, _what, words = bench.make_pattern(workload)
+    rows = bench.make_rows(workload, words, 0, n, "cuda")
+    return pattern, rows, words
+
+
+def oracle_of(pattern):
+    from oracle.walker import Dfa, OraclePattern
+    t = pattern.tables()
+    d = {k: Dfa(t["class_map"], t["stride"], v["table"], v["accepting"], v["max_char"]) for k, v in t["dfas"].items()}
+    return OraclePattern(d["matches"], d["contained_in"], d["forwards"], d["backwards"], t["fixed_len"], -1)
+
+
+def sample_rows(n, k=60_000, seed=7):
+    rng = np.random.default_rng(seed)
+    idx = np.unique(np.concatenate([rng.integers(0, n, k), np.arange(0, 4096), np.arange(n - 4096, n)]))
+    return idx
+
+
+def check_sample_against_oracle(pattern, rows, fw_bits, fs, fe, c_bits):
+    import torch
+    idx = sample_rows(rows.shape[0])
+    host = rows[torch.from_numpy(idx).cuda()].cpu().numpy()
+    if host.dtype == np.int16:
+        host = host.view(np.uint16)
+    o = oracle_of(pattern)
+    of, ofs, ofe = o.batch_find(host, threads=8)
+    assert (fw_bits[idx] == of).all()
+    assert (fs[idx] == ofs).all() and (fe[idx] == ofe).all()
+    assert (c_bits[idx] == o.batch_contained_in(host, threads=8)).all()
+
+
+def partition_invariant(op, rows, whole_words):
+    import torch
+    cut = 64 * 61_237  # shards start on 64-row boundaries (needle_amd/sharding.py)
+    a, b = op(rows[:cut]), op(rows[cut:])
+    a, b = (a[0], b[0]) if isinstance(a, tuple) else (a, b)
+    assert torch.equal(torch.cat([a, b]), whole_words)
+
+
+@pytest.mark.gpu
+def test_c2_full_size_properties():
+    import torch
+    from needle_amd.pattern import unpack_bitmap
+    p, rows, _ = make("c2")
+    n = rows.shape[0]
+    cw = p.contained_in_batch(rows)
+    again = p.contained_in_batch(rows)
+    assert torch.equal(cw, again)
+    c_bits = unpack_bitmap(cw, n)
+    is_digit = (rows >= 48) & (rows <= 57)
+    has_digit = is_digit.any(dim=1)
+    assert (c_bits == has_digit.cpu().numpy()).all()
+    assert abs(c_bits.mean() - 0.5) < 0.001
+    fw, fs, fe = p.find_batch(rows)
+    f_bits = unpack_bitmap(fw, n)
+    assert (f_bits == c_bits).all()
+    first = is_digit.to(torch.uint8).argmax(dim=1).to(torch.int32)  # first maximum == first digit
+    want_start = torch.where(has_digit, first, torch.full_like(first, -1))
+    assert torch.equal(fs, want_start)
+    # end of the run that starts at `first`: first non-digit at or after it (or the row end)
+    cols = torch.arange(256, device="cuda", dtype=torch.int32)[None, :]
+    stop = (~is_digit) & (cols > first[:, None])
+    has_stop = stop.any(dim=1)
+    run_end = torch.where(has_stop, stop.to(torch.uint8).argmax(dim=1).to(torch.int32), torch.full_like(first, 256))
+    assert torch.equal(fe, torch.where(has_digit, run_end, torch.full_like(first, -1)))
+    del stop, cols
+    m_bits = unpack_bitmap(p.matches_batch(rows), n)
+    assert (m_bits == is_digit.all(dim=1).cpu().numpy()).all()
+    partition_invariant(p.contained_in_batch, rows, cw)
+    check_sample_against_oracle(p, rows, f_bits, fs.cpu().numpy(), fe.cpu().numpy(), c_bits)
+
+
+@pytest.mark.gpu
+def test_c3_full_size_properties():
+    import torch
+    from needle_amd.pattern import unpack_bitmap
+    p, rows, words = make("c3")
+    n = rows.shape[0]
+    fw, fs, fe = p.find_batch(rows)
+    fw2, fs2, fe2 = p.find_batch(rows)
+    assert torch.equal(fw, fw2) and torch.equal(fs, fs2) and torch.equal(fe, fe2)
+    f_bits = unpack_bitmap(fw, n)
+    cw = p.contained_in_batch(rows)
+    c_bits = unpack_bitmap(cw, n)
+    assert (f_bits == c_bits).all()
+    matched = torch.from_numpy(f_bits).cuda()
+    assert bool(((fs >= 0) == matched).all()) and bool(((fe > fs) | ~matched).all())
+    # [start, end) spells a keyword: base-32 code of the <= 5 letters, looked up in the keyword code set
+    ln = (fe - fs).clamp(min=0)
+    assert bool(((ln >= 3) & (ln <= 5) | ~matched).all())
+    code = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for j in range(5):
+        ch = rows.gather(1, (fs.long().clamp(min=0) + j).clamp(max=255)[:, None])[:, 0].long() - 96
+        code = torch.where(ln > j, code * 32 + ch, code)
+    wcodes = []
+    for w in words:
+        v = 0
+        for ch in w:
+            v = v * 32 + (ord(ch) - 96)
+        wcodes.append(v)
+    ok = torch.isin(code, torch.tensor(sorted(wcodes), dtype=torch.int64, device="cuda"))
+    assert bool((ok | ~matched).all())
+    # leftmost: with the row cut one char before `end`, indexForwards can no longer end at `end`; the match found
+    # there (if any) must not start before `start`
+    cut = torch.where(matched, fe - 1, torch.zeros_like(fe))
+    _w, cs, _ce = p.find_batch(rows, cut)
+    assert bool(((cs == -1) | (cs >= fs) | ~matched).all())
+    partition_invariant(p.find_batch, rows, fw)
+    check_sample_against_oracle(p, rows, f_bits, fs.cpu().numpy(), fe.cpu().numpy(), c_bits)
+
+
+@pytest.mark.gpu
+def test_c5_full_size_properties():
+    import torch
+    from needle_amd import workload as W
+    from needle_amd.pattern import unpack_bitmap
+    p, rows, _ = make("c5")
+    n = rows.shape[0]
+    fw, fs, fe = p.find_batch(rows)
+    f_bits = unpack_bitmap(fw, n)
+    cw = p.contained_in_batch(rows)
+    c_bits = unpack_bitmap(cw, n)
+    assert (f_bits == c_bits).all()
+    # class membership a second way: a 65536-entry torch lookup built from the same explicit ranges
+    lut = torch.zeros(65536, dtype=torch.bool, device="cuda")
+    for a, b in W.SCRIPT_RANGES:
+        lut[a:b + 1] = True
+    matched = torch.from_numpy(f_bits).cuda()
+    slab = 1 << 20
+    for s in range(0, n, slab):
+        r = rows[s:s + slab].long() & 0xFFFF
+        member = lut[r]
+        st, en, mt = fs[s:s + slab].long(), fe[s:s + slab].long(), matched[s:s + slab]
+        cols = torch.arange(256, device="cuda")[None, :]
+        inside = (cols >= st[:, None]) & (cols < en[:, None])
+        assert bool(((member | ~inside).all(dim=1) | ~mt).all())  # every char of the span is in-range
+        assert bool((((en - st) >= 3) | ~mt).all())
+        after = member.gather(1, en.clamp(0, 255)[:, None])[:, 0] & (en < 256)
+        assert bool((~after | ~mt).all())  # greedy: the run cannot be extended
+        before = member.gather(1, (st - 1).clamp(0, 255)[:, None])[:, 0] & (st > 0)
+        assert bool((~before | ~mt).all())  # leftmost: it is not the tail of a longer run
+        # no match <=> no run of 3 in-range chars anywhere in the row
+        run3 = member[:, :-2] & member[:, 1:-1] & member[:, 2:]
+        assert bool((run3.any(dim=1) == mt).all())
+    partition_invariant(p.find_batch, rows, fw)
+    check_sample_against_oracle(p, rows, f_bits, fs.cpu().numpy(), fe.cpu().numpy(), c_bits)
