@@ -102,7 +102,8 @@ def cpu_baseline(workload, pattern, rows_dev, budget_s=12.0):
 
 def measured_read_ceiling(buf):
     """This GPU's streaming-READ ceiling on the bench's own resident buffer: a trivial coalesced read-reduce kernel
-    (needle_amd/csrc/stream_probe.hip, a measurement aid outside the product ABI), best of a few launch shapes."""
+    (needle_amd/csrc/stream_probe.hip, a measurement aid outside the product ABI), best of a few launch shapes with
+    plain and with nontemporal loads."""
     import ctypes
     import torch
     from needle_amd.build import PROBE_LIB
@@ -114,7 +115,7 @@ def measured_read_ceiling(buf):
     out = torch.zeros(4, dtype=torch.int32, device=buf.device)
     s = torch.cuda.current_stream().cuda_stream
     best = 0.0
-    for blocks, unroll in ((2048, 4), (4096, 4), (4096, 8), (8192, 8)):
+    for blocks, unroll in ((2048, 1), (4096, 1), (2048, 4), (4096, 4), (4096, 8), (8192, 8), (2048, 104), (4096, 104), (4096, 108), (8192, 108)):  # 1xx = nt loads
         for _ in range(2):
             L.stream_read_launch(buf.data_ptr(), n, out.data_ptr(), blocks, unroll, s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

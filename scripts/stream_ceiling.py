@@ -14,7 +14,7 @@ out = torch.zeros(4, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 best = {}
 for blocks in (256 * 4, 256 * 8, 256 * 16, 256 * 32):
-    for unroll in (1, 4, 8):
+    for unroll in (1, 4, 8, 104, 108):
         for _ in range(3):
             L.stream_read_launch(buf.data_ptr(), n, out.data_ptr(), blocks, unroll, s)
         torch.cuda.synchronize()
