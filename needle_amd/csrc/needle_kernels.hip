@@ -53,6 +53,7 @@ struct Geom {
     __device__ static __forceinline__ int swz(int r) { return CHB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 };
 
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
 // 16 bytes of haystack.  STREAM: the wave consumes whole 128-byte lines exactly once -> `global_load ... nt`
@@ -119,6 +120,13 @@ __device__ __forceinline__ uint32_t or_byte(uint32_t a, uint32_t w) { // a | (by
 __device__ __forceinline__ uint32_t lds_u8(uint32_t a) { return *(NEEDLE_LDS(uint8_t))(uintptr_t)(a); }
 __device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *(NEEDLE_LDS(uint16_t))(uintptr_t)(a); }
 __device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(NEEDLE_LDS(uint32_t))(uintptr_t)(a); }
+
+// One wait for every LDS read issued so far, and nothing scheduled across it.
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // Walk constants a lane keeps in registers (see the fixed LDS layout in needle_device.h).
 struct Walk {
@@ -283,6 +291,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     int32_t last;
     int32_t cursor = 0;  // OP_FIND with per-row cursors: Matcher.nextStart (FROM of find(FROM, TO)); < 0 = exhausted
     bool dead = false;
+    // OP_FIND with a backward automaton: the three dwords of row text ending with the one that holds the char at
+    // lastMatch - 1 (copied out of the LDS tile while it is there), and the last two dwords of the previous tile.
+    // indexBackwards then starts on registers: going back to the row in memory costs a second fetch of its 128-byte
+    // line from HBM per matched row (C3: +1.28 GB on a 2.56 GB batch).
+    constexpr int CPD = 4 / CW;            // chars per dword
+    constexpr int HN = (CW == 1) ? 3 : 5; // snapshot dwords: >= 9 chars back from lastMatch - 1 at any alignment
+    // (native vectors, constant indices after unrolling: plain arrays captured by the lambdas end up in scratch)
+    u32x8 hist = {0, 0, 0, 0, 0, 0, 0, 0}; // [0 .. HN)
+    u32x4 carry = {0, 0, 0, 0};            // carry[i]: dword (last - i) of the previous tile
+    auto tile_dword = [&](uint32_t j) __attribute__((always_inline)) -> uint32_t {
+        return lds_u32(tile.row_addr + ((((j >> 2) ^ (uint32_t)G::swz(lane))) << 4) + ((j & 3u) << 2));
+    };
     auto begin_group = [&](uint64_t grp) __attribute__((always_inline)) {
         my_row = (grp << 6) + lane;
         row_ok = my_row < a.n_rows;
@@ -326,19 +346,49 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             if (lane_live) {
             // all state-independent lookups of the piece first (they pipeline in the LDS) ...
             uint32_t col[CPP];
-#define NEEDLE_LOOKUP(D, K)                                                                         \
-    col[(D) * (4 / CW) + (K)] = lookup<MODE, CW, GUARD, K>(wk, w[D], p0 + (D) * (4 / CW) + (K) < rem, \
-                                                           p0 + (D) * (4 / CW) + (K) < skip);
+            if (CW == 2) {
+                // UTF-16: three dependent lookups per char (page table -> page -> F).  Issued as three batches of 8
+                // with ONE wait between batches: left to the scheduler they come out as ~14 short waits per piece,
+                // each exposing a full LDS round trip.
+                constexpr uint32_t kPages = (MODE == MODE_PACK) ? kLdsPages2Pack : kLdsPages2Table;
+                uint32_t pg[CPP], ce[CPP];
+#define NEEDLE_PG(D, K) pg[(D) * 2 + (K)] = lds_u16(shl_byte<(2 * (K) + 1) & 3>(w[D], 1) + kLdsPtab2);
+#define NEEDLE_CE(D, K) ce[(D) * 2 + (K)] = lds_u8(or_byte<(2 * (K)) & 3>(pg[(D) * 2 + (K)], w[D]) + kPages);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                NEEDLE_LOOKUP(d, 0)
-                NEEDLE_LOOKUP(d, 1)
-                if (CW == 1) {
+                for (int d = 0; d < 4; ++d) {
+                    NEEDLE_PG(d, 0)
+                    NEEDLE_PG(d, 1)
+                }
+                lds_fence();
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    NEEDLE_CE(d, 0)
+                    NEEDLE_CE(d, 1)
+                }
+                lds_fence();
+#undef NEEDLE_PG
+#undef NEEDLE_CE
+#pragma unroll
+                for (int i = 0; i < CPP; ++i) {
+                    uint32_t c = (MODE == MODE_PACK) ? lds_u32(ce[i] + kLdsF2) : ce[i]; // pages hold column * 4 | * element size
+                    if (GUARD) {
+                        c = (p0 + i < rem) ? c : wk.pad_e;
+                        c = (p0 + i < skip) ? wk.pre_e : c;
+                    }
+                    col[i] = c;
+                }
+            } else {
+#define NEEDLE_LOOKUP(D, K)                                                                         \
+    col[(D) * 4 + (K)] = lookup<MODE, 1, GUARD, K>(wk, w[D], p0 + (D) * 4 + (K) < rem, p0 + (D) * 4 + (K) < skip);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    NEEDLE_LOOKUP(d, 0)
+                    NEEDLE_LOOKUP(d, 1)
                     NEEDLE_LOOKUP(d, 2)
                     NEEDLE_LOOKUP(d, 3)
                 }
-            }
 #undef NEEDLE_LOOKUP
+            }
             // ... then ONE wait for all of them instead of one s_waitcnt per char (the walk is issue-bound), ...
             if (MODE == MODE_PACK && NEEDLE_PIECE_FENCE) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -357,7 +407,25 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             }
             } // lane_live
         }
-        if (OP == OP_FIND) last = last_rel >= 0 ? (int32_t)idx0 + last_rel : last;
+        if (OP == OP_FIND) {
+            if (a.fixed_len < 0) { // wave-uniform
+                if (last_rel >= 0) {
+                    const uint32_t de = (uint32_t)(last_rel - 1) / CPD; // tile dword holding the accepting char
+#pragma unroll
+                    for (int i = 0; i < HN; ++i) {
+                        const uint32_t t = tile_dword(de >= (uint32_t)i ? de - i : 0);
+                        const uint32_t back = (uint32_t)i - de - 1u; // when de < i: how far into the previous tile
+                        uint32_t c = carry[0];
+#pragma unroll
+                        for (int k = 1; k < HN - 1; ++k) c = back == (uint32_t)k ? carry[k] : c; // back <= i - 1 <= HN - 2
+                        hist[i] = de >= (uint32_t)i ? t : c;
+                    }
+                }
+                const u32x4 tail = tile_piece<CHB>(tile, lane, G::kPieces - 1);
+                carry = tail.wzyx;
+            }
+            last = last_rel >= 0 ? (int32_t)idx0 + last_rel : last;
+        }
         // wave-uniform early exit: every lane has an absorbing verdict (sink, or accepted for containedIn)
         bool live;
         if (OP == OP_CONTAINED_IN) live = st < accept_lo;
@@ -387,6 +455,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo;
             const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
             int32_t idx_b = last - 1;
+            const int32_t hist_dword = (last > 0 ? last - 1 : 0) / CPD; // row dword index of hist0
             uint32_t bs = a.bhdr.start;
             int32_t lastb = a.bhdr.root_accepting ? cursor : INT_MAX; // :543-547 (LENGTH var = FROM)
             bool active = res;
@@ -396,7 +465,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                 for (int k = 0; k < 8; ++k) {
                     const int32_t p = idx_b - k;
                     cs[k] = 0;
-                    if (active && p >= cursor) cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
+                    if (active && p >= cursor) {
+                        const int32_t rel = hist_dword - p / CPD; // 0 .. HN-1: still inside the snapshot
+                        if (rel < HN) {
+                            uint32_t word = hist[0];
+#pragma unroll
+                            for (int i = 1; i < HN; ++i) word = rel == i ? hist[i] : word;
+                            cs[k] = (word >> ((uint32_t)(p % CPD) * (8u * CW))) & (CW == 1 ? 0xFFu : 0xFFFFu);
+                        } else {
+                            cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p]; // a match longer than the snapshot
+                        }
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
