@@ -67,6 +67,24 @@ public final class GpuPattern implements Pattern, AutoCloseable {
         return bitmap;
     }
 
+    /**
+     * find() over an array of haystacks: the strings are flattened to one char buffer + offsets (no per-string
+     * Matcher objects, SURVEY.md s8 a9) and cross the boundary once.  Returns the match bitmap.
+     */
+    public long[] findBatch(String[] haystacks, int[] start, int[] end) {
+        long[] offsets = new long[haystacks.length + 1];
+        for (int i = 0; i < haystacks.length; i++) {
+            offsets[i + 1] = offsets[i] + haystacks[i].length();
+        }
+        char[] data = new char[(int) offsets[haystacks.length]];
+        for (int i = 0; i < haystacks.length; i++) {
+            haystacks[i].getChars(0, haystacks[i].length(), data, (int) offsets[i]);
+        }
+        long[] bitmap = new long[(haystacks.length + 63) / 64];
+        check(Native.packedHost(handle, 2, data, offsets, bitmap, start, end), null);
+        return bitmap;
+    }
+
     @Override
     public void close() {
         if (handle != 0) {

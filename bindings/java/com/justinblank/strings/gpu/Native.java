@@ -45,6 +45,12 @@ final class Native {
     static native int findHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride,
                                int rowLen, java.nio.ByteBuffer lengths, long[] bitmap, int[] start, int[] end);
 
+    /**
+     * Packed host batches (needle_*_packed_host): the UTF-16 code units of all haystacks back to back + offsets[n + 1]
+     * (what a String[] flattens to).  op: 0 matches, 1 containedIn, 2 find (start/end may be null otherwise).
+     */
+    static native int packedHost(long handle, int op, char[] data, long[] offsets, long[] bitmap, int[] start, int[] end);
+
     // one Matcher (reference cursor semantics)
     static native int matcherCreate(long pattern, char[] s, long[] handleOut);
 

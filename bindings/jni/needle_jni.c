@@ -109,6 +109,31 @@ NATIVE(jint, findHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jl
     return bitmap_call(env, 2, h, &v, bitmap, start, end);
 }
 
+NATIVE(jint, packedHost)(JNIEnv *env, jclass c, jlong h, jint op, jcharArray data, jlongArray offsets, jlongArray bitmap, jintArray start, jintArray end) {
+    needle_packed_view v;
+    memset(&v, 0, sizeof(v));
+    jsize n1 = (*env)->GetArrayLength(env, offsets);
+    jchar *d = (*env)->GetCharArrayElements(env, data, NULL);
+    jlong *o = (*env)->GetLongArrayElements(env, offsets, NULL);
+    jlong *bm = (*env)->GetLongArrayElements(env, bitmap, NULL);
+    jint *st = start ? (*env)->GetIntArrayElements(env, start, NULL) : NULL;
+    jint *en = end ? (*env)->GetIntArrayElements(env, end, NULL) : NULL;
+    v.data = d;
+    v.char_width = 2;
+    v.n_rows = (uint64_t)(n1 - 1);
+    v.offsets = (const uint64_t *)o;
+    const needle_pattern *p = (const needle_pattern *)(intptr_t)h;
+    int rc = op == 0   ? needle_matches_packed_host(p, &v, (uint64_t *)bm)
+             : op == 1 ? needle_contained_in_packed_host(p, &v, (uint64_t *)bm)
+                       : needle_find_packed_host(p, &v, (uint64_t *)bm, (int32_t *)st, (int32_t *)en);
+    (*env)->ReleaseCharArrayElements(env, data, d, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, offsets, o, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, bitmap, bm, 0);
+    if (st) (*env)->ReleaseIntArrayElements(env, start, st, 0);
+    if (en) (*env)->ReleaseIntArrayElements(env, end, en, 0);
+    return rc;
+}
+
 NATIVE(jint, matcherCreate)(JNIEnv *env, jclass c, jlong pattern, jcharArray s, jlongArray out) {
     jsize n = (*env)->GetArrayLength(env, s);
     jchar *u = (*env)->GetCharArrayElements(env, s, NULL);

@@ -14,7 +14,8 @@ EXPORTS = [
     "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_find_next_dev", "needle_matches_host",
     "needle_contained_in_host", "needle_find_host", "needle_matcher_create", "needle_matcher_destroy",
     "needle_matcher_matches", "needle_matcher_contained_in", "needle_matcher_find", "needle_matcher_find_range",
-    "needle_matcher_start", "needle_matcher_end",
+    "needle_matcher_start", "needle_matcher_end", "needle_rows_from_packed_dev", "needle_matches_packed_host",
+    "needle_contained_in_packed_host", "needle_find_packed_host",
 ]
 
 
@@ -31,6 +32,11 @@ class TableDesc(ctypes.Structure):
 class BatchView(ctypes.Structure):
     _fields_ = [("rows", ctypes.c_void_p), ("char_width", ctypes.c_uint32), ("n_rows", ctypes.c_uint64),
                 ("row_stride", ctypes.c_uint64), ("row_len", ctypes.c_uint32), ("lengths", ctypes.c_void_p)]
+
+
+class PackedView(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("char_width", ctypes.c_uint32), ("n_rows", ctypes.c_uint64),
+                ("offsets", ctypes.c_void_p)]
 
 
 class PatternInfo(ctypes.Structure):
@@ -78,6 +84,10 @@ def lib():
     for n in ("needle_matches_host", "needle_contained_in_host"):
         getattr(L, n).argtypes = [VP, P(BatchView), VP]
     L.needle_find_host.argtypes = [VP, P(BatchView), VP, VP, VP]
+    L.needle_rows_from_packed_dev.argtypes = [P(PackedView), VP, ctypes.c_uint64, VP, VP, VP]
+    for n in ("needle_matches_packed_host", "needle_contained_in_packed_host"):
+        getattr(L, n).argtypes = [VP, P(PackedView), VP]
+    L.needle_find_packed_host.argtypes = [VP, P(PackedView), VP, VP, VP]
     L.needle_matcher_create.argtypes = [VP, VP, ctypes.c_size_t, P(VP)]
     L.needle_matcher_destroy.argtypes = [VP]
     L.needle_matcher_destroy.restype = None

@@ -17,6 +17,8 @@
 namespace needle {
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
 bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows);
+hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
+                         uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
 } // namespace needle
 
 using namespace needle;
@@ -215,8 +217,129 @@ static int run_host(const needle_pattern *p, int op, const needle_batch_view *v,
 #undef HIP_TRY_C
 }
 
+static int check_packed(const needle_packed_view *v) {
+    if (!v) return fail(NEEDLE_ERR_INVALID, "packed view is NULL");
+    if (v->char_width != 1 && v->char_width != 2) return fail(NEEDLE_ERR_INVALID, "char_width must be 1 or 2");
+    if (!v->offsets) return fail(NEEDLE_ERR_INVALID, "offsets is NULL");
+    return NEEDLE_OK;
+}
+
+// Packed host batch: upload data + offsets, convert to the fixed-stride layout on the device, run, download.
+static int run_packed_host(const needle_pattern *p, int op, const needle_packed_view *v, uint64_t *bitmap, int32_t *start,
+                           int32_t *end) {
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_packed(v);
+    if (rc) return rc;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!bitmap) return fail(NEEDLE_ERR_INVALID, "bitmap is NULL");
+    if (op == OP_FIND && (!start || !end)) return fail(NEEDLE_ERR_INVALID, "start/end is NULL");
+    const uint64_t cw = v->char_width;
+    uint64_t max_len = 0;
+    for (uint64_t r = 0; r < v->n_rows; ++r) {
+        if (v->offsets[r + 1] < v->offsets[r]) return fail(NEEDLE_ERR_INVALID, "offsets must be non-decreasing");
+        max_len = std::max<uint64_t>(max_len, v->offsets[r + 1] - v->offsets[r]);
+    }
+    if (max_len > 0xFFFFFFFFull) return fail(NEEDLE_ERR_INVALID, "row longer than 2^32 - 1 chars");
+    const uint64_t total_chars = v->offsets[v->n_rows];
+    if (total_chars && !v->data) return fail(NEEDLE_ERR_INVALID, "data is NULL");
+    uint64_t stride_bytes = (max_len * cw + 15) & ~(uint64_t)15;
+    if (stride_bytes == 0) stride_bytes = 16;
+    const size_t words = (v->n_rows + 63) / 64;
+    void *d_data = nullptr, *d_rows = nullptr;
+    uint64_t *d_off = nullptr, *d_bm = nullptr;
+    uint32_t *d_len = nullptr;
+    int32_t *d_s = nullptr, *d_e = nullptr;
+    auto cleanup = [&]() {
+        for (void *q : {d_data, d_rows, (void *)d_off, (void *)d_bm, (void *)d_len, (void *)d_s, (void *)d_e})
+            if (q) (void)hipFree(q);
+    };
+#define HIP_TRY_C(expr)                                    \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) {                            \
+            cleanup();                                     \
+            return hip_fail(_e, #expr);                    \
+        }                                                  \
+    } while (0)
+    const size_t data_bytes = (size_t)((total_chars * cw + 3) & ~(uint64_t)3);
+    HIP_TRY_C(hipMalloc(&d_data, data_bytes ? data_bytes : 4));
+    if (total_chars) HIP_TRY_C(hipMemcpy(d_data, v->data, (size_t)(total_chars * cw), hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMalloc((void **)&d_off, (v->n_rows + 1) * 8));
+    HIP_TRY_C(hipMemcpy(d_off, v->offsets, (v->n_rows + 1) * 8, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMalloc(&d_rows, v->n_rows * stride_bytes));
+    HIP_TRY_C(hipMalloc((void **)&d_len, v->n_rows * 4));
+    HIP_TRY_C(hipMalloc((void **)&d_bm, words * 8));
+    if (op == OP_FIND) {
+        HIP_TRY_C(hipMalloc((void **)&d_s, v->n_rows * 4));
+        HIP_TRY_C(hipMalloc((void **)&d_e, v->n_rows * 4));
+    }
+    needle_packed_view dpv = *v;
+    dpv.data = d_data;
+    dpv.offsets = d_off;
+    rc = needle_rows_from_packed_dev(&dpv, d_rows, stride_bytes / cw, d_len, nullptr, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    needle_batch_view bv;
+    memset(&bv, 0, sizeof(bv));
+    bv.rows = d_rows;
+    bv.char_width = v->char_width;
+    bv.n_rows = v->n_rows;
+    bv.row_stride = stride_bytes / cw;
+    bv.lengths = d_len;
+    rc = run_dev(p, op, &bv, d_bm, d_s, d_e, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    HIP_TRY_C(hipDeviceSynchronize());
+    HIP_TRY_C(hipMemcpy(bitmap, d_bm, words * 8, hipMemcpyDeviceToHost));
+    if (op == OP_FIND) {
+        HIP_TRY_C(hipMemcpy(start, d_s, v->n_rows * 4, hipMemcpyDeviceToHost));
+        HIP_TRY_C(hipMemcpy(end, d_e, v->n_rows * 4, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+    return NEEDLE_OK;
+#undef HIP_TRY_C
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+int needle_rows_from_packed_dev(const needle_packed_view *v, void *d_rows, uint64_t row_stride, uint32_t *d_lengths,
+                                int32_t *d_overflow, void *stream) {
+    int rc = check_packed(v);
+    if (rc) return rc;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_rows || !d_lengths) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    const uint64_t stride_bytes = row_stride * v->char_width;
+    if (stride_bytes == 0 || stride_bytes % 16 != 0)
+        return fail(NEEDLE_ERR_INVALID, "row_stride * char_width must be a non-zero multiple of 16 bytes");
+    if (((uintptr_t)d_rows) % 16 != 0) return fail(NEEDLE_ERR_INVALID, "d_rows must be 16-byte aligned");
+    if (((uintptr_t)v->data) % 4 != 0) return fail(NEEDLE_ERR_INVALID, "packed data must be 4-byte aligned");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    static thread_local int cus_cached = 0;
+    if (!cus_cached) {
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        cus_cached = prop.multiProcessorCount;
+    }
+    HIP_TRY(launch_unpack(v->data, v->offsets, v->n_rows, v->char_width, d_rows, stride_bytes, d_lengths, d_overflow,
+                          cus_cached, (hipStream_t)stream));
+    return NEEDLE_OK;
+}
+
+int needle_matches_packed_host(const needle_pattern *p, const needle_packed_view *v, uint64_t *bm) {
+    return run_packed_host(p, OP_MATCHES, v, bm, nullptr, nullptr);
+}
+int needle_contained_in_packed_host(const needle_pattern *p, const needle_packed_view *v, uint64_t *bm) {
+    return run_packed_host(p, OP_CONTAINED_IN, v, bm, nullptr, nullptr);
+}
+int needle_find_packed_host(const needle_pattern *p, const needle_packed_view *v, uint64_t *bm, int32_t *st, int32_t *en) {
+    return run_packed_host(p, OP_FIND, v, bm, st, en);
+}
 
 const char *needle_version(void) { return "needle_hip 0.1 (gfx950)"; }
 const char *needle_last_error(void) { return g_err.c_str(); }

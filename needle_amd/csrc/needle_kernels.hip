@@ -563,6 +563,63 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
 }
 
 // ------------------------------------------------------------------------------------------------
+// packed ("CSR") rows -> fixed-stride rows: one thread per 16-byte piece of the output.  Output stores are
+// lane-linear 16-byte pieces (fully coalesced); the source of a piece starts at an arbitrary byte of the packed
+// buffer, so it is read as five ALIGNED dwords and funnel-shifted (v_alignbyte) into place.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ offsets,
+                                                     uint64_t n_rows, uint32_t cw, uint8_t *__restrict__ out,
+                                                     uint64_t stride_bytes, uint32_t *__restrict__ lengths,
+                                                     int32_t *overflow) {
+    const uint64_t ppr = stride_bytes >> 4; // pieces per row
+    const uint64_t total = n_rows * ppr;
+    const uint64_t end_bytes = offsets[n_rows] * cw;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = q / ppr;
+        const uint32_t k = (uint32_t)(q - row * ppr);
+        const uint64_t b0 = offsets[row] * cw;
+        uint64_t len_b = offsets[row + 1] * cw - b0;
+        if (len_b > stride_bytes) {
+            len_b = stride_bytes;
+            if (k == 0 && overflow) *overflow = 1;
+        }
+        if (k == 0) lengths[row] = (uint32_t)(len_b / cw);
+        const uint64_t pos = (uint64_t)k * 16u; // byte position of this piece inside the row
+        u32x4 v = {0, 0, 0, 0};
+        if (pos < len_b) {
+            const uint64_t src = b0 + pos;
+            const uint64_t base = src & ~(uint64_t)3;
+            const uint32_t sh = (uint32_t)(src & 3u);
+            uint32_t d[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) d[i] = (base + 4u * i < end_bytes) ? *(const uint32_t *)(data + base + 4u * i) : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+            const uint64_t valid = len_b - pos; // bytes of the row in this piece (>= 16: all of it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t lo = 4u * i;
+                if (valid <= lo) v[i] = 0;
+                else if (valid < lo + 4u) v[i] &= (1u << (8u * (uint32_t)(valid - lo))) - 1u;
+            }
+        }
+        *(u32x4 *)(out + row * stride_bytes + pos) = v;
+    }
+}
+
+hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
+                         uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream) {
+    const uint64_t total = n_rows * (stride_bytes >> 4);
+    uint64_t blocks = (total + 255) / 256;
+    const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t *)data, offsets, n_rows, cw,
+                       (uint8_t *)out, stride_bytes, lengths, overflow);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
 struct LaunchShape {

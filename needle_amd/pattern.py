@@ -305,6 +305,79 @@ class Pattern:
         """(bitmap words, start int32[n], end int32[n]); unmatched rows have start = end = -1."""
         return self._run("find", rows, lengths, stream)
 
+    # ---- haystacks packed back to back (one char buffer + offsets: what a JNI host gets from a String[])
+    def _run_packed_host(self, op, data, offsets):
+        L = _lib.lib()
+        data = np.ascontiguousarray(data)
+        if data.dtype == np.int16:
+            data = data.view(np.uint16)
+        assert data.ndim == 1 and data.dtype in (np.uint8, np.uint16), "data: 1-D uint8/uint16 code units"
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        v = _lib.PackedView()
+        v.data, v.char_width, v.n_rows, v.offsets = data.ctypes.data, data.dtype.itemsize, n, offsets.ctypes.data
+        words = np.zeros((n + 63) // 64, dtype=np.uint64)
+        if op == "find":
+            st = np.full(n, -1, dtype=np.int32)
+            en = np.full(n, -1, dtype=np.int32)
+            _check(L.needle_find_packed_host(self._h, ctypes.byref(v), words.ctypes.data, st.ctypes.data, en.ctypes.data))
+            return words, st, en
+        fn = L.needle_matches_packed_host if op == "matches" else L.needle_contained_in_packed_host
+        _check(fn(self._h, ctypes.byref(v), words.ctypes.data))
+        return words
+
+    def matches_packed(self, data, offsets):
+        return self._run_packed_host("matches", data, offsets)
+
+    def contained_in_packed(self, data, offsets):
+        return self._run_packed_host("contained_in", data, offsets)
+
+    def find_packed(self, data, offsets):
+        return self._run_packed_host("find", data, offsets)
+
+    def find_strings(self, strings):
+        """find() over a list of str (UTF-16 code units, like java.lang.String) -> (matched bool[n], start, end)."""
+        data, offsets = pack_strings(strings)
+        words, st, en = self.find_packed(data, offsets)
+        return unpack_bitmap(words, len(strings)), st, en
+
+    @staticmethod
+    def rows_from_packed(data, offsets, row_stride=None, stream=None):
+        """Device tensors: packed code units (1-D uint8 | int16) + int64 offsets[n + 1] -> (rows [n, row_stride],
+        lengths int32[n]) in the fixed-stride layout the scan kernels read.  row_stride defaults to the longest row
+        rounded up to 16 bytes (one device->host sync to learn it)."""
+        import torch
+        L = _lib.lib()
+        assert data.is_cuda and data.dim() == 1 and data.is_contiguous() and data.dtype in (torch.uint8, torch.int16, torch.uint16)
+        assert offsets.is_cuda and offsets.dtype == torch.int64 and offsets.dim() == 1 and offsets.is_contiguous()
+        n = offsets.numel() - 1
+        cw = data.element_size()
+        per = 16 // cw
+        if row_stride is None:
+            longest = int((offsets[1:] - offsets[:-1]).max().item()) if n else 0
+            row_stride = max(per, (longest + per - 1) // per * per)
+        assert row_stride % per == 0
+        with torch.cuda.device(data.device):
+            s = torch.cuda.current_stream(data.device).cuda_stream if stream is None else stream
+            rows = torch.empty((n, row_stride), dtype=data.dtype, device=data.device)
+            lengths = torch.empty(n, dtype=torch.int32, device=data.device)
+            overflow = torch.zeros(1, dtype=torch.int32, device=data.device)
+            v = _lib.PackedView()
+            v.data, v.char_width, v.n_rows, v.offsets = data.data_ptr(), cw, n, offsets.data_ptr()
+            _check(L.needle_rows_from_packed_dev(ctypes.byref(v), rows.data_ptr(), row_stride, lengths.data_ptr(),
+                                                 overflow.data_ptr(), s))
+        return rows, lengths, overflow
+
+
+def pack_strings(strings):
+    """list[str] -> (uint16 code units back to back, uint64 offsets[n + 1])."""
+    units = [_utf16(x) for x in strings]
+    offsets = np.zeros(len(units) + 1, dtype=np.uint64)
+    if units:
+        offsets[1:] = np.cumsum([u.size for u in units])
+    data = np.concatenate(units) if units else np.zeros(0, dtype=np.uint16)
+    return data.astype(np.uint16), offsets
+
 
 def unpack_bitmap(words, n_rows):
     """bitmap words -> bool array of n_rows (numpy)."""

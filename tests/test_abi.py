@@ -91,3 +91,22 @@ def test_precompiled_blob_roundtrip(lib):
     for bad in (blob[:100], blob[:-1], b"XXXX" + blob[4:], blob + b"\0", blob[:8] + b"\xff\xff\xff\x7f" + blob[12:]):
         with pytest.raises(ValueError):
             Pattern.from_bytes(bad)
+
+
+def test_packed_view_validation_without_a_gpu(lib):
+    """Argument checks of the packed (offsets) entry points happen before any device call."""
+    from needle_amd import _lib
+    from needle_amd.pattern import DFACompiler
+    p = DFACompiler.compile("[0-9]+", "d")
+    data = np.frombuffer(b"ab12cd", dtype=np.uint8).copy()
+    bad_offsets = np.array([0, 4, 2], dtype=np.uint64)  # decreasing
+    with pytest.raises(ValueError):
+        p.find_packed(data, bad_offsets)
+    v = _lib.PackedView()
+    v.data, v.char_width, v.n_rows, v.offsets = data.ctypes.data, 3, 1, bad_offsets.ctypes.data
+    assert lib.needle_rows_from_packed_dev(ctypes.byref(v), None, 16, None, None, None) == _lib.ERR_INVALID
+    v.char_width = 1
+    assert lib.needle_rows_from_packed_dev(ctypes.byref(v), None, 16, None, None, None) == _lib.ERR_INVALID  # NULL outputs
+    # zero rows: nothing to do, no device needed
+    words = p.contained_in_packed(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
+    assert words.size == 0
