@@ -17,6 +17,7 @@
 namespace needle {
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
 bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows);
+hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipStream_t stream);
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
 } // namespace needle
@@ -117,6 +118,44 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     const bool need_backward = op == OP_FIND && p->t.fixed_len < 0;
     rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
+    // Few, long rows: one row per lane would leave the chip idle.  Packed-mode automata take the stripe path
+    // (function composition, needle_kernels.hip); NEEDLE_LONG_ROWS=0 turns it off, =1 forces it (tests).
+    {
+        static const int force = getenv("NEEDLE_LONG_ROWS") ? atoi(getenv("NEEDLE_LONG_ROWS")) : -1;
+        const uint64_t stride_bytes = v->row_stride * v->char_width;
+        const bool wanted = force >= 0 ? force == 1 : (v->n_rows < 65536 && stride_bytes >= 8 * (uint64_t)kStripeBytes);
+        if (wanted && fp->prog.hdr.mode == MODE_PACK && !d_from && (uint64_t)v->row_len <= v->row_stride) {
+            StripeArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.rows = (const uint8_t *)v->rows;
+            sa.n_rows = v->n_rows;
+            sa.stride_bytes = stride_bytes;
+            sa.row_len = v->row_len;
+            sa.lengths = v->lengths;
+            sa.prog = fp->d_blob;
+            sa.hdr = fp->prog.hdr;
+            sa.spr = (uint32_t)((stride_bytes + kStripeBytes - 1) / kStripeBytes);
+            sa.bitmap = d_bitmap;
+            sa.start = d_start;
+            sa.end = d_end;
+            sa.fixed_len = -1;
+            sa.op = (uint32_t)op;
+            if (op == OP_FIND) {
+                sa.fixed_len = p->t.fixed_len;
+                if (sa.fixed_len < 0) {
+                    rc = get_program(p, W_BACKWARDS, (int)v->char_width, 1, &bp, nullptr);
+                    if (rc) return rc;
+                    sa.bprog = bp->d_blob;
+                    sa.bhdr = bp->prog.hdr;
+                }
+            }
+            HIP_TRY(hipMallocAsync((void **)&sa.fn, (size_t)sa.n_rows * sa.spr * 4, (hipStream_t)stream));
+            hipError_t e = launch_long_rows((int)v->char_width, sa, n_cus, (hipStream_t)stream);
+            (void)hipFreeAsync(sa.fn, (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "launch_long_rows");
+            return NEEDLE_OK;
+        }
+    }
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = (const uint8_t *)v->rows;

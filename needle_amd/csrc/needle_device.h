@@ -67,6 +67,29 @@ struct ScanArgs {
     int32_t *end;
 };
 
+// Long rows: a row is cut into 4 KiB stripes (one wave-step each, 64 contiguous bytes per lane) and
+// the automaton's transition FUNCTION of every stripe is computed for all entry states at once (packed mode only).
+constexpr uint32_t kStripeBytes = 4096;
+struct StripeArgs {
+    const uint8_t *rows;
+    uint64_t n_rows;
+    uint64_t stride_bytes;
+    uint32_t row_len;        // chars, when lengths == nullptr
+    const uint32_t *lengths;
+    const uint8_t *prog;     // packed-mode program blob
+    ProgHeader hdr;
+    uint32_t spr;            // stripes per row = ceil(stride_bytes / kStripeBytes)
+    uint32_t *fn;            // [n_rows][spr]: pass 1 writes each stripe's function, the prefix pass replaces it by the
+                             // stripe's ENTRY state (5 * device state id)
+    uint64_t *bitmap;        // prefix pass: verdicts (matches / containedIn), or "matched" for find (set by the last pass)
+    int32_t *end;            // find: lastMatch per row (pass 2, atomicMax); initialised by the prefix pass
+    int32_t *start;          // find: written by the backward pass
+    const uint8_t *bprog;    // find: backward program (global-walk layout) and header
+    ProgHeader bhdr;
+    int32_t fixed_len;
+    uint32_t op;
+};
+
 // Fixed LDS byte offsets of the forward automaton (compile-time so that they fold into ds_read immediates).
 //   char_width 1:  packed: F[256][64] u32 at 0 (one copy per lane) table modes: cmap16[256] at 0, table at 512
 //   char_width 2:  ptab16[256] at 0 (page * 256);  packed: F[64] u32 at 512, pages8 (col * 4) at 768

@@ -1,0 +1,113 @@
+"""Few, long rows: packed-mode automata switch to the stripe path (function composition across
+4 KiB stripes, intra-row parallelism); everything else stays on the one-row-per-lane kernels.  Both must agree with
+the oracle bit for bit: verdicts, find() end = lastMatch (possibly megabytes into the row, possibly a match that
+itself spans many stripes) and start."""
+import numpy as np
+import pytest
+
+from test_gpu_configs import compiled
+
+
+def gpu_all(p, rows, lens):
+    import torch
+    from needle_amd.pattern import unpack_bitmap
+    t = torch.from_numpy(rows.view(np.int16) if rows.dtype == np.uint16 else rows).cuda()
+    tl = None if lens is None else torch.from_numpy(lens.astype(np.int32)).cuda()
+    n = rows.shape[0]
+    m = unpack_bitmap(p.matches_batch(t, tl), n)
+    c = unpack_bitmap(p.contained_in_batch(t, tl), n)
+    fw, fs, fe = p.find_batch(t, tl)
+    return m, c, unpack_bitmap(fw, n), fs.cpu().numpy(), fe.cpu().numpy()
+
+
+def check(p, o, rows, lens):
+    m, c, f, fs, fe = gpu_all(p, rows, lens)
+    L = None if lens is None else lens.astype(np.uint32)
+    assert (m == o.batch_matches(rows, L, threads=4)).all()
+    assert (c == o.batch_contained_in(rows, L, threads=4)).all()
+    of, os_, oe = o.batch_find(rows, L, threads=4)
+    assert (f == of).all()
+    assert (fe == oe).all(), (fe, oe)
+    assert (fs == os_).all(), (fs, os_)
+
+
+CASES = [
+    # regex, char width, noise alphabet, what gets planted
+    ("[0-9]+", 1, "abcdefghij klmnop", "0123456789"),
+    ("a.c", 1, "xyz\n ", "abc"),
+    ("ε|λ", 2, "abc xyz", "ελ"),
+    ("[α-ω]{3}[α-ω]*", 2, "abc xyz—", "αβγδω"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regex,cw,noise,plant", CASES)
+def test_long_rows_take_the_stripe_path_and_match_the_oracle(regex, cw, noise, plant):
+    p, o = compiled(regex)
+    assert p.info()["kernel_mode"]["forwards"] == 0  # packed mode: eligible for the stripe path
+    rng = np.random.default_rng(5)
+    dtype = np.uint8 if cw == 1 else np.uint16
+    n, stride = 7, 300_000  # stride not a multiple of the 4 KiB stripe; 8-bit: 74 stripes per row
+    stride -= stride % (16 // cw)
+    noise_a, plant_a = np.array([ord(ch) for ch in noise]), np.array([ord(ch) for ch in plant])
+    rows = rng.choice(noise_a, (n, stride)).astype(dtype)
+    # row 0: no match at all; row 1: one short match deep inside; row 2: match in the very last chars; row 3: a run that
+    # spans several stripes (find's end far from its start); row 4: match at 0; row 5: many matches; row 6: all plant
+    three = np.resize(plant_a, 3)
+    rows[1, 200_123:200_126] = three
+    rows[2, stride - 3:] = three
+    rows[3, 50_000:50_000 + 3 * 4096 // cw + 77] = rng.choice(plant_a, 3 * 4096 // cw + 77)
+    rows[4, 0:3] = three
+    rows[5, rng.integers(0, stride, 2000)] = rng.choice(plant_a, 2000)
+    rows[6, :] = rng.choice(plant_a, stride)
+    check(p, o, rows, None)
+    # ragged: lengths cut rows inside a stripe, at stripe boundaries, to zero and to one char
+    lens = np.array([stride, 200_125, stride - 1, 50_000 + 4096 // cw, 0, 1, 8192 // cw], dtype=np.int64)
+    check(p, o, rows, lens)
+
+
+@pytest.mark.gpu
+def test_one_very_long_row():
+    import torch
+    from needle_amd.pattern import unpack_bitmap
+    p, o = compiled("[0-9]+")
+    n_chars = 64 * 1024 * 1024
+    row = np.full((1, n_chars), ord("x"), dtype=np.uint8)
+    t = torch.from_numpy(row).cuda()
+    assert not unpack_bitmap(p.contained_in_batch(t), 1)[0]
+    row[0, n_chars - 5: n_chars - 2] = [ord("4"), ord("2"), ord("7")]
+    t = torch.from_numpy(row).cuda()
+    assert unpack_bitmap(p.contained_in_batch(t), 1)[0]
+    fw, fs, fe = p.find_batch(t)
+    assert unpack_bitmap(fw, 1)[0] and (int(fs[0]), int(fe[0])) == (n_chars - 5, n_chars - 2)
+    assert o.find(row[0].tobytes().decode("latin-1")) == (True, n_chars - 5, n_chars - 2)
+
+
+@pytest.mark.gpu
+def test_stripe_path_equals_lane_path_on_ordinary_batches(monkeypatch):
+    """The two work splits are interchangeable: forcing the stripe path on a short-row batch (NEEDLE_LONG_ROWS is read
+    once per process, so the forced run happens in a subprocess) gives the same bits as the default path."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from needle_amd import workload as W
+from needle_amd.pattern import DFACompiler, unpack_bitmap
+p = DFACompiler.compile("[0-9]+", "d")
+rows = W.digits_batch(torch, 0, 3000, 256, device="cuda")
+lens = torch.from_numpy((np.arange(3000) * 2654435761 % 257).astype(np.int32)).cuda()
+c = unpack_bitmap(p.contained_in_batch(rows, lens), 3000)
+m = unpack_bitmap(p.matches_batch(rows, lens), 3000)
+fw, fs, fe = p.find_batch(rows, lens)
+np.save(sys.argv[1], np.concatenate([c, m, unpack_bitmap(fw, 3000), fs.cpu().numpy(), fe.cpu().numpy()]))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for force in ("0", "1"):
+        path = "/tmp/needle_long_rows_%s.npy" % force
+        env = dict(os.environ, NEEDLE_LONG_ROWS=force)
+        subprocess.check_call([sys.executable, "-c", code, path], cwd=root, env=env)
+        out.append(np.load(path))
+    assert (out[0] == out[1]).all()
