@@ -281,6 +281,20 @@ def main():
         mr, exact = must_read_bytes(args.workload, pattern, rows, cw)
         out["must_read"] = {"bytes_per_step": mr, "GB/s": mr / (elapsed / args.steps) / 1e9, "exact": exact,
                             "note": "chars the reference loop touches before it stops x bytes/char (SURVEY.md s8d secondary denominator)"}
+    if use_dist:
+        # the gather reported separately (blocking, nothing overlapped with it) beside the step time in
+        # which it IS overlapped with the next step's scan
+        from needle_amd.sharding import gather_bitmap
+        w0 = res[0] if is_find else res
+        gather_bitmap(w0, total_rows, world, rank)
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        for _ in range(10):
+            gather_bitmap(w0, total_rows, world, rank)
+        torch.cuda.synchronize()
+        out["gather"] = {"collective": "all_gather_into_tensor (RCCL)", "bytes_per_rank": int(w0.numel() * 8),
+                         "ms_blocking": (time.perf_counter() - g0) / 10 * 1e3,
+                         "note": "inside the timed steps it is issued asynchronously and overlaps with the next scan"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, pattern, rows)
     if rank == 0:

@@ -184,6 +184,82 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     return NEEDLE_OK;
 }
 
+// Small host batches (above all the one-row batches of the Matcher mirror): one grow-only device arena + pinned
+// staging buffer + stream per host thread, ONE upload and ONE download per call -- instead of five hipMalloc/hipFree
+// pairs and as many synchronous copies.
+namespace {
+struct HostArena {
+    int dev = -1;
+    uint8_t *d = nullptr, *h = nullptr;
+    size_t cap = 0;
+    hipStream_t stream = nullptr;
+    ~HostArena() { release(); }
+    void release() {
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        if (stream) (void)hipStreamDestroy(stream);
+        d = h = nullptr;
+        stream = nullptr;
+        cap = 0;
+        dev = -1;
+    }
+    hipError_t reserve(size_t bytes) {
+        int cur = 0;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return e;
+        if (cur == dev && bytes <= cap) return hipSuccess;
+        release();
+        size_t want = 1 << 16;
+        while (want < bytes) want <<= 1;
+        if ((e = hipMalloc((void **)&d, want)) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void **)&h, want, hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        cap = want;
+        dev = cur;
+        return hipSuccess;
+    }
+};
+constexpr size_t kSmallHostBatchBytes = 4u << 20;
+} // namespace
+
+static int run_host_small(const needle_pattern *p, int op, const needle_batch_view *v, uint64_t dst_stride, uint64_t *bitmap,
+                          int32_t *start, int32_t *end) {
+    static thread_local HostArena arena;
+    const size_t cw = v->char_width, n = (size_t)v->n_rows;
+    const size_t src_stride = (size_t)v->row_stride * cw;
+    const size_t words = (n + 63) / 64;
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    // in: rows | lengths      out: bitmap | start | end
+    const size_t o_rows = 0, o_len = up16(n * dst_stride), in_bytes = o_len + (v->lengths ? up16(n * 4) : 0);
+    const size_t o_bm = in_bytes, o_s = o_bm + up16(words * 8), o_e = o_s + up16(n * 4), total = o_e + up16(n * 4);
+    HIP_TRY(arena.reserve(total));
+    if (dst_stride == src_stride) {
+        memcpy(arena.h + o_rows, v->rows, n * src_stride);
+    } else {
+        for (size_t r = 0; r < n; ++r) {
+            memcpy(arena.h + o_rows + r * dst_stride, (const uint8_t *)v->rows + r * src_stride, src_stride);
+            memset(arena.h + o_rows + r * dst_stride + src_stride, 0, dst_stride - src_stride);
+        }
+    }
+    if (v->lengths) memcpy(arena.h + o_len, v->lengths, n * 4);
+    HIP_TRY(hipMemcpyAsync(arena.d, arena.h, in_bytes, hipMemcpyHostToDevice, arena.stream));
+    needle_batch_view dv = *v;
+    dv.rows = arena.d + o_rows;
+    dv.lengths = v->lengths ? (const uint32_t *)(arena.d + o_len) : nullptr;
+    dv.row_stride = dst_stride / cw;
+    int rc = run_dev(p, op, &dv, (uint64_t *)(arena.d + o_bm), (int32_t *)(arena.d + o_s), (int32_t *)(arena.d + o_e), arena.stream);
+    if (rc) return rc;
+    const size_t out_bytes = op == OP_FIND ? total - o_bm : up16(words * 8);
+    HIP_TRY(hipMemcpyAsync(arena.h + o_bm, arena.d + o_bm, out_bytes, hipMemcpyDeviceToHost, arena.stream));
+    HIP_TRY(hipStreamSynchronize(arena.stream));
+    memcpy(bitmap, arena.h + o_bm, words * 8);
+    if (op == OP_FIND) {
+        memcpy(start, arena.h + o_s, n * 4);
+        memcpy(end, arena.h + o_e, n * 4);
+    }
+    return NEEDLE_OK;
+}
+
 // Host-buffer convenience: pad rows to a 16-byte stride, upload, run, download.
 static int run_host(const needle_pattern *p, int op, const needle_batch_view *v, uint64_t *bitmap, int32_t *start,
                     int32_t *end) {
@@ -196,6 +272,8 @@ static int run_host(const needle_pattern *p, int op, const needle_batch_view *v,
     uint64_t dst_stride = (src_stride + 15) & ~(uint64_t)15;
     if (dst_stride == 0) dst_stride = 16;
     const size_t words = (v->n_rows + 63) / 64;
+    if (op == OP_FIND && (!start || !end)) return fail(NEEDLE_ERR_INVALID, "start/end is NULL");
+    if (v->n_rows * dst_stride + v->n_rows * 16 <= kSmallHostBatchBytes) return run_host_small(p, op, v, dst_stride, bitmap, start, end);
     uint8_t *d_rows = nullptr;
     uint32_t *d_len = nullptr;
     uint64_t *d_bm = nullptr;
