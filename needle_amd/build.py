@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libneedle_hip.so")
-SOURCES = ["needle_kernels.hip", "needle_api.cpp", "needle_lower.cpp", "needle_regex.cpp"]
-HEADERS = ["needle_device.h", "needle_lower.h", "needle_regex.h", os.path.join("..", "..", "include", "needle_hip.h")]
+SOURCES = ["needle_kernels.hip", "needle_stripe.hip", "needle_api.cpp", "needle_lower.cpp", "needle_regex.cpp"]
+HEADERS = ["needle_device.h", "needle_walk.h", "needle_lower.h", "needle_regex.h", os.path.join("..", "..", "include", "needle_hip.h")]
 
 
 PROBE_LIB = os.path.join(HERE, "libneedle_probe.so")  # measurement aid for bench.py, not part of the product ABI
@@ -34,11 +34,24 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-Wall", "-Wno-unused-variable", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-variable"]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:  # one hipcc per translation unit, all at once (the scan kernel's 96 instantiations dominate)
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        cmd = flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB
 
 

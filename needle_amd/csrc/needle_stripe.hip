@@ -1,0 +1,335 @@
+// Kernels beside the main scan: haystacks packed back to back -> fixed-stride rows, and the stripe path that gives
+// few, long rows intra-row parallelism.  gfx950 only.
+#include "needle_walk.h"
+
+namespace needle {
+
+// ------------------------------------------------------------------------------------------------
+// packed ("CSR") rows -> fixed-stride rows: one thread per 16-byte piece of the output.  Output stores are
+// lane-linear 16-byte pieces (fully coalesced); the source of a piece starts at an arbitrary byte of the packed
+// buffer, so it is read as five ALIGNED dwords and funnel-shifted (v_alignbyte) into place.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unpack_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ offsets,
+                                                     uint64_t n_rows, uint32_t cw, uint8_t *__restrict__ out,
+                                                     uint64_t stride_bytes, uint32_t *__restrict__ lengths,
+                                                     int32_t *overflow) {
+    const uint64_t ppr = stride_bytes >> 4; // pieces per row
+    const uint64_t total = n_rows * ppr;
+    const uint64_t end_bytes = offsets[n_rows] * cw;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = q / ppr;
+        const uint32_t k = (uint32_t)(q - row * ppr);
+        const uint64_t b0 = offsets[row] * cw;
+        uint64_t len_b = offsets[row + 1] * cw - b0;
+        if (len_b > stride_bytes) {
+            len_b = stride_bytes;
+            if (k == 0 && overflow) *overflow = 1;
+        }
+        if (k == 0) lengths[row] = (uint32_t)(len_b / cw);
+        const uint64_t pos = (uint64_t)k * 16u; // byte position of this piece inside the row
+        u32x4 v = {0, 0, 0, 0};
+        if (pos < len_b) {
+            const uint64_t src = b0 + pos;
+            const uint64_t base = src & ~(uint64_t)3;
+            const uint32_t sh = (uint32_t)(src & 3u);
+            uint32_t d[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) d[i] = (base + 4u * i < end_bytes) ? *(const uint32_t *)(data + base + 4u * i) : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+            const uint64_t valid = len_b - pos; // bytes of the row in this piece (>= 16: all of it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t lo = 4u * i;
+                if (valid <= lo) v[i] = 0;
+                else if (valid < lo + 4u) v[i] &= (1u << (8u * (uint32_t)(valid - lo))) - 1u;
+            }
+        }
+        *(u32x4 *)(out + row * stride_bytes + pos) = v;
+    }
+}
+
+hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
+                         uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream) {
+    const uint64_t total = n_rows * (stride_bytes >> 4);
+    uint64_t blocks = (total + 255) / 256;
+    const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t *)data, offsets, n_rows, cw,
+                       (uint8_t *)out, stride_bytes, lengths, overflow);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Long rows (packed mode): intra-row parallelism by function composition.
+//
+// One row per lane cannot use the chip when there are few, long rows.  With <= 6 device states the per-char
+// transition function F[c] is one dword (5-bit fields); so is the function of ANY substring: compose(A then B)
+// field i = B[A[i]].  A wave takes one 4 KiB stripe: each lane loads its own 64 contiguous bytes straight into
+// registers (no LDS transposition needed: a lane's bytes are contiguous), walks them for ALL entry states at once
+// (one v_bfe_u32 per state and char), and an in-wave ordered scan composes the 64 lane functions.
+//   pass 1  stripe_kernel<CW, false>: every stripe's function                        -> fn[row][stripe]
+//   prefix  stripe_prefix_kernel: per row, sequentially over its stripes: entry state of each stripe (in place),
+//           final state -> matches()/containedIn() verdict
+//   pass 2  stripe_kernel<CW, true>  (find): lane entry state = stripe entry state through the exclusive lane scan,
+//           then the lane walks its bytes again tracking the last accepting position; lanes after the automaton died
+//           enter in the sink and accept nothing, so lastMatch (DFAClassBuilder.java:438-468) is simply the MAX of the
+//           accepting positions: atomicMax per row
+//   start   backward_row_kernel: indexBackwards from lastMatch - 1, one lane per row
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kIdentFn = (0u << 0) | (5u << 5) | (10u << 10) | (15u << 15) | (20u << 20) | (25u << 25);
+
+// B after A: field i of the result = B[A[i]]
+__device__ __forceinline__ uint32_t compose_fn(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r |= __builtin_amdgcn_ubfe(b, __builtin_amdgcn_ubfe(a, 5u * i, 5), 5) << (5u * i);
+    return r;
+}
+
+// NS = device states incl. the sink (2..6).  The sink maps to itself under every char, so only states 1 .. NS-1 are
+// tracked: NS - 1 v_bfe_u32 per char.
+template <int CW, bool FIND, int NS>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const StripeArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
+    __syncthreads();
+    Walk wk;
+    wk.ncols_e = 0, wk.pad_e = a.hdr.pad_f, wk.pre_e = a.hdr.pre_f, wk.table_off = 0, wk.gtable = nullptr;
+    wk.lane4 = (uint32_t)(lane & 31) * 4u;
+    constexpr int CPL = 64 / CW; // chars per lane and stripe
+    const uint32_t accept_lo = a.hdr.accept_lo * 5u;
+    const uint64_t total = a.n_rows * a.spr;
+    for (uint64_t v = (uint64_t)blockIdx.x * kWavesPerBlock + wave; v < total; v += (uint64_t)gridDim.x * kWavesPerBlock) {
+        const uint64_t row = v / a.spr;
+        const uint32_t s = (uint32_t)(v - row * a.spr);
+        const uint32_t len = a.lengths ? a.lengths[row] : a.row_len;
+        const uint64_t first = (uint64_t)s * (kStripeBytes / CW) + (uint64_t)lane * CPL; // this lane's first char
+        const uint32_t n_valid = first >= len ? 0u : (uint32_t)(len - first < (uint64_t)CPL ? len - first : CPL);
+        uint32_t entry = 0; // FIND: 5 * state in which the row's automaton reaches this stripe
+        if (FIND) entry = a.fn[v];
+        if ((uint64_t)s * (kStripeBytes / CW) >= len || (FIND && entry == 0)) { // stripe past the row's end / automaton dead
+            if (!FIND && lane == 0) a.fn[v] = kIdentFn;
+            continue;
+        }
+        u32x4 d[4] = {};
+        const uint64_t off = (uint64_t)s * kStripeBytes + (uint64_t)lane * 64u;
+        if (n_valid) { // 64 B inside the row's stride (len <= stride, stride a multiple of 16 B)
+            const uint8_t *p = a.rows + row * a.stride_bytes + off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (off + 16u * j < a.stride_bytes) d[j] = *(const u32x4 *)(p + 16 * j);
+        }
+        // the per-char functions of this lane's chars (kept for the second walk of FIND)
+        uint32_t g[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] = 5u * i; // fields NS .. 5 stay identity (never a real state)
+        const bool full = __ballot(n_valid != (uint32_t)CPL) == 0ull;
+        auto walk_all = [&](auto per_char) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w[4] = {d[j][0], d[j][1], d[j][2], d[j][3]};
+                uint32_t f[16 / CW];
+#define NEEDLE_F(D, K) f[(D) * (4 / CW) + (K)] = lookup<MODE_PACK, CW, false, K>(wk, w[D], true, false);
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    NEEDLE_F(dd, 0)
+                    NEEDLE_F(dd, 1)
+                    if (CW == 1) {
+                        NEEDLE_F(dd, 2)
+                        NEEDLE_F(dd, 3)
+                    }
+                }
+#undef NEEDLE_F
+                lds_fence();
+#pragma unroll
+                for (int i = 0; i < 16 / CW; ++i) per_char(j * (16 / CW) + i, f[i]);
+            }
+        };
+        if (full) {
+            walk_all([&](int, uint32_t f) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 1; i < NS; ++i) g[i] = __builtin_amdgcn_ubfe(f, g[i], 5);
+            });
+        } else {
+            walk_all([&](int c, uint32_t f) __attribute__((always_inline)) {
+                f = (uint32_t)c < n_valid ? f : kIdentFn;
+#pragma unroll
+                for (int i = 1; i < NS; ++i) g[i] = __builtin_amdgcn_ubfe(f, g[i], 5);
+            });
+        }
+        uint32_t fn = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fn |= g[i] << (5u * i);
+        // ordered inclusive scan over the lanes: after step d lane l holds the function of lanes l-2d+1 .. l
+        uint32_t incl = fn;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t left = (uint32_t)__shfl_up((int)incl, dlt);
+            if (lane >= dlt) incl = compose_fn(left, incl);
+        }
+        if (!FIND) {
+            if (lane == 63) a.fn[v] = incl;
+            continue;
+        }
+        uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
+        if (lane == 0) excl = kIdentFn;
+        uint32_t st = __builtin_amdgcn_ubfe(excl, entry, 5);
+        int32_t last_rel = -1;
+        if (full) {
+            walk_all([&](int c, uint32_t f) __attribute__((always_inline)) {
+                st = __builtin_amdgcn_ubfe(f, st, 5);
+                last_rel = st >= accept_lo ? c + 1 : last_rel;
+            });
+        } else {
+            walk_all([&](int c, uint32_t f) __attribute__((always_inline)) {
+                st = __builtin_amdgcn_ubfe((uint32_t)c < n_valid ? f : kIdentFn, st, 5);
+                last_rel = (st >= accept_lo && (uint32_t)c < n_valid) ? c + 1 : last_rel;
+            });
+        }
+        int32_t best = last_rel >= 0 ? (int32_t)first + last_rel : -1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int32_t t = __shfl_xor(best, o);
+            best = t > best ? t : best;
+        }
+        if (lane == 0 && best >= 0) atomicMax(a.end + row, best);
+    }
+}
+
+// fn[] -> entry states, and the verdicts.  One workgroup per row: thread t composes its contiguous chunk of stripe
+// functions, an ordered workgroup scan (wave shuffles + 16 wave totals through LDS) gives every chunk its entry
+// function, and a second pass over the chunk replaces each function by the stripe's entry state.  (One thread per
+// row walking 262144 stripes of a 1 GiB row one dependent load at a time took 25 ms.)
+__global__ __launch_bounds__(1024) void stripe_prefix_kernel(const StripeArgs a) {
+    __shared__ uint32_t wave_total[16];
+    const uint32_t accept_lo = a.hdr.accept_lo * 5u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = (blockDim.x + 63) >> 6;
+    const uint32_t per = (a.spr + blockDim.x - 1) / blockDim.x; // stripes per thread
+    for (uint64_t row = blockIdx.x; row < a.n_rows; row += gridDim.x) {
+        uint32_t *fn = a.fn + row * a.spr;
+        const uint32_t s0 = (uint32_t)tid * per < a.spr ? (uint32_t)tid * per : a.spr;
+        const uint32_t s1 = s0 + per < a.spr ? s0 + per : a.spr;
+        uint32_t mine = kIdentFn;
+        for (uint32_t s = s0; s < s1; ++s) mine = compose_fn(mine, fn[s]);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t left = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl = compose_fn(left, incl);
+        }
+        if (lane == 63) wave_total[wave] = incl;
+        __syncthreads();
+        uint32_t before = kIdentFn; // everything in the waves before this one
+        for (int w = 0; w < wave; ++w) before = compose_fn(before, wave_total[w]);
+        uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
+        if (lane == 0) excl = kIdentFn;
+        excl = compose_fn(before, excl);
+        uint32_t q = __builtin_amdgcn_ubfe(excl, a.hdr.start * 5u, 5);
+        for (uint32_t s = s0; s < s1; ++s) {
+            const uint32_t f = fn[s];
+            fn[s] = q;
+            q = __builtin_amdgcn_ubfe(f, q, 5);
+        }
+        if (tid == (int)blockDim.x - 1) { // its chunk is the last one (possibly empty): q is the row's final state
+            if (a.op == OP_FIND) a.end[row] = a.hdr.root_accepting ? 0 : -1; // :356 lastMatch before the first char
+            else if (q >= accept_lo) atomicOr((unsigned long long *)(a.bitmap + (row >> 6)), 1ull << (row & 63));
+        }
+        __syncthreads(); // wave_total is reused by the next row
+    }
+    (void)n_waves;
+}
+
+// find(): matched bit + start (DFAClassBuilder.java:640-656) for the long-row path; one lane per row, everything
+// read from global memory (the rows here are few).
+template <int CW>
+__global__ __launch_bounds__(256) void backward_row_kernel(const StripeArgs a) {
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < a.n_rows; base += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = base + threadIdx.x;
+        bool res = false;
+        if (row < a.n_rows) {
+            const int32_t last = a.end[row];
+            res = last >= 0;
+            int32_t s = -1;
+            if (res) {
+                if (a.fixed_len >= 0) {
+                    s = last - a.fixed_len;
+                } else {
+                    const uint8_t *bcmap = a.prog + a.hdr.off_bcmap, *bptab = a.prog + a.hdr.off_bptab, *bpages = a.prog + a.hdr.off_bpages;
+                    const uint16_t *bt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
+                    const uint8_t *rowp = a.rows + row * a.stride_bytes;
+                    uint32_t bs = a.bhdr.start;
+                    int32_t lastb = a.bhdr.root_accepting ? 0 : INT_MAX;
+                    for (int32_t p = last - 1; p >= 0; --p) {
+                        const uint32_t c = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
+                        bs = bt[bs * a.bhdr.n_cols + column_of<CW>(bcmap, bptab, bpages, c)];
+                        if (bs == 0) break;
+                        if (bs >= a.bhdr.accept_lo) lastb = p;
+                    }
+                    s = lastb;
+                }
+            }
+            a.start[row] = s;
+            if (!res) a.end[row] = -1;
+        }
+        const uint64_t word = __ballot(res);
+        if ((threadIdx.x & 63) == 0 && row < a.n_rows) a.bitmap[row >> 6] = word;
+    }
+}
+
+template <int CW, bool FIND, int NS>
+static hipError_t launch_stripe(const StripeArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
+    auto k = stripe_kernel<CW, FIND, NS>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(kWavesPerBlock * 64), lds, stream, a);
+    return hipGetLastError();
+}
+template <int CW, bool FIND>
+static hipError_t launch_stripe_n(const StripeArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (a.hdr.n_states) {
+    case 0: case 1: case 2: return launch_stripe<CW, FIND, 2>(a, grid, lds, stream);
+    case 3: return launch_stripe<CW, FIND, 3>(a, grid, lds, stream);
+    case 4: return launch_stripe<CW, FIND, 4>(a, grid, lds, stream);
+    case 5: return launch_stripe<CW, FIND, 5>(a, grid, lds, stream);
+    default: return launch_stripe<CW, FIND, 6>(a, grid, lds, stream);
+    }
+}
+
+hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipStream_t stream) {
+    const uint64_t total = a.n_rows * a.spr;
+    uint64_t blocks = (total + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
+    const size_t lds = (a.hdr.lds_bytes + 15u) & ~15u;
+    const dim3 grid((unsigned)blocks);
+    const unsigned pblocks = (unsigned)((a.n_rows + 255) / 256);
+    hipError_t e = char_width == 1 ? launch_stripe_n<1, false>(a, grid, lds, stream) : launch_stripe_n<2, false>(a, grid, lds, stream);
+    if (e != hipSuccess) return e;
+    {
+        if (a.op != OP_FIND) { // verdict bits are OR-ed in
+            e = hipMemsetAsync(a.bitmap, 0, ((a.n_rows + 63) / 64) * 8, stream);
+            if (e != hipSuccess) return e;
+        }
+        unsigned threads = 64;
+        while (threads < 1024 && threads < a.spr) threads <<= 1;
+        const uint64_t max_blocks = (uint64_t)n_cus * (2048 / threads);
+        hipLaunchKernelGGL(stripe_prefix_kernel, dim3((unsigned)(a.n_rows < max_blocks ? a.n_rows : max_blocks)), dim3(threads), 0, stream, a);
+    }
+    if (a.op == OP_FIND) {
+        e = char_width == 1 ? launch_stripe_n<1, true>(a, grid, lds, stream) : launch_stripe_n<2, true>(a, grid, lds, stream);
+        if (e != hipSuccess) return e;
+        if (char_width == 1) hipLaunchKernelGGL(backward_row_kernel<1>, dim3(pblocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(backward_row_kernel<2>, dim3(pblocks), dim3(256), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
+} // namespace needle

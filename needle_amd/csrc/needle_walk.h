@@ -1,0 +1,164 @@
+// Device-side helpers shared by the kernels of libneedle_hip.so (needle_kernels.hip: the one-row-per-lane scan;
+// needle_stripe.hip: the stripe path for few long rows and the packed-rows conversion): LDS access at absolute
+// addresses, SDWA byte selects, the tile geometry and the per-char lookup / transition of a lowered automaton.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "needle_device.h"
+
+#ifndef NEEDLE_MASK_DONE_LANES
+#define NEEDLE_MASK_DONE_LANES 1
+#endif
+#ifndef NEEDLE_NT_LOADS
+#define NEEDLE_NT_LOADS 1
+#endif
+#ifndef NEEDLE_PIECE_FENCE
+#define NEEDLE_PIECE_FENCE 1
+#endif
+
+namespace needle {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+// native 16-byte vector (a first-class SSA value: tiles held across loop iterations stay in VGPRs; HIP's uint4
+// wrapper struct gets demoted to scratch when it is conditionally re-assigned)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CHB>
+struct Geom {
+    static constexpr int kPieces = CHB / 16;         // 16-B pieces per row chunk: 8 | 4
+    static constexpr int kRowsPerInstr = 64 / kPieces; // rows covered by one wave-wide 16 B/lane load: 8 | 16
+    static constexpr int kInstrs = 64 / kRowsPerInstr; // loads per lane per tile: 8 | 4
+    static constexpr int kTileBytes = 64 * CHB;
+    // bank-slot swizzle of tile row r (see header comment): distinct for the rows one ds_read_b128 lane group touches
+    __device__ static __forceinline__ int swz(int r) { return CHB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+};
+
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+// 16 bytes of haystack.  STREAM: the wave consumes whole 128-byte lines exactly once -> `global_load ... nt`
+// (measured on the 10M x 256 batch: 5.5 -> 6.2 TB/s).  Not for the 64-byte-piece shape: there the second half of a
+// line must still be in L2 when its request arrives right behind the first one's (nt there: 0.70 -> 0.91 ms).
+template <bool STREAM>
+__device__ __forceinline__ u32x4 load_row16(const uint8_t *p) {
+    if (STREAM && NEEDLE_NT_LOADS) return __builtin_nontemporal_load((const u32x4 *)p);
+    return *(const u32x4 *)p;
+}
+
+// A wave's LDS tile: 64 rows of CHB bytes at `row_stride` bytes apart (row_stride == CHB for the plain layout; 256
+// when the rows live in the unused upper halves of the packed-mode F rows, see shape_for_program).
+struct Tile {
+    uint32_t store_addr;  // this lane's first store slot: base + (lane / pieces) * row_stride + (lane % pieces) * 16
+    uint32_t store_step;  // rows-per-instruction * row_stride
+    uint32_t row_addr;    // base + lane * row_stride: this lane's own row
+};
+
+__device__ __forceinline__ void store_piece(const Tile &t, int j, u32x4 v) {
+    *(lds_u32x4 *)(uintptr_t)(t.store_addr + j * t.store_step) = v;
+}
+
+template <int CHB>
+__device__ __forceinline__ u32x4 tile_piece(const Tile &t, int lane, int kk) {
+    return *(const lds_u32x4 *)(uintptr_t)(t.row_addr + ((kk ^ Geom<CHB>::swz(lane)) << 4));
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+        v = v > t ? v : t;
+    }
+    return v;
+}
+
+// ---- one-instruction byte/word extraction (SDWA operand selects): the walk is VALU-issue bound (one wave
+// instruction per ~4 cycles per SIMD), so every per-char VALU instruction saved is throughput.
+template <int K>
+__device__ __forceinline__ uint32_t shl_byte(uint32_t w, uint32_t sh) { // (byte K of w) << sh
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh), "v"(w));
+    if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(sh), "v"(w));
+    if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(sh), "v"(w));
+    if (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(sh), "v"(w));
+    return r;
+}
+template <int K>
+__device__ __forceinline__ uint32_t or_byte(uint32_t a, uint32_t w) { // a | (byte K of w)
+    uint32_t r;
+    if (K == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(w));
+    if (K == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(w));
+    if (K == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(w));
+    if (K == 3) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+
+// LDS reads at an ABSOLUTE LDS byte address through address-space-3 pointers.  The dynamic segment starts at LDS
+// address 0 (this file declares no static __shared__; scan_kernel traps if that ever changes), so table offsets
+// are plain immediates: going through `smem` costs a `v_add 0` (late-resolved symbol) per access, going through
+// generic pointers a null-check v_cndmask on top.
+#define NEEDLE_LDS(T) __attribute__((address_space(3))) const T *
+__device__ __forceinline__ uint32_t lds_u8(uint32_t a) { return *(NEEDLE_LDS(uint8_t))(uintptr_t)(a); }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *(NEEDLE_LDS(uint16_t))(uintptr_t)(a); }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(NEEDLE_LDS(uint32_t))(uintptr_t)(a); }
+
+// One wait for every LDS read issued so far, and nothing scheduled across it.
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Walk constants a lane keeps in registers (see the fixed LDS layout in needle_device.h).
+struct Walk {
+    uint32_t ncols_e;   // table modes: row stride in BYTES of the next-state table (n_cols * element size)
+    uint32_t pad_e;     // table modes: PAD column * element size;  packed mode: F of the PAD column
+    uint32_t pre_e;     // same for the PRE column (identity: chars before the row's find() cursor)
+    uint32_t table_off; // char_width 2 table modes: LDS byte offset of the table
+    uint32_t lane4;     // lane * 4 (byte 0 of the packed-mode F address)
+    const uint16_t *gtable; // MODE_GLOBAL
+};
+
+template <int CW>
+__device__ __forceinline__ uint32_t column_of(const uint8_t *cmap, const uint8_t *ptab, const uint8_t *pages, uint32_t c) {
+    if (CW == 1) return cmap[c];
+    return pages[((uint32_t)ptab[c >> 8] << 8) | (c & 255u)];
+}
+
+// A transition in two halves so that a whole 16-byte piece can be batched: `lookup` is everything that does not
+// depend on the automaton state (char -> F, or char -> column * element size); `apply` is the dependent part.
+// K: char number inside dword w (0..3 for bytes, 0..1 for UTF-16 units).
+template <int MODE, int CW, bool GUARD, int K>
+__device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_row, bool before_cursor) {
+    uint32_t col; // packed mode: F;  table modes: column * element size
+    if (CW == 1) {
+        // packed mode: F[byte][32 lane copies]: address = byte << 8 | (lane & 31) * 4, formed by ONE v_perm_b32;
+        // every lane reads its own LDS bank, so the lookup is conflict-free whatever the text looks like
+        if (MODE == MODE_PACK) col = lds_u32(__builtin_amdgcn_perm(w, wk.lane4, 0x0C0C0400u + ((uint32_t)K << 8)) + kLdsF1);
+        else col = lds_u16(shl_byte<K>(w, 1) + kLdsCmap1);
+    } else {
+        const uint32_t pg = lds_u16(shl_byte<(2 * K + 1) & 3>(w, 1) + kLdsPtab2);  // page base = page * 256
+        const uint32_t ce = lds_u8(or_byte<(2 * K) & 3>(pg, w) + (MODE == MODE_PACK ? kLdsPages2Pack : kLdsPages2Table));
+        col = (MODE == MODE_PACK) ? lds_u32(ce + kLdsF2) : ce; // pages hold column * 4 (packed) | * element size
+    }
+    if (GUARD) {
+        col = in_row ? col : wk.pad_e;
+        col = before_cursor ? wk.pre_e : col;
+    }
+    return col;
+}
+// st: 5 * state in MODE_PACK (the bit offset of the state's field in F), the state id otherwise.
+template <int MODE, int CW>
+__device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t col) {
+    if (MODE == MODE_PACK) return __builtin_amdgcn_ubfe(col, st, 5);
+    const uint32_t i = __umul24(st, wk.ncols_e) + col;
+    if (MODE == MODE_GLOBAL) return wk.gtable[i];
+    const uint32_t addr = i + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off);
+    return MODE == MODE_TABLE8 ? lds_u8(addr) : lds_u16(addr);
+}
+
+} // namespace needle
