@@ -72,7 +72,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(workload, pattern, rows_dev, budget_s=12.0):
+def cpu_baseline(workload, pattern, rows_dev, op_name, budget_s=12.0):
     """Times the CPU oracle on a bounded sample of the same rows (rank 0, N = 1 only)."""
     import numpy as np
     from oracle.walker import Dfa, OraclePattern
@@ -84,7 +84,7 @@ def cpu_baseline(workload, pattern, rows_dev, budget_s=12.0):
     host = rows_dev[:n].cpu().numpy()
     if host.dtype == np.int16:
         host = host.view(np.uint16)
-    fn = o.batch_contained_in if workload == "c2" else o.batch_find
+    fn = {"contained_in": o.batch_contained_in, "find": o.batch_find, "matches": o.batch_matches}[op_name]
     fn(host[:4096], threads=cores)
     passes, t0 = 0, time.perf_counter()
     while True:
@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (weak) or in total (strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--regex", default=None, help="tuning runs: another regex over the chosen workload's rows")
+    ap.add_argument("--op", default=None, choices=["matches", "contained_in", "find"], help="tuning runs: another op")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the read-ceiling probe and the must-read byte count")
     args = ap.parse_args()
@@ -181,12 +183,16 @@ def main():
 
     from needle_amd.sharding import shard_range, gather_bitmap_async
     pattern, what, words = make_pattern(args.workload)
+    if args.regex is not None:  # not a BASELINE config: labelled as such in config.workload
+        from needle_amd.pattern import DFACompiler
+        pattern, what = DFACompiler.compile(args.regex, "Custom"), "CUSTOM regex %r %s()" % (args.regex, args.op or "default op")
     total_rows = args.rows * world if args.scaling == "weak" else args.rows
     row0, n_rows = shard_range(total_rows, world, rank)
     rows = make_rows(args.workload, words, row0, n_rows, dev)
     cw = rows.element_size()
-    op = pattern.contained_in_batch if args.workload == "c2" else pattern.find_batch
-    is_find = args.workload != "c2"
+    op_name = args.op or ("contained_in" if args.workload == "c2" else "find")
+    op = {"contained_in": pattern.contained_in_batch, "find": pattern.find_batch, "matches": pattern.matches_batch}[op_name]
+    is_find = op_name == "find"
 
     def step():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -278,7 +284,7 @@ def main():
         if ceil:
             out["roofline"]["measured_read_ceiling"] = ceil
             out["roofline"]["frac_of_measured_ceiling"] = out["roofline"]["achieved"] / ceil
-        mr, exact = must_read_bytes(args.workload, pattern, rows, cw)
+        mr, exact = must_read_bytes(args.workload if args.regex is None and args.op is None else "custom", pattern, rows, cw)
         out["must_read"] = {"bytes_per_step": mr, "GB/s": mr / (elapsed / args.steps) / 1e9, "exact": exact,
                             "note": "chars the reference loop touches before it stops x bytes/char (SURVEY.md s8d secondary denominator)"}
     if use_dist:
@@ -296,7 +302,7 @@ def main():
                          "ms_blocking": (time.perf_counter() - g0) / 10 * 1e3,
                          "note": "inside the timed steps it is issued asynchronously and overlaps with the next scan"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, pattern, rows)
+        out["cpu_baseline"] = cpu_baseline(args.workload, pattern, rows, op_name)
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -14,6 +14,9 @@ enum Mode : int {
     MODE_TABLE8 = 1,  // [state][column] uint8 next-state table in LDS
     MODE_TABLE16 = 2, // [state][column] uint16 next-state table in LDS
     MODE_GLOBAL = 3,  // uint16 table too large for LDS: walked out of HBM/L2
+    MODE_PAIR = 4,    // 8-bit rows, <= 256 states, n_states * n_cols^2 entries fit the LDS: TWO chars per dependent
+                      // lookup -- uint16 [state][col1][col2] = next state after both | code << 8 (find: 0 no accept,
+                      // 1 accepted after the first char only, 2 accepted after the second)
 };
 
 // Device-side numbering of a lowered automaton (independent of the reference's state numbers):
@@ -95,6 +98,8 @@ struct StripeArgs {
 //   char_width 2:  ptab16[256] at 0 (page * 256);  packed: F[64] u32 at 512, pages8 (col * 4) at 768
 //                                                  table modes: pages8 (col * elem) at 512, table at hdr.off_table
 constexpr uint32_t kLdsF1 = 0, kLdsCmap1 = 0, kLdsTable1 = 512;
+//                  pair mode: cmapA16[256] at 0 (col * n_cols * 2: first char of a pair), cmapB16[256] at 512 (col * 2)
+constexpr uint32_t kLdsCmapB1 = 512, kLdsPairTable1 = 1024;
 constexpr uint32_t kLdsPtab2 = 0, kLdsF2 = 512;
 // pages base differs by mode; the kernel selects with kLdsPages2 below through the MODE it is instantiated for
 constexpr uint32_t kLdsPages2Pack = 768, kLdsPages2Table = 512;

@@ -40,6 +40,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     wk.ncols_e = a.hdr.n_cols * ELEM;
     wk.pad_e = (MODE == MODE_PACK) ? a.hdr.pad_f : a.hdr.pad_col * ELEM;
     wk.pre_e = (MODE == MODE_PACK) ? a.hdr.pre_f : (a.hdr.pad_col + 1u) * ELEM;
+    wk.pad_b = wk.pre_b = 0;
+    if (MODE == MODE_PAIR) { // row stride of [state][col1][col2] uint16; columns premultiplied for either position
+        wk.ncols_e = a.hdr.n_cols * a.hdr.n_cols * 2u;
+        wk.pad_e = a.hdr.pad_col * a.hdr.n_cols * 2u;
+        wk.pre_e = (a.hdr.pad_col + 1u) * a.hdr.n_cols * 2u;
+        wk.pad_b = a.hdr.pad_col * 2u;
+        wk.pre_b = (a.hdr.pad_col + 1u) * 2u;
+    }
     wk.table_off = a.hdr.off_table;
     wk.lane4 = (uint32_t)(lane & 31) * 4u; // lanes l and l+32 are served in different LDS passes: 32 copies suffice
     wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
@@ -235,12 +243,31 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
 #undef NEEDLE_LOOKUP
             }
             // ... then ONE wait for all of them instead of one s_waitcnt per char (the walk is issue-bound), ...
+            // (packed mode only: in the table and pair modes the same fence costs 5-8 %, their lookups are better left
+            // interleaved with the dependent chain)
             if (MODE == MODE_PACK && NEEDLE_PIECE_FENCE) {
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ... then the dependent chain
+            if (MODE == MODE_PAIR) {
+                uint32_t pair_e[CPP / 2]; // off the chain: column pair offsets
+#pragma unroll
+                for (int i = 0; i < CPP; i += 2) pair_e[i / 2] = col[i] + col[i + 1];
+#pragma unroll
+                for (int i = 0; i < CPP; i += 2) {
+                    const uint32_t e = lds_u16(__umul24(st, wk.ncols_e) + pair_e[i / 2] + kLdsPairTable1);
+                    st = e & 0xFFu;
+                    if (OP == OP_FIND) {
+                        const uint32_t code = e >> 8;            // 0 | 1: accepted after char i only | 2: after char i + 1
+                        const uint32_t pos = p0 + i + code;      // = index of the accepting char + 1
+                        bool acc = code != 0u;
+                        if (GUARD) acc = acc && (pos > skip);    // an accepting start state must not count before the cursor
+                        last_rel = acc ? (int32_t)pos : last_rel;
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < CPP; ++i) {
                 st = apply<MODE, CW>(wk, st, col[i]);
@@ -444,6 +471,7 @@ static hipError_t launch_m(const ScanArgs &a, bool guard, LaunchShape sh, hipStr
     case MODE_PACK: return launch_g<OP, CW, MODE_PACK>(a, guard, sh, s);
     case MODE_TABLE8: return launch_g<OP, CW, MODE_TABLE8>(a, guard, sh, s);
     case MODE_TABLE16: return launch_g<OP, CW, MODE_TABLE16>(a, guard, sh, s);
+    case MODE_PAIR: return CW == 1 ? launch_g<OP, 1, MODE_PAIR>(a, guard, sh, s) : hipErrorInvalidValue; // 8-bit rows only
     default: return launch_g<OP, CW, MODE_GLOBAL>(a, guard, sh, s);
     }
 }

@@ -169,6 +169,12 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     else if (n_dev <= 256) mode = MODE_TABLE8;
     else mode = MODE_TABLE16;
 
+    // Pair mode: the dependent LDS chain of the table modes is what bounds them (4 waves per SIMD cannot hide it), so
+    // when [state][col][col] fits, one lookup advances TWO chars.  NEEDLE_PAIR_MAX_BYTES=0 turns it off (A/B, tests).
+    static const size_t pair_budget = getenv("NEEDLE_PAIR_MAX_BYTES") ? (size_t)atol(getenv("NEEDLE_PAIR_MAX_BYTES")) : (size_t)(96u << 10);
+    const size_t pair_bytes = (size_t)n_dev * n_cols * n_cols * 2;
+    if (mode == MODE_TABLE8 && char_width == 1 && pair_bytes <= pair_budget && pair_bytes + 4096 <= lds_table_budget) mode = MODE_PAIR;
+
     ColumnMaps bm;
     if (with_backward_maps) bm = column_maps(t, t.dfa[W_BACKWARDS], char_width);
     auto emit_backward_maps = [&]() {
@@ -206,6 +212,24 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             for (int k = 0; k < n_cols; ++k) put32(kLdsF2 + 4 * k, pack(k));
             for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Pack + i] = (uint8_t)(cm.pages[i] * 4);
         }
+        emit_backward_maps();
+        p.hdr.lds_bytes = (uint32_t)p.blob.size();
+    } else if (mode == MODE_PAIR) {
+        p.blob.assign(kLdsPairTable1 + pair_bytes, 0);
+        for (int c = 0; c < 256; ++c) {
+            put16(kLdsCmap1 + 2 * c, (uint32_t)cm.cmap8[c] * n_cols * 2u);
+            put16(kLdsCmapB1 + 2 * c, (uint32_t)cm.cmap8[c] * 2u);
+        }
+        for (int s = 0; s < n_dev; ++s)
+            for (int c1 = 0; c1 < n_cols; ++c1) {
+                const uint32_t s1 = next[(size_t)s * n_cols + c1];
+                for (int c2 = 0; c2 < n_cols; ++c2) {
+                    const uint32_t s2 = next[(size_t)s1 * n_cols + c2];
+                    const uint32_t code = (int)s2 >= accept_lo ? 2u : ((int)s1 >= accept_lo ? 1u : 0u);
+                    put16(kLdsPairTable1 + 2 * (((size_t)s * n_cols + c1) * n_cols + c2), s2 | (code << 8));
+                }
+            }
+        p.hdr.off_table = kLdsPairTable1;
         emit_backward_maps();
         p.hdr.lds_bytes = (uint32_t)p.blob.size();
     } else {

@@ -118,6 +118,7 @@ struct Walk {
     uint32_t ncols_e;   // table modes: row stride in BYTES of the next-state table (n_cols * element size)
     uint32_t pad_e;     // table modes: PAD column * element size;  packed mode: F of the PAD column
     uint32_t pre_e;     // same for the PRE column (identity: chars before the row's find() cursor)
+    uint32_t pad_b, pre_b; // pair mode: PAD / PRE as the SECOND char of a pair (pad_e / pre_e: as the first)
     uint32_t table_off; // char_width 2 table modes: LDS byte offset of the table
     uint32_t lane4;     // lane * 4 (byte 0 of the packed-mode F address)
     const uint16_t *gtable; // MODE_GLOBAL
@@ -139,6 +140,7 @@ __device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_r
         // packed mode: F[byte][32 lane copies]: address = byte << 8 | (lane & 31) * 4, formed by ONE v_perm_b32;
         // every lane reads its own LDS bank, so the lookup is conflict-free whatever the text looks like
         if (MODE == MODE_PACK) col = lds_u32(__builtin_amdgcn_perm(w, wk.lane4, 0x0C0C0400u + ((uint32_t)K << 8)) + kLdsF1);
+        else if (MODE == MODE_PAIR) col = lds_u16(shl_byte<K>(w, 1) + ((K & 1) ? kLdsCmapB1 : kLdsCmap1)); // first | second char of a pair
         else col = lds_u16(shl_byte<K>(w, 1) + kLdsCmap1);
     } else {
         const uint32_t pg = lds_u16(shl_byte<(2 * K + 1) & 3>(w, 1) + kLdsPtab2);  // page base = page * 256
@@ -146,8 +148,8 @@ __device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_r
         col = (MODE == MODE_PACK) ? lds_u32(ce + kLdsF2) : ce; // pages hold column * 4 (packed) | * element size
     }
     if (GUARD) {
-        col = in_row ? col : wk.pad_e;
-        col = before_cursor ? wk.pre_e : col;
+        col = in_row ? col : ((MODE == MODE_PAIR && (K & 1)) ? wk.pad_b : wk.pad_e);
+        col = before_cursor ? ((MODE == MODE_PAIR && (K & 1)) ? wk.pre_b : wk.pre_e) : col;
     }
     return col;
 }

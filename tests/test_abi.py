@@ -56,7 +56,8 @@ def test_from_tables_roundtrip_and_validation(lib):
         assert (t["dfas"][k]["table"] == want).all()
         assert t["dfas"][k]["accepting"] == doc["dfas"][v]["accepting"]
     info = p.info()
-    assert info["n_states"]["matches"] == 31 and info["kernel_mode"]["matches"] == 1  # 32 device states -> uint8 LDS table
+    # 32 device states x 31^2 column pairs x 2 B = 61 KB: the two-chars-per-lookup table fits the LDS
+    assert info["n_states"]["matches"] == 31 and info["kernel_mode"]["matches"] == 4
     # malformed table string / out-of-range target -> ValueError, not a crash
     bad = dict(dfas)
     bad["matches"] = dict(dfas["matches"], table_strings=["0:zz-1"])

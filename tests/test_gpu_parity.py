@@ -167,3 +167,17 @@ def test_narrow_rows_near_the_buffer_end(n_rows, stride, oracle_lib):
         assert (m == o.batch_matches(rows, l)).all() and (c == o.batch_contained_in(rows, l)).all()
         of, ofs, ofe = o.batch_find(rows, l)
         assert (f == of).all() and (fs == ofs).all() and (fe == ofe).all()
+
+
+@pytest.mark.gpu
+def test_single_char_table_mode_stays_covered():
+    """Mid-size automata default to the pair table (two chars per lookup); the one-char uint8 table mode they fall back
+    to when the pair table does not fit is re-run here on the reference's bytecode vectors with the pair mode disabled
+    (the switch is read once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NEEDLE_PAIR_MAX_BYTES="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x",
+                        "-k", "bytecode_vectors or seeded_batches"], cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
