@@ -2,6 +2,8 @@
   (1) the outputs recorded from the reference's own compiled classes (tests/golden/snapshots), and
   (2) the CPU oracle (oracle/needle_walk.c) on seeded batches, incl. ragged / empty / 8- and 16-bit rows.
 Bit-exact: matches/containedIn bitmaps and find (matched, start, end)."""
+import os
+
 import numpy as np
 import pytest
 
