@@ -1,0 +1,58 @@
+"""Differential fuzz on the GPU: seeded random regexes (the generator of tests/test_compile_vs_python_restatement.py)
+x random short haystacks over a small alphabet, all three ops through the packed entry points (ragged rows: the
+guarded kernels) and through a fixed-stride full-length batch (the unguarded kernels), against the oracle walking the
+same tables.  Whatever device mode the automaton lowers to (packed functions, pair table, uint8 / uint16 table) must
+give the reference's bits."""
+import random
+
+import numpy as np
+import pytest
+
+from test_compile_vs_python_restatement import FLAG_SETS, random_regex
+from test_gpu_configs import compiled
+
+ALPHABET = [ord(c) for c in "abcxyz019 AB_\n."] + [0xE9, 0x416, 0x4E2D, 0xFFFF]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_random_regexes_on_random_haystacks(seed):
+    import torch
+    from needle_amd.pattern import PatternException, unpack_bitmap
+    rng = random.Random(4000 + seed)
+    nrng = np.random.default_rng(seed)
+    modes, done = set(), 0
+    while done < 12:
+        regex, flags = random_regex(rng), rng.choice(FLAG_SETS)
+        try:
+            p, o = compiled(regex, flags)
+        except (PatternException, ValueError):
+            continue
+        done += 1
+        modes.add(p.info()["kernel_mode"]["forwards"])
+        # ragged, packed UTF-16 rows
+        n = 400
+        lens = nrng.integers(0, 70, n)
+        rows = [nrng.choice(ALPHABET, int(l)).astype(np.uint16) for l in lens]
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        data = np.concatenate(rows) if offsets[-1] else np.zeros(0, dtype=np.uint16)
+        pad = np.zeros((n, 70), dtype=np.uint16)
+        for i, r in enumerate(rows):
+            pad[i, :len(r)] = r
+        L = lens.astype(np.uint32)
+        assert (unpack_bitmap(p.matches_packed(data, offsets), n) == o.batch_matches(pad, L, threads=4)).all(), (regex, flags)
+        assert (unpack_bitmap(p.contained_in_packed(data, offsets), n) == o.batch_contained_in(pad, L, threads=4)).all(), (regex, flags)
+        fw, fs, fe = p.find_packed(data, offsets)
+        of, os_, oe = o.batch_find(pad, L, threads=4)
+        assert (unpack_bitmap(fw, n) == of).all() and (fs == os_).all() and (fe == oe).all(), (regex, flags)
+        # full-length 8-bit rows, stride 128: the unguarded kernels
+        full = nrng.choice([c for c in ALPHABET if c < 256], (1024, 128)).astype(np.uint8)
+        t = torch.from_numpy(full).cuda()
+        assert (unpack_bitmap(p.matches_batch(t), 1024) == o.batch_matches(full, threads=4)).all(), (regex, flags)
+        assert (unpack_bitmap(p.contained_in_batch(t), 1024) == o.batch_contained_in(full, threads=4)).all(), (regex, flags)
+        fw, fs, fe = p.find_batch(t)
+        of, os_, oe = o.batch_find(full, threads=4)
+        assert (unpack_bitmap(fw, 1024) == of).all(), (regex, flags)
+        assert (fs.cpu().numpy() == os_).all() and (fe.cpu().numpy() == oe).all(), (regex, flags)
+    assert len(modes) >= 2  # the draw covers more than one device mode
