@@ -332,4 +332,180 @@ hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipS
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Short rows (stride <= 64 bytes): no LDS transposition at all.  A row is at most four 16-byte pieces, so every lane
+// loads ITS OWN row straight into registers (64 lanes x 16 B at stride 16..64: whole lines per wave instruction) and
+// walks it there; the next group's loads are in flight meanwhile.  The tiled kernel spends a whole 128-byte tile
+// step per 64 rows whatever their length (45 G rows/s: 0.76 TB/s on 16-byte rows).  Always "guarded": per-row lengths
+// and find() cursors cost a few selects on at most 64 chars.
+// ------------------------------------------------------------------------------------------------
+template <int OP, int CW, int MODE>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
+    __syncthreads();
+    Walk wk;
+    constexpr uint32_t ELEM = (MODE == MODE_TABLE16) ? 2u : 1u;
+    wk.ncols_e = a.hdr.n_cols * ELEM;
+    wk.pad_e = (MODE == MODE_PACK) ? a.hdr.pad_f : a.hdr.pad_col * ELEM;
+    wk.pre_e = (MODE == MODE_PACK) ? a.hdr.pre_f : (a.hdr.pad_col + 1u) * ELEM;
+    wk.pad_b = wk.pre_b = 0;
+    if (MODE == MODE_PAIR) {
+        wk.ncols_e = a.hdr.n_cols * a.hdr.n_cols * 2u;
+        wk.pad_e = a.hdr.pad_col * a.hdr.n_cols * 2u;
+        wk.pre_e = (a.hdr.pad_col + 1u) * a.hdr.n_cols * 2u;
+        wk.pad_b = a.hdr.pad_col * 2u;
+        wk.pre_b = (a.hdr.pad_col + 1u) * 2u;
+    }
+    wk.table_off = a.hdr.off_table;
+    wk.lane4 = (uint32_t)(lane & 31) * 4u;
+    wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
+    constexpr uint32_t SCALE = (MODE == MODE_PACK) ? 5u : 1u;
+    const uint32_t accept_lo = a.hdr.accept_lo * SCALE, start_state = a.hdr.start * SCALE;
+    constexpr int CPP = 16 / CW;
+    const uint32_t n_pieces = (uint32_t)(a.stride_bytes >> 4); // 1..4, wave-uniform
+    const uint64_t n_groups = (a.n_rows + 63) >> 6;
+    const uint64_t wave_cnt = (uint64_t)gridDim.x * kWavesPerBlock;
+    uint64_t g = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (g >= n_groups) return;
+    auto fetch = [&](uint64_t grp, u32x4 (&d)[4]) __attribute__((always_inline)) {
+        uint64_t row = (grp << 6) + lane;
+        if (row >= a.n_rows) row = a.n_rows - 1; // lanes past the batch re-read its last row (verdict masked below)
+        const uint8_t *p = a.rows + row * a.stride_bytes;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((uint32_t)j < n_pieces) d[j] = *(const u32x4 *)(p + 16 * j);
+    };
+    u32x4 cur[4] = {}, nxt[4] = {};
+    fetch(g, cur);
+    for (;;) {
+        const uint64_t ng = g + wave_cnt;
+        if (ng < n_groups) fetch(ng, nxt);
+        const uint64_t my_row = (g << 6) + lane;
+        const bool row_ok = my_row < a.n_rows;
+        uint32_t len = 0;
+        if (row_ok) len = a.lengths ? a.lengths[my_row] : a.row_len;
+        int32_t cursor = 0;
+        bool dead = false;
+        if (OP == OP_FIND && a.from) {
+            cursor = row_ok ? a.from[my_row] : -1;
+            dead = cursor < 0; // find(): `if nextStart == -1 return false`, DFAClassBuilder.java:629-630
+            if (dead) cursor = 0;
+        }
+        uint32_t st = start_state;
+        int32_t last = -1;
+        if (OP == OP_FIND && a.hdr.root_accepting) last = ((uint32_t)cursor < len) ? cursor : 0; // :356, :440
+        int32_t last_rel = -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((uint32_t)j < n_pieces) {
+                const uint32_t w[4] = {cur[j][0], cur[j][1], cur[j][2], cur[j][3]};
+                walk_piece<OP, CW, MODE, true>(wk, w, (uint32_t)(j * CPP), len, (uint32_t)cursor, accept_lo, st, last_rel);
+            }
+        }
+        if (OP == OP_FIND) last = last_rel >= 0 ? last_rel : last;
+        bool res;
+        if (OP == OP_FIND) res = row_ok && !dead && (last >= 0);
+        else res = row_ok && (st >= accept_lo);
+        const uint64_t word = __ballot(res);
+        if (lane == 0) a.bitmap[g] = word;
+        if (OP == OP_FIND) {
+            int32_t s = -1;
+            const int32_t e = res ? last : -1;
+            if (a.fixed_len >= 0) {
+                s = res ? last - a.fixed_len : -1; // :640-646
+            } else {
+                // indexBackwards(end - 1, FROM), :536-583.  Column map (and a small backward table) in LDS, the row's
+                // chars re-read 8 at a time from its line (fetched a moment ago: L2).
+                const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
+                const uint16_t *bt = a.hdr.off_btable ? (const uint16_t *)(smem + a.hdr.off_btable)
+                                                       : (const uint16_t *)(a.bprog + a.bhdr.off_table);
+                const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo;
+                const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
+                int32_t idx_b = last - 1;
+                uint32_t bs = a.bhdr.start;
+                int32_t lastb = a.bhdr.root_accepting ? cursor : INT_MAX; // :543-547 (LENGTH var = FROM)
+                bool active = res;
+                while (__ballot(active) != 0ull) {
+                    uint32_t cs[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int32_t p = idx_b - k;
+                        cs[k] = 0;
+                        if (active && p >= cursor) cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (active) {
+                            if (idx_b < cursor) { // loop bound `index >= FROM`, :549
+                                active = false;
+                            } else {
+                                bs = bt[bs * bcols + column_of<CW>(bcmap, bptab, bpages, cs[k])];
+                                if (bs == 0) {
+                                    active = false;
+                                } else {
+                                    if (bs >= bacc) lastb = idx_b;
+                                    --idx_b;
+                                }
+                            }
+                        }
+                    }
+                }
+                s = res ? lastb : -1;
+            }
+            if (row_ok) {
+                a.start[my_row] = s;
+                a.end[my_row] = e;
+            }
+        }
+        if (ng >= n_groups) break;
+        g = ng;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+}
+
+template <int OP, int CW, int MODE>
+static hipError_t launch_short_one(const ScanArgs &a, int grid, size_t lds, hipStream_t stream) {
+    auto k = short_kernel<OP, CW, MODE>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kWavesPerBlock * 64), lds, stream, a);
+    return hipGetLastError();
+}
+template <int OP, int CW>
+static hipError_t launch_short_m(const ScanArgs &a, int grid, size_t lds, hipStream_t s) {
+    switch (a.hdr.mode) {
+    case MODE_PACK: return launch_short_one<OP, CW, MODE_PACK>(a, grid, lds, s);
+    case MODE_TABLE8: return launch_short_one<OP, CW, MODE_TABLE8>(a, grid, lds, s);
+    case MODE_TABLE16: return launch_short_one<OP, CW, MODE_TABLE16>(a, grid, lds, s);
+    case MODE_PAIR: return CW == 1 ? launch_short_one<OP, 1, MODE_PAIR>(a, grid, lds, s) : hipErrorInvalidValue;
+    default: return launch_short_one<OP, CW, MODE_GLOBAL>(a, grid, lds, s);
+    }
+}
+template <int OP>
+static hipError_t launch_short_c(const ScanArgs &a, int cw, int grid, size_t lds, hipStream_t s) {
+    return cw == 1 ? launch_short_m<OP, 1>(a, grid, lds, s) : launch_short_m<OP, 2>(a, grid, lds, s);
+}
+
+// rows of at most 64 bytes (stride a multiple of 16)
+hipError_t launch_short_rows(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream) {
+    const uint64_t n_groups = (a.n_rows + 63) >> 6;
+    uint64_t blocks = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
+    const size_t lds = (a.hdr.lds_bytes + 15u) & ~15u;
+    switch (op) {
+    case OP_MATCHES: return launch_short_c<OP_MATCHES>(a, char_width, (int)blocks, lds, stream);
+    case OP_CONTAINED_IN: return launch_short_c<OP_CONTAINED_IN>(a, char_width, (int)blocks, lds, stream);
+    default: return launch_short_c<OP_FIND>(a, char_width, (int)blocks, lds, stream);
+    }
+}
+
 } // namespace needle

@@ -163,4 +163,101 @@ __device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t 
     return MODE == MODE_TABLE8 ? lds_u8(addr) : lds_u16(addr);
 }
 
+// One 16-byte piece of one row: w = its four dwords, p0 = index of its first char inside the tile (or row), rem /
+// skip = GUARD: chars of the row from the tile start on / chars before the find() cursor, st = the automaton state
+// (5 * id in packed mode), last_rel = OP_FIND: index + 1 of the last accepting char seen (same origin as p0).
+template <int OP, int CW, int MODE, bool GUARD>
+__device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4], uint32_t p0, uint32_t rem, uint32_t skip,
+                                           uint32_t accept_lo, uint32_t &st, int32_t &last_rel) {
+    constexpr int CPP = 16 / CW; // chars per 16-byte piece
+    // Table modes are bound by LDS cycles, not by issue: a lane whose verdict is already final (sink, or
+    // accepted for containedIn) is masked out of the piece's lookups, so its LDS passes and the bank
+    // conflicts it would cause disappear.  (Packed mode is conflict-free by construction: no masking.)
+    bool lane_live = true;
+    if (MODE != MODE_PACK && NEEDLE_MASK_DONE_LANES)
+        lane_live = (OP == OP_CONTAINED_IN) ? (st - 1u < accept_lo - 1u) : (st != 0u);
+    if (lane_live) {
+    // all state-independent lookups of the piece first (they pipeline in the LDS) ...
+    uint32_t col[CPP];
+    if (CW == 2) {
+        // UTF-16: three dependent lookups per char (page table -> page -> F).  Issued as three batches of 8
+        // with ONE wait between batches: left to the scheduler they come out as ~14 short waits per piece,
+        // each exposing a full LDS round trip.
+        constexpr uint32_t kPages = (MODE == MODE_PACK) ? kLdsPages2Pack : kLdsPages2Table;
+        uint32_t pg[CPP], ce[CPP];
+#define NEEDLE_PG(D, K) pg[(D) * 2 + (K)] = lds_u16(shl_byte<(2 * (K) + 1) & 3>(w[D], 1) + kLdsPtab2);
+#define NEEDLE_CE(D, K) ce[(D) * 2 + (K)] = lds_u8(or_byte<(2 * (K)) & 3>(pg[(D) * 2 + (K)], w[D]) + kPages);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            NEEDLE_PG(d, 0)
+            NEEDLE_PG(d, 1)
+        }
+        lds_fence();
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            NEEDLE_CE(d, 0)
+            NEEDLE_CE(d, 1)
+        }
+        lds_fence();
+#undef NEEDLE_PG
+#undef NEEDLE_CE
+#pragma unroll
+        for (int i = 0; i < CPP; ++i) {
+            uint32_t c = (MODE == MODE_PACK) ? lds_u32(ce[i] + kLdsF2) : ce[i]; // pages hold column * 4 | * element size
+            if (GUARD) {
+                c = (p0 + i < rem) ? c : wk.pad_e;
+                c = (p0 + i < skip) ? wk.pre_e : c;
+            }
+            col[i] = c;
+        }
+    } else {
+#define NEEDLE_LOOKUP(D, K)                                                                         \
+    col[(D) * 4 + (K)] = lookup<MODE, 1, GUARD, K>(wk, w[D], p0 + (D) * 4 + (K) < rem, p0 + (D) * 4 + (K) < skip);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            NEEDLE_LOOKUP(d, 0)
+            NEEDLE_LOOKUP(d, 1)
+            NEEDLE_LOOKUP(d, 2)
+            NEEDLE_LOOKUP(d, 3)
+        }
+#undef NEEDLE_LOOKUP
+    }
+    // ... then ONE wait for all of them instead of one s_waitcnt per char (the walk is issue-bound), ...
+    // (packed mode only: in the table and pair modes the same fence costs 5-8 %, their lookups are better left
+    // interleaved with the dependent chain)
+    if (MODE == MODE_PACK && NEEDLE_PIECE_FENCE) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ... then the dependent chain
+    if (MODE == MODE_PAIR) {
+        uint32_t pair_e[CPP / 2]; // off the chain: column pair offsets
+#pragma unroll
+        for (int i = 0; i < CPP; i += 2) pair_e[i / 2] = col[i] + col[i + 1];
+#pragma unroll
+        for (int i = 0; i < CPP; i += 2) {
+            const uint32_t e = lds_u16(__umul24(st, wk.ncols_e) + pair_e[i / 2] + kLdsPairTable1);
+            st = e & 0xFFu;
+            if (OP == OP_FIND) {
+                const uint32_t code = e >> 8;            // 0 | 1: accepted after char i only | 2: after char i + 1
+                const uint32_t pos = p0 + i + code;      // = index of the accepting char + 1
+                bool acc = code != 0u;
+                if (GUARD) acc = acc && (pos > skip);    // an accepting start state must not count before the cursor
+                last_rel = acc ? (int32_t)pos : last_rel;
+            }
+        }
+    } else
+#pragma unroll
+    for (int i = 0; i < CPP; ++i) {
+        st = apply<MODE, CW>(wk, st, col[i]);
+        if (OP == OP_FIND) {
+            bool acc = st >= accept_lo;
+            if (GUARD) acc = acc && (p0 + i >= skip); // an accepting start state must not count before the cursor
+            last_rel = acc ? (int32_t)(p0 + i + 1) : last_rel;
+        }
+    }
+    } // lane_live
+}
+
 } // namespace needle
