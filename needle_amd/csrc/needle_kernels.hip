@@ -185,12 +185,31 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         constexpr int kUnroll = GUARD ? (OP == OP_FIND ? 1 : 2) : G::kPieces;
         constexpr int CPP = 16 / CW; // chars per 16-byte piece
         u32x4 v = tile_piece<CHB>(tile, lane, 0);
+        if (GUARD && NEEDLE_SPLIT_BOUNDARY && a.from == nullptr) {
+            // Ragged rows without cursors (wave-uniform branch): a row has at most ONE piece that its length cuts.
+            // Pieces wholly inside the row run the unguarded code under an exec mask, pieces wholly past it are
+            // skipped (chars there can only park the automaton: PAD is identity or the sink), and the cut piece of
+            // every lane -- a different one per lane -- is walked once after the loop with the per-char guards.
+            const uint32_t n_in = rem / CPP; // pieces of this tile wholly inside the row (may exceed kPieces)
+#pragma unroll
+            for (int kk = 0; kk < G::kPieces; ++kk) {
+                const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
+                if (kk + 1 < G::kPieces) v = tile_piece<CHB>(tile, lane, kk + 1);
+                if ((uint32_t)kk < n_in) walk_piece<OP, CW, MODE, false>(wk, w, kk * CPP, 0, 0, accept_lo, st, last_rel);
+            }
+            if (n_in < (uint32_t)G::kPieces && rem % CPP != 0) {
+                const u32x4 b = tile_piece<CHB>(tile, lane, (int)n_in);
+                const uint32_t w[4] = {b[0], b[1], b[2], b[3]};
+                walk_piece<OP, CW, MODE, true>(wk, w, n_in * CPP, rem, 0, accept_lo, st, last_rel);
+            }
+        } else {
 #pragma unroll kUnroll
         for (int kk = 0; kk < G::kPieces; ++kk) {
             const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
             if (kk + 1 < G::kPieces) v = tile_piece<CHB>(tile, lane, kk + 1); // next piece: its latency hides below
             const uint32_t p0 = kk * CPP;
             walk_piece<OP, CW, MODE, GUARD>(wk, w, p0, rem, skip, accept_lo, st, last_rel);
+        }
         }
         if (OP == OP_FIND) {
             if (a.fixed_len < 0) { // wave-uniform

@@ -16,6 +16,9 @@
 #ifndef NEEDLE_NT_LOADS
 #define NEEDLE_NT_LOADS 1
 #endif
+#ifndef NEEDLE_SPLIT_BOUNDARY
+#define NEEDLE_SPLIT_BOUNDARY 1
+#endif
 #ifndef NEEDLE_PIECE_FENCE
 #define NEEDLE_PIECE_FENCE 1
 #endif

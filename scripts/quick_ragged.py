@@ -7,9 +7,12 @@ rows = torch.empty((n, 256), dtype=torch.uint8, device="cuda")
 for s in range(0, n, 1 << 19):
     m = min(1 << 19, n - s); rows[s:s+m] = W.digits_batch(torch, s, m, 256, device="cuda")
 lens = (torch.arange(n, device="cuda", dtype=torch.int64) * 2654435761 % 256 + 1).to(torch.int32)
-p = DFACompiler.compile("[0-9]+", "d")
+rx = sys.argv[1] if len(sys.argv) > 1 else "[0-9]+"
+p = DFACompiler.compile(rx, "d")
+full_lens = torch.full((n,), 256, dtype=torch.int32, device="cuda")
+print(rx)
 for name, op in (("containedIn", p.contained_in_batch), ("matches", p.matches_batch), ("find", p.find_batch)):
-    for l, tag in ((None, "full"), (lens, "ragged[1,256]")):
+    for l, tag in ((None, "full"), (full_lens, "lengths=256"), (lens, "ragged[1,256]")):
         for _ in range(3): op(rows, l)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
