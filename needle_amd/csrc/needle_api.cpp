@@ -1,6 +1,7 @@
 // C ABI of libneedle_hip.so (include/needle_hip.h): pattern objects, per-device program cache, batch entry
 // points, and the single-haystack Matcher mirror.  No CPU matching path exists in this library.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -261,8 +262,32 @@ static int run_host_small(const needle_pattern *p, int op, const needle_batch_vi
 }
 
 // Host-buffer convenience: pad rows to a 16-byte stride, upload, run, download.
+static int run_host_one(const needle_pattern *p, int op, const needle_batch_view *v, uint64_t *bitmap, int32_t *start,
+                        int32_t *end);
+
+// Host batches of any size: at most kHostChunkBytes of rows are resident on the device at a time (chunks start on
+// 64-row boundaries, so every chunk owns whole bitmap words).
 static int run_host(const needle_pattern *p, int op, const needle_batch_view *v, uint64_t *bitmap, int32_t *start,
                     int32_t *end) {
+    int rc = check_view(v, false);
+    if (rc) return rc;
+    static const uint64_t kHostChunkBytes = getenv("NEEDLE_HOST_CHUNK_BYTES") ? (uint64_t)atoll(getenv("NEEDLE_HOST_CHUNK_BYTES")) : (2ull << 30);
+    const uint64_t row_bytes = std::max<uint64_t>(16, (v->row_stride * v->char_width + 15) & ~(uint64_t)15);
+    uint64_t per = std::max<uint64_t>(64, (kHostChunkBytes / row_bytes) & ~(uint64_t)63);
+    if (v->n_rows <= per) return run_host_one(p, op, v, bitmap, start, end);
+    for (uint64_t r0 = 0; r0 < v->n_rows; r0 += per) {
+        needle_batch_view c = *v;
+        c.n_rows = std::min<uint64_t>(per, v->n_rows - r0);
+        c.rows = (const uint8_t *)v->rows + r0 * v->row_stride * v->char_width;
+        c.lengths = v->lengths ? v->lengths + r0 : nullptr;
+        rc = run_host_one(p, op, &c, bitmap ? bitmap + r0 / 64 : nullptr, start ? start + r0 : nullptr, end ? end + r0 : nullptr);
+        if (rc) return rc;
+    }
+    return NEEDLE_OK;
+}
+
+static int run_host_one(const needle_pattern *p, int op, const needle_batch_view *v, uint64_t *bitmap, int32_t *start,
+                        int32_t *end) {
     int rc = check_view(v, false);
     if (rc) return rc;
     if (v->n_rows == 0) return NEEDLE_OK;
@@ -341,9 +366,74 @@ static int check_packed(const needle_packed_view *v) {
     return NEEDLE_OK;
 }
 
-// Packed host batch: upload data + offsets, convert to the fixed-stride layout on the device, run, download.
+static int run_packed_host_one(const needle_pattern *p, int op, const needle_packed_view *v, uint64_t *bitmap,
+                               int32_t *start, int32_t *end);
+
+// Packed host batch.  The fixed-stride layout the kernels read pads every row to the longest one: harmless when the
+// lengths are alike, ruinous when one 1 MB document sits among a million 40-char strings.  Rows are therefore grouped
+// into length classes (stride 64 B, 256 B, 1 KiB, ... x4) and every class runs as its own batch, so the padded
+// bytes stay below 4x the text.
 static int run_packed_host(const needle_pattern *p, int op, const needle_packed_view *v, uint64_t *bitmap, int32_t *start,
                            int32_t *end) {
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_packed(v);
+    if (rc) return rc;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!bitmap) return fail(NEEDLE_ERR_INVALID, "bitmap is NULL");
+    if (op == OP_FIND && (!start || !end)) return fail(NEEDLE_ERR_INVALID, "start/end is NULL");
+    const uint64_t cw = v->char_width, n = v->n_rows;
+    uint64_t max_len = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        if (v->offsets[r + 1] < v->offsets[r]) return fail(NEEDLE_ERR_INVALID, "offsets must be non-decreasing");
+        max_len = std::max<uint64_t>(max_len, v->offsets[r + 1] - v->offsets[r]);
+    }
+    const uint64_t total_bytes = v->offsets[n] * cw;
+    const uint64_t padded = n * std::max<uint64_t>(16, (max_len * cw + 15) & ~(uint64_t)15);
+    if (padded <= 4 * total_bytes + (64u << 10)) return run_packed_host_one(p, op, v, bitmap, start, end);
+    auto klass = [&](uint64_t len_chars) { // smallest k with len * cw <= 64 << 2k
+        int k = 0;
+        while ((len_chars * cw) > (64ull << (2 * k))) ++k;
+        return k;
+    };
+    const int n_classes = klass(max_len) + 1;
+    std::vector<std::vector<uint64_t>> rows_of((size_t)n_classes);
+    for (uint64_t r = 0; r < n; ++r) rows_of[(size_t)klass(v->offsets[r + 1] - v->offsets[r])].push_back(r);
+    memset(bitmap, 0, ((n + 63) / 64) * 8);
+    std::vector<uint8_t> data;
+    std::vector<uint64_t> off, bm;
+    std::vector<int32_t> st, en;
+    for (const auto &ids : rows_of) {
+        if (ids.empty()) continue;
+        off.assign(ids.size() + 1, 0);
+        for (size_t i = 0; i < ids.size(); ++i) off[i + 1] = off[i] + (v->offsets[ids[i] + 1] - v->offsets[ids[i]]);
+        data.resize((size_t)(off.back() * cw));
+        for (size_t i = 0; i < ids.size(); ++i)
+            memcpy(data.data() + off[i] * cw, (const uint8_t *)v->data + v->offsets[ids[i]] * cw, (size_t)((off[i + 1] - off[i]) * cw));
+        needle_packed_view sub;
+        sub.data = data.data();
+        sub.char_width = v->char_width;
+        sub.n_rows = ids.size();
+        sub.offsets = off.data();
+        bm.assign((ids.size() + 63) / 64, 0);
+        if (op == OP_FIND) {
+            st.assign(ids.size(), -1);
+            en.assign(ids.size(), -1);
+        }
+        rc = run_packed_host_one(p, op, &sub, bm.data(), st.data(), en.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < ids.size(); ++i) {
+            if ((bm[i >> 6] >> (i & 63)) & 1) bitmap[ids[i] >> 6] |= 1ull << (ids[i] & 63);
+            if (op == OP_FIND) {
+                start[ids[i]] = st[i];
+                end[ids[i]] = en[i];
+            }
+        }
+    }
+    return NEEDLE_OK;
+}
+
+static int run_packed_host_one(const needle_pattern *p, int op, const needle_packed_view *v, uint64_t *bitmap,
+                               int32_t *start, int32_t *end) {
     if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
     int rc = check_packed(v);
     if (rc) return rc;

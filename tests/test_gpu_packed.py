@@ -82,3 +82,63 @@ def test_find_strings_matches_single_string_matcher():
         assert bool(matched[i]) == m.find(), s
         if matched[i]:
             assert (st[i], en[i]) == (m.start(), m.end()), s
+
+
+@pytest.mark.gpu
+def test_skewed_lengths_run_as_length_classes():
+    """One 300 000-char document among thousands of short strings: padding every row to the longest one would need
+    1.5 GB for 0.5 MB of text; the packed host path groups rows into length classes instead.  Same bits either way."""
+    from needle_amd.pattern import unpack_bitmap
+    p, o = compiled("[0-9]+")
+    rng = np.random.default_rng(3)
+    alphabet = np.array([ord(c) for c in "abcxyz 0123456789"])
+    rows, lens = random_rows(rng, 5000, 60, alphabet)
+    for at, n_chars in ((17, 300_000), (4000, 5_000), (4999, 700)):
+        rows[at] = rng.choice(alphabet, n_chars)
+    rows[17][:299_990] = ord("q")  # the long row's only digits sit in its last ten chars
+    data, offsets = pack(rows, np.uint8)
+    fw, fs, fe = p.find_packed(data, offsets)
+    cb = unpack_bitmap(p.contained_in_packed(data, offsets), len(rows))
+    mb = unpack_bitmap(p.matches_packed(data, offsets), len(rows))
+    got = unpack_bitmap(fw, len(rows))
+    for i, r in enumerate(rows):
+        s = r.astype(np.uint8).tobytes().decode("latin-1")
+        found, st, en = o.find(s)
+        assert got[i] == found and cb[i] == found and mb[i] == o.matches(s), i
+        if found:
+            assert (fs[i], fe[i]) == (st, en), i
+        else:
+            assert (fs[i], fe[i]) == (-1, -1), i
+    assert fs[17] >= 299_990
+
+
+@pytest.mark.gpu
+def test_large_host_batches_are_chunked():
+    """Host batches larger than the device-resident chunk size run chunk by chunk (64-row aligned); the chunk size is read
+    once per process, so the small-chunk run happens in a subprocess."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, ".")
+from needle_amd import workload as W
+from needle_amd.pattern import DFACompiler
+p = DFACompiler.compile("[0-9]+", "d")
+rows = W.digits_batch(np, 0, 30011, 256)
+lens = (np.arange(30011) * 2654435761 % 257).astype(np.uint32)
+c = p.contained_in_batch(rows, lens)
+m = p.matches_batch(rows)
+fw, fs, fe = p.find_batch(rows, lens)
+np.save(sys.argv[1], np.concatenate([c.view(np.int64), m.view(np.int64), fw.view(np.int64), fs.astype(np.int64), fe.astype(np.int64)]))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for chunk in ("0", str(1 << 20)):  # 0: library default (one chunk), 1 MiB: 8 chunks of 4096 rows
+        path = "/tmp/needle_chunk_%s.npy" % chunk
+        env = dict(os.environ)
+        if chunk != "0":
+            env["NEEDLE_HOST_CHUNK_BYTES"] = chunk
+        subprocess.check_call([sys.executable, "-c", code, path], cwd=root, env=env)
+        out.append(np.load(path))
+    assert (out[0] == out[1]).all()
