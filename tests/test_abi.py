@@ -111,3 +111,26 @@ def test_packed_view_validation_without_a_gpu(lib):
     # zero rows: nothing to do, no device needed
     words = p.contained_in_packed(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
     assert words.size == 0
+
+
+def test_table_string_codec_known_answers(lib):
+    """ByteClassUtilTest.java:17-58: the hex "state:class-target,...;..." codec (fillMultipleByteClassesFromString
+    [UsingShorts]_singleArray), through the oracle's decoder and through needle_pattern_from_tables' table_string."""
+    from needle_amd.pattern import Pattern
+    from oracle.walker import decode_table_strings
+    text = "0:1-2,2-3,3-c;1:1-3,2-4,3-13;2:1-4,2-5,3-e;c:1-d,2-e,3-17"
+    want = {1: 2, 2: 3, 3: 12, 5: 3, 49: 13}
+    t = decode_table_strings([text], 24, 4)
+    for i, v in want.items():
+        assert t[i] == v
+    for i in range(4096):  # encodeDecode: hex round trip
+        assert int(format(i, "x"), 16) == i
+    cm = np.zeros(65536, dtype=np.uint8)
+    spec = dict(n_states=24, max_char=0xFFFF, accepting=[23], table_strings=[text])
+    p = Pattern.from_tables(cm, 4, {k: spec for k in ("matches", "contained_in", "forwards", "backwards")})
+    got = p.tables()["dfas"]["matches"]["table"]
+    for i, v in want.items():
+        assert got[i] == v
+    assert (got == t).all()
+    with pytest.raises(ValueError):  # fill_bytes_from_string_errors_on_bad_input: "1-z"
+        Pattern.from_tables(cm, 4, {k: dict(spec, table_strings=["0:1-z"]) for k in ("matches", "contained_in", "forwards", "backwards")})
