@@ -55,4 +55,33 @@ def test_random_regexes_on_random_haystacks(seed):
         of, os_, oe = o.batch_find(full, threads=4)
         assert (unpack_bitmap(fw, 1024) == of).all(), (regex, flags)
         assert (fs.cpu().numpy() == os_).all() and (fe.cpu().numpy() == oe).all(), (regex, flags)
-    assert len(modes) >= 2  # the draw covers more than one device mode
+        # short rows (stride <= 64 B: the register-resident kernel), ragged and full
+        lens_s = nrng.integers(0, 25, n)
+        rows_s = [nrng.choice(ALPHABET, int(l)).astype(np.uint16) for l in lens_s]
+        off_s = np.zeros(n + 1, dtype=np.uint64)
+        off_s[1:] = np.cumsum(lens_s)
+        data_s = np.concatenate(rows_s) if off_s[-1] else np.zeros(0, dtype=np.uint16)
+        pad_s = np.zeros((n, 25), dtype=np.uint16)
+        for i, r in enumerate(rows_s):
+            pad_s[i, :len(r)] = r
+        fw, fs, fe = p.find_packed(data_s, off_s)
+        of, os_, oe = o.batch_find(pad_s, lens_s.astype(np.uint32), threads=4)
+        assert (unpack_bitmap(fw, n) == of).all() and (fs == os_).all() and (fe == oe).all(), (regex, flags, "short")
+        assert (unpack_bitmap(p.matches_packed(data_s, off_s), n) == o.batch_matches(pad_s, lens_s.astype(np.uint32), threads=4)).all(), (regex, flags, "short")
+        full_s = nrng.choice([c for c in ALPHABET if c < 256], (1000, 48)).astype(np.uint8)
+        ts = torch.from_numpy(full_s).cuda()
+        fw, fs, fe = p.find_batch(ts)
+        of, os_, oe = o.batch_find(full_s, threads=4)
+        assert (unpack_bitmap(fw, 1000) == of).all() and (fs.cpu().numpy() == os_).all() and (fe.cpu().numpy() == oe).all(), (regex, flags, "short full")
+        assert (unpack_bitmap(p.contained_in_batch(ts), 1000) == o.batch_contained_in(full_s, threads=4)).all(), (regex, flags, "short full")
+        # few long rows (the stripe path when the automaton lowers to packed functions; one row per lane otherwise)
+        long_rows = nrng.choice([c for c in ALPHABET if c < 256], (3, 40_000)).astype(np.uint8)
+        long_lens = np.array([40_000, 33_333, 4096], dtype=np.uint32)
+        tl = torch.from_numpy(long_rows).cuda()
+        tll = torch.from_numpy(long_lens.astype(np.int32)).cuda()
+        fw, fs, fe = p.find_batch(tl, tll)
+        of, os_, oe = o.batch_find(long_rows, long_lens, threads=3)
+        assert (unpack_bitmap(fw, 3) == of).all() and (fs.cpu().numpy() == os_).all() and (fe.cpu().numpy() == oe).all(), (regex, flags, "long")
+        assert (unpack_bitmap(p.matches_batch(tl, tll), 3) == o.batch_matches(long_rows, long_lens, threads=3)).all(), (regex, flags, "long")
+        assert (unpack_bitmap(p.contained_in_batch(tl, tll), 3) == o.batch_contained_in(long_rows, long_lens, threads=3)).all(), (regex, flags, "long")
+    assert modes  # (which device modes a seed draws varies: packed functions, pair table, uint8 table)
