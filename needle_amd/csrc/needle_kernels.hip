@@ -185,22 +185,32 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         constexpr int kUnroll = GUARD ? (OP == OP_FIND ? 1 : 2) : G::kPieces;
         constexpr int CPP = 16 / CW; // chars per 16-byte piece
         u32x4 v = tile_piece<CHB>(tile, lane, 0);
-        if (GUARD && NEEDLE_SPLIT_BOUNDARY && a.from == nullptr) {
-            // Ragged rows without cursors (wave-uniform branch): a row has at most ONE piece that its length cuts.
-            // Pieces wholly inside the row run the unguarded code under an exec mask, pieces wholly past it are
-            // skipped (chars there can only park the automaton: PAD is identity or the sink), and the cut piece of
-            // every lane -- a different one per lane -- is walked once after the loop with the per-char guards.
-            const uint32_t n_in = rem / CPP; // pieces of this tile wholly inside the row (may exceed kPieces)
+        if (GUARD && NEEDLE_SPLIT_BOUNDARY) {
+            // Ragged rows / per-row cursors: a row has at most ONE piece that its length cuts and ONE that its find()
+            // cursor cuts.  Pieces wholly between the two run the unguarded code under an exec mask; pieces wholly
+            // before the cursor or past the length are skipped (chars there can only park the automaton: PRE is
+            // identity, PAD identity or the sink); the cut pieces -- different ones per lane -- are walked with the
+            // per-char guards, the cursor's before the loop and the length's after it.
+            const uint32_t n_in = rem / CPP;                  // pieces of this tile wholly inside the row (may exceed kPieces)
+            const uint32_t first_in = (skip + CPP - 1) / CPP; // first piece wholly at or after the cursor
+            const bool cursor_cut = (skip % CPP != 0) && (skip / CPP < (uint32_t)G::kPieces);
+            if (cursor_cut) {
+                const uint32_t cp = skip / CPP;
+                const u32x4 c = tile_piece<CHB>(tile, lane, (int)cp);
+                const uint32_t w[4] = {c[0], c[1], c[2], c[3]};
+                walk_piece<OP, CW, MODE, true>(wk, w, cp * CPP, rem, skip, accept_lo, st, last_rel);
+            }
 #pragma unroll
             for (int kk = 0; kk < G::kPieces; ++kk) {
                 const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
                 if (kk + 1 < G::kPieces) v = tile_piece<CHB>(tile, lane, kk + 1);
-                if ((uint32_t)kk < n_in) walk_piece<OP, CW, MODE, false>(wk, w, kk * CPP, 0, 0, accept_lo, st, last_rel);
+                if ((uint32_t)kk >= first_in && (uint32_t)kk < n_in)
+                    walk_piece<OP, CW, MODE, false>(wk, w, kk * CPP, 0, 0, accept_lo, st, last_rel);
             }
-            if (n_in < (uint32_t)G::kPieces && rem % CPP != 0) {
+            if (n_in < (uint32_t)G::kPieces && rem % CPP != 0 && !(cursor_cut && skip / CPP == n_in)) {
                 const u32x4 b = tile_piece<CHB>(tile, lane, (int)n_in);
                 const uint32_t w[4] = {b[0], b[1], b[2], b[3]};
-                walk_piece<OP, CW, MODE, true>(wk, w, n_in * CPP, rem, 0, accept_lo, st, last_rel);
+                walk_piece<OP, CW, MODE, true>(wk, w, n_in * CPP, rem, skip, accept_lo, st, last_rel);
             }
         } else {
 #pragma unroll kUnroll

@@ -277,29 +277,29 @@ class Pattern:
         dev = rows.device
         cursor = torch.zeros(n, dtype=torch.int32, device=dev)
         ids = torch.arange(n, dtype=torch.int64, device=dev)
-        out_rows, out_s, out_e = [], [], []
-        rounds = 0
+        counts = torch.zeros(n, dtype=torch.int64, device=dev)
+        per_round = []  # round k holds the k-th match of every row that has one: no sort needed to build the CSR
         while True:
             _, st, en = self.find_next_batch(rows, cursor, lengths)
             hit = en >= 0
             if not bool(hit.any()):
                 break
-            out_rows.append(ids[hit])
-            out_s.append(st[hit])
-            out_e.append(en[hit])
+            per_round.append((ids[hit], st[hit], en[hit]))
+            counts += hit
             empty = hit & (en == st)
             cursor = torch.where(hit & ~empty, en, torch.full_like(en, -1))
-            rounds += 1
-            if max_rounds is not None and rounds >= max_rounds:
+            if max_rounds is not None and len(per_round) >= max_rounds:
                 break
-        if not out_rows:
-            return torch.zeros(n + 1, dtype=torch.int64, device=dev), cursor[:0], cursor[:0]
-        r, s_, e_ = torch.cat(out_rows), torch.cat(out_s), torch.cat(out_e)
-        order = torch.argsort(r * (1 << 32) + s_.to(torch.int64), stable=True)
-        r, s_, e_ = r[order], s_[order], e_[order]
         offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-        offsets[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
-        return offsets, s_, e_
+        offsets[1:] = torch.cumsum(counts, 0)
+        total = int(offsets[-1].item())
+        out_s = torch.empty(total, dtype=torch.int32, device=dev)
+        out_e = torch.empty(total, dtype=torch.int32, device=dev)
+        for k, (r, s_, e_) in enumerate(per_round):
+            pos = offsets[r] + k
+            out_s[pos] = s_
+            out_e[pos] = e_
+        return offsets, out_s, out_e
 
     def find_batch(self, rows, lengths=None, stream=None):
         """(bitmap words, start int32[n], end int32[n]); unmatched rows have start = end = -1."""
