@@ -213,7 +213,7 @@ struct HostArena {
         size_t want = 1 << 16;
         while (want < bytes) want <<= 1;
         if ((e = hipMalloc((void **)&d, want)) != hipSuccess) return e;
-        if ((e = hipHostMalloc((void **)&h, want, hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void **)&h, want, hipHostMallocMapped)) != hipSuccess) return e;
         if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return e;
         cap = want;
         dev = cur;
@@ -221,6 +221,7 @@ struct HostArena {
     }
 };
 constexpr size_t kSmallHostBatchBytes = 4u << 20;
+constexpr size_t kZeroCopyBytes = 16u << 10;
 } // namespace
 
 static int run_host_small(const needle_pattern *p, int op, const needle_batch_view *v, uint64_t dst_stride, uint64_t *bitmap,
@@ -243,15 +244,27 @@ static int run_host_small(const needle_pattern *p, int op, const needle_batch_vi
         }
     }
     if (v->lengths) memcpy(arena.h + o_len, v->lengths, n * 4);
-    HIP_TRY(hipMemcpyAsync(arena.d, arena.h, in_bytes, hipMemcpyHostToDevice, arena.stream));
+    // Tiny batches (one Matcher call): the kernel reads the pinned staging buffer and writes its results there
+    // directly over PCIe -- one launch and one wait, no copy commands at all.
+    const bool zero_copy = total <= kZeroCopyBytes;
+    uint8_t *base = arena.d;
+    if (zero_copy) {
+        void *mapped = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&mapped, arena.h, 0));
+        base = (uint8_t *)mapped;
+    } else {
+        HIP_TRY(hipMemcpyAsync(arena.d, arena.h, in_bytes, hipMemcpyHostToDevice, arena.stream));
+    }
     needle_batch_view dv = *v;
-    dv.rows = arena.d + o_rows;
-    dv.lengths = v->lengths ? (const uint32_t *)(arena.d + o_len) : nullptr;
+    dv.rows = base + o_rows;
+    dv.lengths = v->lengths ? (const uint32_t *)(base + o_len) : nullptr;
     dv.row_stride = dst_stride / cw;
-    int rc = run_dev(p, op, &dv, (uint64_t *)(arena.d + o_bm), (int32_t *)(arena.d + o_s), (int32_t *)(arena.d + o_e), arena.stream);
+    int rc = run_dev(p, op, &dv, (uint64_t *)(base + o_bm), (int32_t *)(base + o_s), (int32_t *)(base + o_e), arena.stream);
     if (rc) return rc;
-    const size_t out_bytes = op == OP_FIND ? total - o_bm : up16(words * 8);
-    HIP_TRY(hipMemcpyAsync(arena.h + o_bm, arena.d + o_bm, out_bytes, hipMemcpyDeviceToHost, arena.stream));
+    if (!zero_copy) {
+        const size_t out_bytes = op == OP_FIND ? total - o_bm : up16(words * 8);
+        HIP_TRY(hipMemcpyAsync(arena.h + o_bm, arena.d + o_bm, out_bytes, hipMemcpyDeviceToHost, arena.stream));
+    }
     HIP_TRY(hipStreamSynchronize(arena.stream));
     memcpy(bitmap, arena.h + o_bm, words * 8);
     if (op == OP_FIND) {
@@ -525,16 +538,11 @@ int needle_rows_from_packed_dev(const needle_packed_view *v, void *d_rows, uint6
         return fail(NEEDLE_ERR_INVALID, "row_stride * char_width must be a non-zero multiple of 16 bytes");
     if (((uintptr_t)d_rows) % 16 != 0) return fail(NEEDLE_ERR_INVALID, "d_rows must be 16-byte aligned");
     if (((uintptr_t)v->data) % 4 != 0) return fail(NEEDLE_ERR_INVALID, "packed data must be 4-byte aligned");
-    int dev = 0;
+    int dev = 0, cus = 0;
     HIP_TRY(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    static thread_local int cus_cached = 0;
-    if (!cus_cached) {
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        cus_cached = prop.multiProcessorCount;
-    }
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     HIP_TRY(launch_unpack(v->data, v->offsets, v->n_rows, v->char_width, d_rows, stride_bytes, d_lengths, d_overflow,
-                          cus_cached, (hipStream_t)stream));
+                          cus, (hipStream_t)stream));
     return NEEDLE_OK;
 }
 

@@ -387,12 +387,8 @@ struct LaunchShape {
 template <int OP, int CW, int MODE, bool GUARD, int CHB>
 static hipError_t launch_one(const ScanArgs &a, LaunchShape sh, hipStream_t stream) {
     auto k = scan_kernel<OP, CW, MODE, GUARD, CHB>;
-    static thread_local bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static thread_local uint64_t configured = 0;
+    if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.waves * 64), sh.lds, stream, a);
     return hipGetLastError();
 }

@@ -284,12 +284,8 @@ __global__ __launch_bounds__(256) void backward_row_kernel(const StripeArgs a) {
 template <int CW, bool FIND, int NS>
 static hipError_t launch_stripe(const StripeArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     auto k = stripe_kernel<CW, FIND, NS>;
-    static thread_local bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static thread_local uint64_t configured = 0;
+    if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(kWavesPerBlock * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -471,12 +467,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
 template <int OP, int CW, int MODE>
 static hipError_t launch_short_one(const ScanArgs &a, int grid, size_t lds, hipStream_t stream) {
     auto k = short_kernel<OP, CW, MODE>;
-    static thread_local bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static thread_local uint64_t configured = 0;
+    if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kWavesPerBlock * 64), lds, stream, a);
     return hipGetLastError();
 }

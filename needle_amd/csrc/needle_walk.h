@@ -263,4 +263,17 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
     } // lane_live
 }
 
+// Host side: let kernel `fn` use the whole 160 KiB of LDS.  The attribute belongs to (function, device): it is set
+// once per device a host thread launches `fn` on (a bit mask of devices already done, per instantiation).
+inline hipError_t allow_full_lds(const void *fn, uint64_t &done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done_mask & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e == hipSuccess) done_mask |= bit;
+    return e;
+}
+
 } // namespace needle
