@@ -133,3 +133,40 @@ def test_reference_inline_asserts_gpu_matcher():
             run_case(p, c, rng, rounds=1)
             n += 1
     assert n > 100
+
+
+# DFACompilerTest.java:623-633,663-699: sherlockStreetInFile / upperOrLowercaseSherlockInFile walk every
+# non-overlapping match of the regex over `Files.readAllLines(sherlockholmes.txt).get(0)` with repeated find() and
+# require the JDK's (start, end) each time.  That first line (it begins with U+FEFF, so it takes the UTF-16 path):
+SHERLOCK_LINE0 = "﻿The Project Gutenberg eBook of The Adventures of Sherlock Holmes, by Arthur Conan Doyle"
+FILE_CASES = [("Sherlock|Street", [(50, 58)]), ("[Ss]herlock", [(50, 58)]),
+              # findingIngWords, :603-614: two matches by repeated find()
+              ("[a-zA-Z]+ing", None)]
+ING_HAYSTACK = "the most perfect reasoning and observing machine that the world has seen"
+
+
+def stdlib_matches(regex, s):
+    import re
+    return [(m.start(), m.end()) for m in re.finditer(regex, s)]
+
+
+def test_file_based_repeated_find_oracle(oracle_lib):
+    for regex, want in FILE_CASES:
+        s = SHERLOCK_LINE0 if want is not None else ING_HAYSTACK
+        want = want if want is not None else stdlib_matches(regex, s)
+        o, _ = oracle_for(regex, 0)
+        assert o.find_all(s) == want
+    assert len(stdlib_matches("[a-zA-Z]+ing", ING_HAYSTACK)) == 2
+
+
+@pytest.mark.gpu
+def test_file_based_repeated_find_gpu_matcher():
+    from needle_amd.pattern import DFACompiler
+    for regex, want in FILE_CASES:
+        s = SHERLOCK_LINE0 if want is not None else ING_HAYSTACK
+        want = want if want is not None else stdlib_matches(regex, s)
+        m = DFACompiler.compile(regex, "fileSearchRegex").matcher(s)
+        got = []
+        while m.find():
+            got.append((m.start(), m.end()))
+        assert got == want, regex
