@@ -234,6 +234,8 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
         __builtin_amdgcn_sched_barrier(0);
     }
     // ... then the dependent chain
+    uint32_t lr = 0;                                          // OP_FIND: last accepting position inside this piece, + 1
+    const uint32_t skip_rel = skip > p0 ? skip - p0 : 0u;     // GUARD: chars of this piece before the cursor
     if (MODE == MODE_PAIR) {
         uint32_t pair_e[CPP / 2]; // off the chain: column pair offsets
 #pragma unroll
@@ -244,10 +246,10 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
             st = e & 0xFFu;
             if (OP == OP_FIND) {
                 const uint32_t code = e >> 8;            // 0 | 1: accepted after char i only | 2: after char i + 1
-                const uint32_t pos = p0 + i + code;      // = index of the accepting char + 1
+                const uint32_t pos = i + code;           // = index of the accepting char inside the piece + 1
                 bool acc = code != 0u;
-                if (GUARD) acc = acc && (pos > skip);    // an accepting start state must not count before the cursor
-                last_rel = acc ? (int32_t)pos : last_rel;
+                if (GUARD) acc = acc && (pos > skip_rel); // an accepting start state must not count before the cursor
+                lr = acc ? pos : lr;
             }
         }
     } else
@@ -256,10 +258,14 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
         st = apply<MODE, CW>(wk, st, col[i]);
         if (OP == OP_FIND) {
             bool acc = st >= accept_lo;
-            if (GUARD) acc = acc && (p0 + i >= skip); // an accepting start state must not count before the cursor
-            last_rel = acc ? (int32_t)(p0 + i + 1) : last_rel;
+            if (GUARD) acc = acc && ((uint32_t)i >= skip_rel); // an accepting start state must not count before the cursor
+            lr = acc ? (uint32_t)(i + 1) : lr;
         }
     }
+    // (positions are tracked inside the piece, 1 .. 16: inline constants.  Tracking p0 + i + 1 directly made the
+    // compiler keep 64 position literals in VGPRs across the unrolled tile loop -- 128 VGPRs, spills, and a scratch
+    // reload whose s_waitcnt vmcnt(0) drained the prefetched tile loads.)
+    if (OP == OP_FIND) last_rel = lr ? (int32_t)(p0 + lr) : last_rel;
     } // lane_live
 }
 
