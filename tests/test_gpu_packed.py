@@ -142,3 +142,37 @@ np.save(sys.argv[1], np.concatenate([c.view(np.int64), m.view(np.int64), fw.view
         subprocess.check_call([sys.executable, "-c", code, path], cwd=root, env=env)
         out.append(np.load(path))
     assert (out[0] == out[1]).all()
+
+
+@pytest.mark.gpu
+def test_one_pattern_shared_by_host_threads():
+    """A Pattern is immutable and shareable (Pattern thread-safe, Matcher not): several host threads
+    drive their own Matchers and small batches through ONE pattern object concurrently (ctypes drops the GIL)."""
+    import threading
+    from needle_amd.pattern import DFACompiler, unpack_bitmap
+    p = DFACompiler.compile("[0-9]+|Sherlock")
+    strings = ["ab12cd345", "", "no digits here", "Sherlock Holmes 221B", "x" * 100 + "7", "Sherloc"]
+    want = [[(2, 4), (6, 9)], [], [], [(0, 8), (16, 19)], [(100, 101)], []]
+    errors = []
+
+    def worker(seed):
+        try:
+            for it in range(150):
+                i = (seed + it) % len(strings)
+                m = p.matcher(strings[i])
+                got = []
+                while m.find():
+                    got.append((m.start(), m.end()))
+                assert got == want[i], (seed, it, got)
+                matched, st, en = p.find_strings(strings)
+                assert list(matched) == [bool(w) for w in want]
+                assert [(int(a), int(b)) for a, b, ok in zip(st, en, matched) if ok] == [w[0] for w in want if w]
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
