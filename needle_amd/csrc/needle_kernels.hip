@@ -10,7 +10,9 @@
 //        --ds_read_b128 (each lane its own row; the global SOURCE piece index is XOR-swizzled so that these
 //        row-strided reads hit 16 distinct 16-B bank slots per 16-lane service group)--> per-char walk.
 // Register staging (instead of global_load_lds DMA) is what lets a wave keep a full tile of HBM reads in flight
-// while it walks the previous one: in-flight bytes are not capped by the LDS tile buffers.
+// while it walks the previous one: in-flight bytes are not capped by the LDS tile buffers.  Every 128-byte line is
+// requested exactly once: by one `nt` load instruction (CHB = 128) or by the two halves of a fetch unit issued back to
+// back (CHB = 64).  The per-char code itself (all automaton modes) is walk_piece() in needle_walk.h.
 //
 // The loops restated here (reference: needle-compiler/src/main/java/com/justinblank/strings/
 // DFAClassBuilder.java): matches() :892-910, containedIn() :1004-1022, indexForwards() :438-468,

@@ -1,5 +1,9 @@
-// Kernels beside the main scan: haystacks packed back to back -> fixed-stride rows, and the stripe path that gives
-// few, long rows intra-row parallelism.  gfx950 only.
+// Kernels beside the tiled scan (needle_kernels.hip), gfx950 only:
+//   unpack_kernel                      haystacks packed back to back -> the fixed-stride layout
+//   stripe_kernel / stripe_prefix_kernel / backward_row_kernel
+//                                      few, long rows: per-stripe transition functions composed across a row
+//                                      (intra-row parallelism for packed-mode automata)
+//   short_kernel                       rows of at most 64 bytes: register-resident, no LDS transposition
 #include "needle_walk.h"
 
 namespace needle {
