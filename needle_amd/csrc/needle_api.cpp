@@ -18,6 +18,8 @@
 namespace needle {
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
 bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows);
+hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, const int32_t *s, const int32_t *e, int32_t *cursor,
+                                   uint32_t *counts, int32_t *starts, int32_t *ends, int32_t *any_hit, int n_cus, hipStream_t stream);
 hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipStream_t stream);
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
@@ -751,6 +753,47 @@ int needle_find_next_dev(const needle_pattern *p, const needle_batch_view *v, co
                          int32_t *en, void *s) {
     if (!cur) return fail(NEEDLE_ERR_INVALID, "cursor is NULL");
     return run_dev(p, OP_FIND, v, bm, st, en, s, cur);
+}
+int needle_find_all_dev(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
+                        int32_t *d_end, int *more, void *stream_) {
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, true);
+    if (rc) return rc;
+    if (more) *more = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_counts || (slots && (!d_start || !d_end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t n = (size_t)v->n_rows, words = (n + 63) / 64;
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    uint8_t *tmp = nullptr; // cursor | start | end (int32 each) | bitmap | any-hit flag
+    const size_t o_cur = 0, o_s = n * 4, o_e = 2 * n * 4, o_bm = (3 * n * 4 + 15) & ~(size_t)15, o_flag = o_bm + words * 8;
+    HIP_TRY(hipMallocAsync((void **)&tmp, o_flag + 16, stream));
+    auto done = [&](int code) {
+        (void)hipFreeAsync(tmp, stream);
+        return code;
+    };
+    if (hipMemsetAsync(tmp + o_cur, 0, n * 4, stream) != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
+    for (uint32_t k = 0;; ++k) {
+        if (hipMemsetAsync(tmp + o_flag, 0, 4, stream) != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
+        rc = run_dev(p, OP_FIND, v, (uint64_t *)(tmp + o_bm), (int32_t *)(tmp + o_s), (int32_t *)(tmp + o_e), stream,
+                     (const int32_t *)(tmp + o_cur));
+        if (rc) return done(rc);
+        hipError_t e = launch_find_all_collect(n, slots, k, (const int32_t *)(tmp + o_s), (const int32_t *)(tmp + o_e),
+                                               (int32_t *)(tmp + o_cur), d_counts, d_start, d_end, (int32_t *)(tmp + o_flag), cus, stream);
+        if (e != hipSuccess) return done(hip_fail(e, "find_all_collect"));
+        int32_t any = 0;
+        e = hipMemcpyAsync(&any, tmp + o_flag, 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return done(hip_fail(e, "find_all round"));
+        if (!any) break;          // round k found nothing anywhere: every row is exhausted
+        if (k >= slots) {         // a match beyond the last slot exists
+            if (more) *more = 1;
+            break;
+        }
+    }
+    return done(NEEDLE_OK);
 }
 int needle_matches_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm) {
     return run_host(p, OP_MATCHES, v, bm, nullptr, nullptr);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         if (GUARD && OP == OP_FIND && a.from) {
             cursor = row_ok ? a.from[my_row] : -1;
             dead = cursor < 0; // find(): `if nextStart == -1 return false`, DFAClassBuilder.java:629-630
-            if (dead) cursor = 0;
+            if (dead) cursor = 0, st = 0; // parked in the sink: no lookups, and an all-exhausted wave leaves after one tile
         }
         last = -1; // OP_FIND: lastMatch of indexForwards
         // :356 literal 0, then the first loop iteration's wasAccepted check (:440) moves it to FROM if FROM < length

@@ -333,6 +333,42 @@ hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipS
 }
 
 // ------------------------------------------------------------------------------------------------
+// find-all bookkeeping (needle_find_all_dev): after round k of needle_find_next, file every row's match in its slot
+// k, count it, and move the row's cursor (Matcher.nextStart) -- an empty match ends its row, as does no match.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void find_all_collect_kernel(uint64_t n_rows, uint32_t slots, uint32_t k, const int32_t *s,
+                                                               const int32_t *e, int32_t *cursor, uint32_t *counts,
+                                                               int32_t *starts, int32_t *ends, int32_t *any_hit) {
+    bool hit_any = false;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        const int32_t en = e[r], st = s[r];
+        if (k == 0) counts[r] = 0;
+        if (en >= 0) {
+            if (k < slots) {
+                starts[r * slots + k] = st;
+                ends[r * slots + k] = en;
+                counts[r] = k + 1;
+            }
+            cursor[r] = (en == st) ? -1 : en;
+            hit_any = true;
+        } else {
+            cursor[r] = -1;
+        }
+    }
+    if (__ballot(hit_any) != 0ull && (threadIdx.x & 63) == 0) *any_hit = 1;
+}
+
+hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, const int32_t *s, const int32_t *e, int32_t *cursor,
+                                   uint32_t *counts, int32_t *starts, int32_t *ends, int32_t *any_hit, int n_cus, hipStream_t stream) {
+    uint64_t blocks = (n_rows + 255) / 256;
+    const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(find_all_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n_rows, slots, k, s, e, cursor, counts,
+                       starts, ends, any_hit);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Short rows (stride <= 64 bytes): no LDS transposition at all.  A row is at most four 16-byte pieces, so every lane
 // loads ITS OWN row straight into registers (64 lanes x 16 B at stride 16..64: whole lines per wave instruction) and
 // walks it there; the next group's loads are in flight meanwhile.  The tiled kernel spends a whole 128-byte tile
@@ -395,7 +431,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
             dead = cursor < 0; // find(): `if nextStart == -1 return false`, DFAClassBuilder.java:629-630
             if (dead) cursor = 0;
         }
-        uint32_t st = start_state;
+        uint32_t st = dead ? 0u : start_state; // exhausted rows park in the sink
         int32_t last = -1;
         if (OP == OP_FIND && a.hdr.root_accepting) last = ((uint32_t)cursor < len) ? cursor : 0; // :356, :440
         int32_t last_rel = -1;

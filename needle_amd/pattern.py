@@ -267,6 +267,28 @@ class Pattern:
                                           en.data_ptr(), s))
         return words, st, en
 
+    def find_all_dense(self, rows, max_per_row, lengths=None, stream=None):
+        """needle_find_all_dev: every non-overlapping match of every row in dense per-row slots.
+        -> (counts int32[n], start int32[n, max_per_row], end int32[n, max_per_row], more: bool)"""
+        import torch
+        L = _lib.lib()
+        assert isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dim() == 2 and rows.is_contiguous()
+        v = BatchView()
+        n, stride = rows.shape
+        v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.data_ptr(), rows.element_size(), n, stride, stride
+        if lengths is not None:
+            assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.shape == (n,)
+            v.lengths = lengths.data_ptr()
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            counts = torch.zeros(n, dtype=torch.int32, device=rows.device)
+            st = torch.full((n, max_per_row), -1, dtype=torch.int32, device=rows.device)
+            en = torch.full((n, max_per_row), -1, dtype=torch.int32, device=rows.device)
+            more = ctypes.c_int(0)
+            _check(L.needle_find_all_dev(self._h, ctypes.byref(v), int(max_per_row), counts.data_ptr(), st.data_ptr(),
+                                         en.data_ptr(), ctypes.byref(more), s))
+        return counts, st, en, bool(more.value)
+
     def find_all_batch(self, rows, lengths=None, max_rounds=None):
         """Every non-overlapping match of every row, as the reference's repeated find() would report them
         (DFACompilerTest.java:66-78,671-699): one launch per round over the rows that still have a cursor, results

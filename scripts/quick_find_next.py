@@ -17,3 +17,7 @@ for name, c in (("cursor=0", cur), ("cursor=r%200", cur2)):
 import time
 t0 = time.perf_counter(); off, s, e = p.find_all_batch(rows); torch.cuda.synchronize()
 print("find_all: %.1f ms, %d matches" % ((time.perf_counter() - t0) * 1e3, s.numel()))
+for slots in (1, 2, 4):
+    p.find_all_dense(rows, slots); torch.cuda.synchronize()
+    t0 = time.perf_counter(); counts, ds, de, more = p.find_all_dense(rows, slots); torch.cuda.synchronize()
+    print("find_all_dense slots=%d: %.2f ms, %d matches filed, more=%s" % (slots, (time.perf_counter() - t0) * 1e3, int(counts.sum()), more))

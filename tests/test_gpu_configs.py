@@ -226,6 +226,18 @@ def test_find_all_equals_repeated_reference_find(name, regex, ragged):
         assert got == want, (i, hs[i], got, want)
         total += len(want)
     assert total > len(hs) // 4
+    # the C ABI's own find-all (needle_find_all_dev: dense per-row slots): same matches; with too few slots it files the
+    # first ones and says that there were more
+    most = max(int(offsets[i + 1] - offsets[i]) for i in range(len(hs)))
+    for slots in (most, max(1, most - 1)):
+        counts, ds, de, more = p.find_all_dense(t, slots, tl)
+        counts, ds, de = counts.cpu().numpy(), ds.cpu().numpy(), de.cpu().numpy()
+        assert more == (slots < most)
+        for i in range(len(hs)):
+            k = int(offsets[i + 1] - offsets[i])
+            assert counts[i] == min(k, slots), i
+            assert ds[i, :counts[i]].tolist() == st[offsets[i]:offsets[i] + counts[i]].tolist(), i
+            assert de[i, :counts[i]].tolist() == en[offsets[i]:offsets[i] + counts[i]].tolist(), i
     if ragged:  # the reference's own second find()
         by_h = {h: i for i, h in enumerate(hs)}
         for v in doc["vectors"]:
