@@ -297,6 +297,16 @@ class Pattern:
         import torch
         n = rows.shape[0]
         dev = rows.device
+        if max_rounds is None:  # the library's own rounds, dense slots -> CSR; rows with very many matches: loop below
+            for slots in (4, 16, 64):
+                if n * slots > (1 << 31):
+                    break
+                counts, st, en, more = self.find_all_dense(rows, slots, lengths)
+                if not more:
+                    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+                    offsets[1:] = torch.cumsum(counts, 0)
+                    keep = torch.arange(slots, device=dev, dtype=torch.int32)[None, :] < counts[:, None]
+                    return offsets, st[keep], en[keep]
         cursor = torch.zeros(n, dtype=torch.int32, device=dev)
         ids = torch.arange(n, dtype=torch.int64, device=dev)
         counts = torch.zeros(n, dtype=torch.int64, device=dev)
