@@ -51,6 +51,10 @@ final class Native {
      */
     static native int packedHost(long handle, int op, char[] data, long[] offsets, long[] bitmap, int[] start, int[] end);
 
+    /** needle_find_all_host: counts int[nRows]; start / end int[nRows * maxPerRow]; more int[1]. */
+    static native int findAllHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
+                                  java.nio.ByteBuffer lengths, int maxPerRow, int[] counts, int[] start, int[] end, int[] more);
+
     // one Matcher (reference cursor semantics)
     static native int matcherCreate(long pattern, char[] s, long[] handleOut);
 

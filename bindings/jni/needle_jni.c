@@ -109,6 +109,22 @@ NATIVE(jint, findHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jl
     return bitmap_call(env, 2, h, &v, bitmap, start, end);
 }
 
+NATIVE(jint, findAllHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jint maxPerRow, jintArray counts, jintArray start, jintArray end, jintArray more) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    jint *cn = (*env)->GetIntArrayElements(env, counts, NULL);
+    jint *st = (*env)->GetIntArrayElements(env, start, NULL);
+    jint *en = (*env)->GetIntArrayElements(env, end, NULL);
+    int m = 0;
+    int rc = needle_find_all_host((const needle_pattern *)(intptr_t)h, &v, (uint32_t)maxPerRow, (uint32_t *)cn, (int32_t *)st, (int32_t *)en, &m);
+    jint jm = m;
+    (*env)->SetIntArrayRegion(env, more, 0, 1, &jm);
+    (*env)->ReleaseIntArrayElements(env, counts, cn, 0);
+    (*env)->ReleaseIntArrayElements(env, start, st, 0);
+    (*env)->ReleaseIntArrayElements(env, end, en, 0);
+    return rc;
+}
+
 NATIVE(jint, packedHost)(JNIEnv *env, jclass c, jlong h, jint op, jcharArray data, jlongArray offsets, jlongArray bitmap, jintArray start, jintArray end) {
     needle_packed_view v;
     memset(&v, 0, sizeof(v));

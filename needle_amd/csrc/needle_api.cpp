@@ -795,6 +795,49 @@ int needle_find_all_dev(const needle_pattern *p, const needle_batch_view *v, uin
     }
     return done(NEEDLE_OK);
 }
+int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
+                         int32_t *end, int *more) {
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, false);
+    if (rc) return rc;
+    if (more) *more = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!counts || (slots && (!start || !end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    const size_t cw = v->char_width, n = (size_t)v->n_rows;
+    const size_t src_stride = (size_t)v->row_stride * cw;
+    size_t dst_stride = (src_stride + 15) & ~(size_t)15;
+    if (dst_stride == 0) dst_stride = 16;
+    uint8_t *d = nullptr; // rows | lengths | counts | start | end
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_len = up16(n * dst_stride), o_cnt = o_len + up16(n * 4), o_s = o_cnt + up16(n * 4);
+    const size_t o_e = o_s + up16(n * slots * 4), total = o_e + up16(n * slots * 4);
+    HIP_TRY(hipMalloc((void **)&d, total));
+    auto done = [&](int code) {
+        (void)hipFree(d);
+        return code;
+    };
+    hipError_t e = hipSuccess;
+    if (dst_stride == src_stride) {
+        e = hipMemcpy(d, v->rows, n * src_stride, hipMemcpyHostToDevice);
+    } else {
+        e = hipMemset(d, 0, n * dst_stride);
+        if (e == hipSuccess && src_stride) e = hipMemcpy2D(d, dst_stride, v->rows, src_stride, src_stride, n, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && v->lengths) e = hipMemcpy(d + o_len, v->lengths, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && slots) e = hipMemset(d + o_s, 0xFF, total - o_s); // -1 in every slot
+    if (e != hipSuccess) return done(hip_fail(e, "find_all_host upload"));
+    needle_batch_view dv = *v;
+    dv.rows = d;
+    dv.lengths = v->lengths ? (const uint32_t *)(d + o_len) : nullptr;
+    dv.row_stride = dst_stride / cw;
+    rc = needle_find_all_dev(p, &dv, slots, (uint32_t *)(d + o_cnt), (int32_t *)(d + o_s), (int32_t *)(d + o_e), more, nullptr);
+    if (rc) return done(rc);
+    e = hipMemcpy(counts, d + o_cnt, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && slots) e = hipMemcpy(start, d + o_s, n * slots * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && slots) e = hipMemcpy(end, d + o_e, n * slots * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(hip_fail(e, "find_all_host download"));
+    return done(NEEDLE_OK);
+}
 int needle_matches_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm) {
     return run_host(p, OP_MATCHES, v, bm, nullptr, nullptr);
 }

@@ -270,8 +270,26 @@ class Pattern:
     def find_all_dense(self, rows, max_per_row, lengths=None, stream=None):
         """needle_find_all_dev: every non-overlapping match of every row in dense per-row slots.
         -> (counts int32[n], start int32[n, max_per_row], end int32[n, max_per_row], more: bool)"""
-        import torch
         L = _lib.lib()
+        if isinstance(rows, np.ndarray):  # host buffers: needle_find_all_host
+            rows = np.ascontiguousarray(rows)
+            if rows.dtype == np.int16:
+                rows = rows.view(np.uint16)
+            assert rows.ndim == 2 and rows.dtype in (np.uint8, np.uint16)
+            n, stride = rows.shape
+            v = BatchView()
+            v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.ctypes.data, rows.dtype.itemsize, n, stride, stride
+            if lengths is not None:
+                lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+                v.lengths = lengths.ctypes.data
+            counts = np.zeros(n, dtype=np.uint32)
+            st = np.full((n, max_per_row), -1, dtype=np.int32)
+            en = np.full((n, max_per_row), -1, dtype=np.int32)
+            more = ctypes.c_int(0)
+            _check(L.needle_find_all_host(self._h, ctypes.byref(v), int(max_per_row), counts.ctypes.data, st.ctypes.data,
+                                          en.ctypes.data, ctypes.byref(more)))
+            return counts, st, en, bool(more.value)
+        import torch
         assert isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dim() == 2 and rows.is_contiguous()
         v = BatchView()
         n, stride = rows.shape

@@ -232,12 +232,16 @@ def test_find_all_equals_repeated_reference_find(name, regex, ragged):
     for slots in (most, max(1, most - 1)):
         counts, ds, de, more = p.find_all_dense(t, slots, tl)
         counts, ds, de = counts.cpu().numpy(), ds.cpu().numpy(), de.cpu().numpy()
+        if slots == most:
+            counts_full, ds_full, de_full = counts, ds, de
         assert more == (slots < most)
         for i in range(len(hs)):
             k = int(offsets[i + 1] - offsets[i])
             assert counts[i] == min(k, slots), i
             assert ds[i, :counts[i]].tolist() == st[offsets[i]:offsets[i] + counts[i]].tolist(), i
             assert de[i, :counts[i]].tolist() == en[offsets[i]:offsets[i] + counts[i]].tolist(), i
+    hc, hs_, he, hmore = p.find_all_dense(rows, most, lens)  # numpy rows: needle_find_all_host
+    assert not hmore and (hc == counts_full).all() and (hs_ == ds_full).all() and (he == de_full).all()
     if ragged:  # the reference's own second find()
         by_h = {h: i for i, h in enumerate(hs)}
         for v in doc["vectors"]:
