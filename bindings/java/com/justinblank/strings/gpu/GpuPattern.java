@@ -68,6 +68,18 @@ public final class GpuPattern implements Pattern, AutoCloseable {
     }
 
     /**
+     * Every non-overlapping match of every row, as repeated {@code matcher.find()} calls would report them: up to
+     * {@code maxPerRow} per row.  counts[r] matches of row r are at start/end[r * maxPerRow + k].  Returns true when
+     * some row had more matches than slots.
+     */
+    public boolean findAllBatch(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen, ByteBuffer lengths,
+                                int maxPerRow, int[] counts, int[] start, int[] end) {
+        int[] more = new int[1];
+        check(Native.findAllHost(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, maxPerRow, counts, start, end, more), null);
+        return more[0] != 0;
+    }
+
+    /**
      * find() over an array of haystacks: the strings are flattened to one char buffer + offsets (no per-string
      * Matcher objects, SURVEY.md s8 a9) and cross the boundary once.  Returns the match bitmap.
      */
