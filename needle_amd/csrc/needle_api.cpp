@@ -105,6 +105,52 @@ static int check_view(const needle_batch_view *v, bool device) {
     return NEEDLE_OK;
 }
 
+// Few, long rows: one row per lane would leave the chip idle.  Packed-mode automata take the stripe path (function
+// composition across 4 KiB stripes, needle_stripe.hip); NEEDLE_LONG_ROWS=0 turns it off, =1 forces it (tests).
+static bool wants_stripe_path(const needle_batch_view *v, const ProgHeader &hdr, bool has_cursors) {
+    static const int force = getenv("NEEDLE_LONG_ROWS") ? atoi(getenv("NEEDLE_LONG_ROWS")) : -1;
+    const uint64_t stride_bytes = v->row_stride * v->char_width;
+    const bool wanted = force >= 0 ? force == 1 : (v->n_rows < 65536 && stride_bytes >= 8 * (uint64_t)kStripeBytes);
+    return wanted && hdr.mode == MODE_PACK && !has_cursors;
+}
+
+static int get_program(needle_pattern *p, int which, int cw, int variant, const DevProgram **out, int *n_cus);
+
+static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v, const DevProgram *fp, int n_cus,
+                           uint64_t *d_bitmap, int32_t *d_start, int32_t *d_end, void *stream) {
+    const uint64_t stride_bytes = v->row_stride * v->char_width;
+    StripeArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.rows = (const uint8_t *)v->rows;
+    sa.n_rows = v->n_rows;
+    sa.stride_bytes = stride_bytes;
+    sa.row_len = v->row_len;
+    sa.lengths = v->lengths;
+    sa.prog = fp->d_blob;
+    sa.hdr = fp->prog.hdr;
+    sa.spr = (uint32_t)((stride_bytes + kStripeBytes - 1) / kStripeBytes);
+    sa.bitmap = d_bitmap;
+    sa.start = d_start;
+    sa.end = d_end;
+    sa.fixed_len = -1;
+    sa.op = (uint32_t)op;
+    if (op == OP_FIND) {
+        sa.fixed_len = p->t.fixed_len;
+        if (sa.fixed_len < 0) {
+            const DevProgram *bp = nullptr;
+            int rc = get_program(p, W_BACKWARDS, (int)v->char_width, 1, &bp, nullptr);
+            if (rc) return rc;
+            sa.bprog = bp->d_blob;
+            sa.bhdr = bp->prog.hdr;
+        }
+    }
+    HIP_TRY(hipMallocAsync((void **)&sa.fn, (size_t)sa.n_rows * sa.spr * 4, (hipStream_t)stream));
+    hipError_t e = launch_long_rows((int)v->char_width, sa, n_cus, (hipStream_t)stream);
+    (void)hipFreeAsync(sa.fn, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "launch_long_rows");
+    return NEEDLE_OK;
+}
+
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
                    int32_t *d_end, void *stream, const int32_t *d_from = nullptr) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
@@ -121,44 +167,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     const bool need_backward = op == OP_FIND && p->t.fixed_len < 0;
     rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
-    // Few, long rows: one row per lane would leave the chip idle.  Packed-mode automata take the stripe path
-    // (function composition, needle_kernels.hip); NEEDLE_LONG_ROWS=0 turns it off, =1 forces it (tests).
-    {
-        static const int force = getenv("NEEDLE_LONG_ROWS") ? atoi(getenv("NEEDLE_LONG_ROWS")) : -1;
-        const uint64_t stride_bytes = v->row_stride * v->char_width;
-        const bool wanted = force >= 0 ? force == 1 : (v->n_rows < 65536 && stride_bytes >= 8 * (uint64_t)kStripeBytes);
-        if (wanted && fp->prog.hdr.mode == MODE_PACK && !d_from && (uint64_t)v->row_len <= v->row_stride) {
-            StripeArgs sa;
-            memset(&sa, 0, sizeof(sa));
-            sa.rows = (const uint8_t *)v->rows;
-            sa.n_rows = v->n_rows;
-            sa.stride_bytes = stride_bytes;
-            sa.row_len = v->row_len;
-            sa.lengths = v->lengths;
-            sa.prog = fp->d_blob;
-            sa.hdr = fp->prog.hdr;
-            sa.spr = (uint32_t)((stride_bytes + kStripeBytes - 1) / kStripeBytes);
-            sa.bitmap = d_bitmap;
-            sa.start = d_start;
-            sa.end = d_end;
-            sa.fixed_len = -1;
-            sa.op = (uint32_t)op;
-            if (op == OP_FIND) {
-                sa.fixed_len = p->t.fixed_len;
-                if (sa.fixed_len < 0) {
-                    rc = get_program(p, W_BACKWARDS, (int)v->char_width, 1, &bp, nullptr);
-                    if (rc) return rc;
-                    sa.bprog = bp->d_blob;
-                    sa.bhdr = bp->prog.hdr;
-                }
-            }
-            HIP_TRY(hipMallocAsync((void **)&sa.fn, (size_t)sa.n_rows * sa.spr * 4, (hipStream_t)stream));
-            hipError_t e = launch_long_rows((int)v->char_width, sa, n_cus, (hipStream_t)stream);
-            (void)hipFreeAsync(sa.fn, (hipStream_t)stream);
-            if (e != hipSuccess) return hip_fail(e, "launch_long_rows");
-            return NEEDLE_OK;
-        }
-    }
+    if (wants_stripe_path(v, fp->prog.hdr, d_from != nullptr)) return run_stripe_path(p, op, v, fp, n_cus, d_bitmap, d_start, d_end, stream);
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = (const uint8_t *)v->rows;
