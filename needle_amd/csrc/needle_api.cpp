@@ -168,10 +168,10 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
     if (wants_stripe_path(v, fp->prog.hdr, d_from != nullptr)) return run_stripe_path(p, op, v, fp, n_cus, d_bitmap, d_start, d_end, stream);
-    // the tiled kernel forms per-lane row offsets in 32 bits (rows-per-load x stride); only the stripe path above takes
-    // rows of hundreds of megabytes
-    if (v->row_stride * v->char_width >= (1ull << 28))
-        return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 256 MiB or more are supported for automata of at most 5 states only (stripe path)");
+    // the tiled kernel forms per-lane row offsets in 32 bits (up to 63 x stride); only the stripe path above takes
+    // rows of tens of megabytes and more
+    if (v->row_stride * v->char_width >= (1ull << 26))
+        return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more are supported for automata of at most 5 states only (stripe path)");
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = (const uint8_t *)v->rows;
