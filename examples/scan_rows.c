@@ -1,0 +1,80 @@
+/* A C host of libneedle_hip.so: compile a regex, put a small fixed-stride batch in HBM, run the three ops and
+ * find-all, print the results.
+ *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/scan_rows.c \
+ *       -Lneedle_amd -lneedle_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/needle_amd -o scan_rows
+ * (plain C: the HIP runtime is only used for hipMalloc / hipMemcpy). */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "needle_hip.h"
+
+#define ROWS 5
+#define STRIDE 32 /* bytes per row: a multiple of 16 */
+
+int main(void) {
+    static const char *text[ROWS] = {"order 66 shipped", "no digits here", "", "a1b22c333", "2024-01-31"};
+    const uint16_t regex[] = {'[', '0', '-', '9', ']', '+'};
+    char host[ROWS][STRIDE];
+    uint32_t lengths[ROWS], counts[ROWS];
+    uint64_t bitmap = 0;
+    int32_t start[ROWS], end[ROWS], all_s[ROWS * 4], all_e[ROWS * 4];
+    void *d_rows, *d_len, *d_bm, *d_s, *d_e, *d_cnt, *d_as, *d_ae;
+    needle_pattern *p = NULL;
+    needle_batch_view v;
+    int more = 0, r, k;
+
+    if (needle_device_count() < 1) {
+        printf("no HIP device\n");
+        return 2;
+    }
+    if (needle_compile(regex, 6, 0, &p) != NEEDLE_OK) {
+        printf("compile failed: %s\n", needle_last_error());
+        return 1;
+    }
+    memset(host, 0, sizeof(host));
+    for (r = 0; r < ROWS; ++r) {
+        lengths[r] = (uint32_t)strlen(text[r]);
+        memcpy(host[r], text[r], lengths[r]);
+    }
+    hipMalloc(&d_rows, sizeof(host));
+    hipMalloc(&d_len, sizeof(lengths));
+    hipMalloc(&d_bm, 8);
+    hipMalloc(&d_s, sizeof(start));
+    hipMalloc(&d_e, sizeof(end));
+    hipMalloc(&d_cnt, sizeof(counts));
+    hipMalloc(&d_as, sizeof(all_s));
+    hipMalloc(&d_ae, sizeof(all_e));
+    hipMemcpy(d_rows, host, sizeof(host), hipMemcpyHostToDevice);
+    hipMemcpy(d_len, lengths, sizeof(lengths), hipMemcpyHostToDevice);
+
+    memset(&v, 0, sizeof(v));
+    v.rows = d_rows;
+    v.char_width = 1;
+    v.n_rows = ROWS;
+    v.row_stride = STRIDE;
+    v.lengths = (const uint32_t *)d_len;
+
+    if (needle_contained_in_dev(p, &v, (uint64_t *)d_bm, NULL) != NEEDLE_OK ||
+        needle_find_dev(p, &v, (uint64_t *)d_bm, (int32_t *)d_s, (int32_t *)d_e, NULL) != NEEDLE_OK ||
+        needle_find_all_dev(p, &v, 4, (uint32_t *)d_cnt, (int32_t *)d_as, (int32_t *)d_ae, &more, NULL) != NEEDLE_OK) {
+        printf("scan failed: %s\n", needle_last_error());
+        return 1;
+    }
+    hipDeviceSynchronize();
+    hipMemcpy(&bitmap, d_bm, 8, hipMemcpyDeviceToHost);
+    hipMemcpy(start, d_s, sizeof(start), hipMemcpyDeviceToHost);
+    hipMemcpy(end, d_e, sizeof(end), hipMemcpyDeviceToHost);
+    hipMemcpy(counts, d_cnt, sizeof(counts), hipMemcpyDeviceToHost);
+    hipMemcpy(all_s, d_as, sizeof(all_s), hipMemcpyDeviceToHost);
+    hipMemcpy(all_e, d_ae, sizeof(all_e), hipMemcpyDeviceToHost);
+    for (r = 0; r < ROWS; ++r) {
+        printf("row %d \"%s\": found=%d first=(%d,%d) all=", r, text[r], (int)((bitmap >> r) & 1), start[r], end[r]);
+        for (k = 0; k < (int)counts[r]; ++k) printf("(%d,%d)", all_s[r * 4 + k], all_e[r * 4 + k]);
+        printf("\n");
+    }
+    printf("more=%d\n", more);
+    needle_pattern_destroy(p);
+    return 0;
+}
