@@ -21,6 +21,11 @@ bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb
 hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, const int32_t *s, const int32_t *e, int32_t *cursor,
                                    uint32_t *counts, int32_t *starts, int32_t *ends, int32_t *any_hit, int n_cus, hipStream_t stream);
 hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipStream_t stream);
+hipError_t launch_spec_len(const SpecArgs &a, hipStream_t stream);
+hipError_t launch_spec_init(const SpecArgs &a, hipStream_t stream);
+hipError_t launch_spec_fix(const SpecArgs &a, hipStream_t stream);
+hipError_t launch_spec_reduce(const SpecArgs &a, hipStream_t stream);
+hipError_t launch_backward_rows(int char_width, const StripeArgs &a, hipStream_t stream);
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
 } // namespace needle
@@ -53,7 +58,8 @@ struct needle_pattern {
     RefTables t;
     std::mutex mu;
     // (device, which, char_width, variant) -> program resident in that device's HBM
-    // variant: 0 plain, 1 global-walk layout (backward automaton of find), 2 forward + backward column maps
+    // variant: 0 plain, 1 global-walk layout (backward automaton of find), 2 forward + backward column maps,
+    //          3 HBM-table layout forced (column maps + uint16 table in one blob: the speculative-stripe fix-up walks it)
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
     ~needle_pattern() {
@@ -82,7 +88,7 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        dp.prog = lower(p->t, (Which)which, cw, max_prog_lds(), variant == 1, variant == 2);
+        dp.prog = lower(p->t, (Which)which, cw, variant == 3 ? 0 : max_prog_lds(), variant == 1, variant == 2);
         HIP_TRY(hipMalloc((void **)&dp.d_blob, dp.prog.blob.size()));
         HIP_TRY(hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice));
         it = p->cache.emplace(key, std::move(dp)).first;
@@ -152,7 +158,124 @@ static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v
 }
 
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
-                   int32_t *d_end, void *stream, const int32_t *d_from = nullptr) {
+                   int32_t *d_end, void *stream, const int32_t *d_from = nullptr, uint32_t *d_end_state = nullptr,
+                   bool no_backward = false);
+
+// Few, long rows of an automaton too big for function composition: speculative stripes (needle_stripe.hip).  Returns
+// NEEDLE_OK with *done = false when the path does not apply or did not reach its fixpoint (the caller then walks the
+// rows one lane each).
+static int run_speculative_stripes(needle_pattern *p, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
+                                   int32_t *d_end, void *stream_, bool *done) {
+    *done = false;
+    static const int force = getenv("NEEDLE_LONG_ROWS") ? atoi(getenv("NEEDLE_LONG_ROWS")) : -1;
+    const uint64_t stride_bytes = v->row_stride * v->char_width;
+    const bool wanted = force >= 0 ? force == 1 : (v->n_rows < 4096 && stride_bytes >= 64 * (uint64_t)kStripeBytes);
+    if (!wanted || op == OP_MATCHES) return NEEDLE_OK;
+    uint32_t stripe = kStripeBytes; // largest power of two <= 4 KiB that divides the row stride
+    while (stripe > 256 && stride_bytes % stripe) stripe >>= 1;
+    if (stride_bytes % stripe || stride_bytes / stripe < 2) return NEEDLE_OK;
+    const int which = op == OP_CONTAINED_IN ? W_CONTAINED_IN : W_FORWARDS;
+    if (p->t.dfa[which].accepting[0]) return NEEDLE_OK; // an accepting start state makes every stripe start look like a match
+    const DevProgram *gp = nullptr, *fp = nullptr, *bp = nullptr;
+    int n_cus = 0;
+    int rc = get_program(p, which, (int)v->char_width, 3, &gp, &n_cus); // HBM-table layout: column maps + uint16 table
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    SpecArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.rows = (const uint8_t *)v->rows;
+    sa.n_rows = v->n_rows;
+    sa.stride_bytes = stride_bytes;
+    sa.stripe_bytes = stripe;
+    sa.spr = (uint32_t)(stride_bytes / stripe);
+    sa.char_width = v->char_width;
+    sa.op = (uint32_t)op;
+    sa.row_len = v->row_len;
+    sa.lengths = v->lengths;
+    sa.gprog = gp->d_blob;
+    sa.hdr = gp->prog.hdr;
+    const size_t ns = (size_t)(sa.n_rows * sa.spr), words = (ns + 63) / 64;
+    // slen | spec_end_state | spec_last | spec_start(unused) | entry | entry_done | true_end_state | true_last  (4 B each), bitmap, flag
+    uint8_t *tmp = nullptr;
+    const size_t o_bm = 8 * ns * 4, o_flag = o_bm + words * 8, total = o_flag + 16;
+    HIP_TRY(hipMallocAsync((void **)&tmp, total, stream));
+    auto finish = [&](int code) {
+        (void)hipFreeAsync(tmp, stream);
+        return code;
+    };
+    uint32_t *u = (uint32_t *)tmp;
+    sa.slen = u;
+    uint32_t *spec_end_state = u + ns;
+    int32_t *spec_last = (int32_t *)(u + 2 * ns), *spec_start = (int32_t *)(u + 3 * ns);
+    sa.spec_end_state = spec_end_state;
+    sa.spec_last = spec_last;
+    sa.entry = u + 4 * ns;
+    sa.entry_done = u + 5 * ns;
+    sa.true_end_state = u + 6 * ns;
+    sa.true_last = (int32_t *)(u + 7 * ns);
+    sa.spec_bitmap = (const uint64_t *)(tmp + o_bm);
+    sa.changed = (int32_t *)(tmp + o_flag);
+    sa.bitmap = d_bitmap;
+    sa.end = d_end;
+    hipError_t e = launch_spec_len(sa, stream);
+    if (e != hipSuccess) return finish(hip_fail(e, "spec_len"));
+    // pass 1: every stripe as a row of its own, from the start state, through the tiled kernel
+    needle_batch_view sv;
+    memset(&sv, 0, sizeof(sv));
+    sv.rows = v->rows;
+    sv.char_width = v->char_width;
+    sv.n_rows = ns;
+    sv.row_stride = stripe / v->char_width;
+    sv.lengths = sa.slen;
+    rc = run_dev(p, op, &sv, (uint64_t *)(tmp + o_bm), spec_start, spec_last, stream_, nullptr, spec_end_state, true);
+    if (rc) return finish(rc);
+    e = launch_spec_init(sa, stream);
+    if (e != hipSuccess) return finish(hip_fail(e, "spec_init"));
+    bool fixed = false;
+    for (int round = 0; round < 48 && !fixed; ++round) {
+        if (hipMemsetAsync(sa.changed, 0, 4, stream) != hipSuccess) return finish(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
+        e = launch_spec_fix(sa, stream);
+        int32_t changed = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&changed, sa.changed, 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return finish(hip_fail(e, "spec_fix"));
+        fixed = changed == 0;
+    }
+    if (!fixed) return finish(NEEDLE_OK); // e.g. a DOTALL `.*` tail: every round settles one more stripe only
+    if (op != OP_FIND && hipMemsetAsync(d_bitmap, 0, ((sa.n_rows + 63) / 64) * 8, stream) != hipSuccess)
+        return finish(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
+    e = launch_spec_reduce(sa, stream);
+    if (e != hipSuccess) return finish(hip_fail(e, "spec_reduce"));
+    if (op == OP_FIND) { // matched bits + start: indexBackwards from lastMatch, one lane per row
+        rc = get_program(p, W_FORWARDS, (int)v->char_width, p->t.fixed_len < 0 ? 2 : 0, &fp, nullptr);
+        if (rc) return finish(rc);
+        StripeArgs ba;
+        memset(&ba, 0, sizeof(ba));
+        ba.rows = (const uint8_t *)v->rows;
+        ba.n_rows = v->n_rows;
+        ba.stride_bytes = stride_bytes;
+        ba.prog = fp->d_blob;
+        ba.hdr = fp->prog.hdr;
+        ba.bitmap = d_bitmap;
+        ba.start = d_start;
+        ba.end = d_end;
+        ba.fixed_len = p->t.fixed_len;
+        ba.op = OP_FIND;
+        if (ba.fixed_len < 0) {
+            rc = get_program(p, W_BACKWARDS, (int)v->char_width, 1, &bp, nullptr);
+            if (rc) return finish(rc);
+            ba.bprog = bp->d_blob;
+            ba.bhdr = bp->prog.hdr;
+        }
+        e = launch_backward_rows((int)v->char_width, ba, stream);
+        if (e != hipSuccess) return finish(hip_fail(e, "backward_rows"));
+    }
+    *done = true;
+    return finish(NEEDLE_OK);
+}
+
+static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
+                   int32_t *d_end, void *stream, const int32_t *d_from, uint32_t *d_end_state, bool no_backward) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
     int rc = check_view(v, true);
@@ -167,7 +290,12 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     const bool need_backward = op == OP_FIND && p->t.fixed_len < 0;
     rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
-    if (wants_stripe_path(v, fp->prog.hdr, d_from != nullptr)) return run_stripe_path(p, op, v, fp, n_cus, d_bitmap, d_start, d_end, stream);
+    if (!d_end_state && wants_stripe_path(v, fp->prog.hdr, d_from != nullptr)) return run_stripe_path(p, op, v, fp, n_cus, d_bitmap, d_start, d_end, stream);
+    if (!d_end_state && !d_from && fp->prog.hdr.mode != MODE_PACK) {
+        bool done = false;
+        rc = run_speculative_stripes(p, op, v, d_bitmap, d_start, d_end, stream, &done);
+        if (rc || done) return rc;
+    }
     // the tiled kernel forms per-lane row offsets in 32 bits (up to 63 x stride); only the stripe path above takes
     // rows of tens of megabytes and more
     if (v->row_stride * v->char_width >= (1ull << 26))
@@ -196,6 +324,8 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     a.bitmap = d_bitmap;
     a.start = d_start;
     a.end = d_end;
+    a.end_state = d_end_state;
+    if (no_backward && op == OP_FIND) a.fixed_len = 0, a.bprog = nullptr; // (speculative pass: only lastMatch is wanted)
     HIP_TRY(launch_scan(op, (int)v->char_width, a, n_cus, (hipStream_t)stream));
     return NEEDLE_OK;
 }

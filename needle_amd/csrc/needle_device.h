@@ -68,6 +68,37 @@ struct ScanArgs {
     uint64_t *bitmap;
     int32_t *start;
     int32_t *end;
+    uint32_t *end_state;    // optional: the automaton state (device id) in which every row's walk stopped
+};
+
+// Long rows of table-mode automata (needle_stripe.hip, "speculative stripes"): every stripe is first scanned as a row of
+// its own from the START state (the tiled kernel, all stripes in parallel); then each stripe whose true entry state
+// differs is re-walked next to the speculative run until the two states meet.
+struct SpecArgs {
+    const uint8_t *rows;
+    uint64_t n_rows;
+    uint64_t stride_bytes;   // of a row
+    uint32_t stripe_bytes;   // divides stride_bytes
+    uint32_t spr;            // stripes per row
+    uint32_t char_width;
+    uint32_t op;             // OP_CONTAINED_IN | OP_FIND
+    uint32_t row_len;
+    const uint32_t *lengths; // per row, or nullptr
+    const uint8_t *gprog;    // forward automaton in the HBM-table layout: column maps at the front, uint16 table at hdr.off_table
+    ProgHeader hdr;
+    // per stripe (n_rows * spr)
+    uint32_t *slen;          // chars of the stripe inside its row
+    const uint32_t *spec_end_state;
+    const int32_t *spec_last;    // find: lastMatch inside the stripe from the speculative run (-1 none)
+    const uint64_t *spec_bitmap; // containedIn: the speculative run accepted
+    uint32_t *entry;         // current guess of the true entry state
+    uint32_t *entry_done;    // entry state the stripe's results were last computed for (0xFFFFFFFF: never)
+    uint32_t *true_end_state;
+    int32_t *true_last;      // find: lastMatch inside the stripe (-1 none); containedIn: 1 accepted / -1 not
+    int32_t *changed;        // set when some stripe's successor got a new entry state
+    // per row
+    uint64_t *bitmap;
+    int32_t *end;
 };
 
 // Long rows: a row is cut into 4 KiB stripes (one wave-step each, 64 contiguous bytes per lane) and

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         else res = row_ok && (st >= accept_lo);
         const uint64_t word = __ballot(res);
         if (lane == 0) a.bitmap[grp] = word;
+        if (a.end_state && row_ok) a.end_state[my_row] = st / SCALE; // (speculative stripes: the state at the stripe's end)
         if (OP != OP_FIND) return;
         int32_t s = -1;
         const int32_t e = res ? last : -1;

@@ -285,6 +285,13 @@ __global__ __launch_bounds__(256) void backward_row_kernel(const StripeArgs a) {
     }
 }
 
+hipError_t launch_backward_rows(int char_width, const StripeArgs &a, hipStream_t stream) {
+    const unsigned pblocks = (unsigned)((a.n_rows + 255) / 256);
+    if (char_width == 1) hipLaunchKernelGGL(backward_row_kernel<1>, dim3(pblocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(backward_row_kernel<2>, dim3(pblocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <int CW, bool FIND, int NS>
 static hipError_t launch_stripe(const StripeArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     auto k = stripe_kernel<CW, FIND, NS>;
@@ -329,6 +336,179 @@ hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipS
         if (char_width == 1) hipLaunchKernelGGL(backward_row_kernel<1>, dim3(pblocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(backward_row_kernel<2>, dim3(pblocks), dim3(256), 0, stream, a);
     }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Speculative stripes: long rows of table-mode automata (SpecArgs, needle_device.h).
+//
+// Function composition (the stripe path above) needs the whole transition function in a register; an automaton of
+// hundreds of states has none.  Search automata forget, though: whatever state a stripe is entered in, after a few
+// chars the walk is in the same state as one that started from the start state.  So every stripe is first scanned
+// from the start state as a row of its own (the tiled kernel: all stripes in parallel, full speed), and then
+//   spec_init_kernel     stripe lengths; entry guess of stripe k + 1 = speculative end state of stripe k
+//   spec_fix_kernel      one lane per stripe whose entry guess is not the start state: walks the true run (from the
+//                        guess) and the speculative run side by side until their states meet -- from there on the
+//                        speculative results hold; before, the true run's do.  Hands its true end state to the next
+//                        stripe; a changed hand-over raises `changed` and the host runs another round (a fixpoint:
+//                        normally reached in two rounds; bounded, with the one-lane walk as the fallback).
+//   spec_reduce_kernel   per row: lastMatch = max over its stripes (stripes behind the automaton's death are entered in
+//                        the sink and accept nothing), verdict bits
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spec_len_kernel(SpecArgs a) {
+    const uint64_t total = a.n_rows * a.spr;
+    const uint32_t per = a.stripe_bytes / a.char_width; // chars per stripe
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = v / a.spr;
+        const uint32_t k = (uint32_t)(v - row * a.spr);
+        const uint32_t len = a.lengths ? a.lengths[row] : a.row_len;
+        const uint64_t first = (uint64_t)k * per;
+        a.slen[v] = first >= len ? 0u : (uint32_t)(len - first < per ? len - first : per);
+    }
+}
+
+__global__ __launch_bounds__(256) void spec_init_kernel(SpecArgs a) {
+    const uint64_t total = a.n_rows * a.spr;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)(v % a.spr);
+        a.entry[v] = k == 0 ? a.hdr.start : a.spec_end_state[v - 1];
+        a.entry_done[v] = 0xFFFFFFFFu;
+    }
+}
+
+template <int CW>
+__global__ __launch_bounds__(256) void spec_fix_kernel(SpecArgs a) {
+    const uint64_t total = a.n_rows * a.spr;
+    const uint8_t *cmap = a.gprog + (CW == 1 ? (uint32_t)kLdsCmap1 : 0u);
+    const uint8_t *ptab = a.gprog + kLdsPtab2, *pages = a.gprog + kLdsPages2Table;
+    const uint16_t *table = (const uint16_t *)(a.gprog + a.hdr.off_table);
+    const uint32_t n_cols = a.hdr.n_cols, start = a.hdr.start, accept_lo = a.hdr.accept_lo;
+    const bool find = a.op == OP_FIND;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t t = a.entry[v];
+        if (a.entry_done[v] == t) continue; // results are already those of this entry state
+        a.entry_done[v] = t;
+        const uint32_t k = (uint32_t)(v % a.spr);
+        const uint32_t n = a.slen[v];
+        uint32_t end_state;
+        int32_t last;
+        const int32_t spec_last = find ? a.spec_last[v] : (((a.spec_bitmap[v >> 6] >> (v & 63)) & 1) ? 1 : -1);
+        if (t == start || n == 0) { // the speculative run IS the true run (an empty stripe hands its entry state on)
+            end_state = n == 0 ? t : a.spec_end_state[v];
+            last = n == 0 ? -1 : spec_last;
+        } else if (find && t == 0) { // entered in the sink: nothing can happen any more
+            end_state = 0;
+            last = -1;
+        } else if (!find && t >= accept_lo) { // containedIn: already accepted (absorbing)
+            end_state = t;
+            last = 1;
+        } else {
+            const uint64_t row = v / a.spr;
+            const uint8_t *p = a.rows + row * a.stride_bytes + (uint64_t)k * a.stripe_bytes;
+            uint32_t qt = t, qs = start;
+            int32_t last_t = -1;
+            uint32_t i = 0;
+            bool met = false;
+            for (; i < n; ++i) {
+                const uint32_t c = CW == 1 ? p[i] : ((const uint16_t *)p)[i];
+                uint32_t col;
+                if (CW == 1) col = ((const uint16_t *)cmap)[c]; // HBM-table layout: cmap16 holds the plain column
+                else col = pages[(((uint32_t)((const uint16_t *)ptab)[c >> 8])) + (c & 255u)];
+                qt = table[qt * n_cols + col];
+                qs = table[qs * n_cols + col];
+                if (qt >= accept_lo) last_t = find ? (int32_t)(i + 1) : 1;
+                if (qt == qs) {
+                    met = true;
+                    ++i;
+                    break;
+                }
+                if (!find && qt >= accept_lo) break; // containedIn: decided
+            }
+            if (met) { // from char i on the two runs are one
+                end_state = a.spec_end_state[v];
+                if (find) last = spec_last > (int32_t)i ? spec_last : last_t;
+                // containedIn: accepting states are absorbing, so a speculative run that had accepted BEFORE the meeting
+                // point would have made the common state accepting (and last_t set): an accept it reports lies behind it
+                else last = (last_t > 0 || spec_last > 0) ? 1 : -1;
+            } else {
+                end_state = qt;
+                last = last_t;
+            }
+        }
+        a.true_end_state[v] = end_state;
+        a.true_last[v] = last;
+        // a stripe that ends in the sink (find) or in an accepting, absorbing state (containedIn) ends the row's story:
+        // nothing is handed on (the reduction stops at the first such stripe), so a death does not crawl through the
+        // rest of the row one stripe per round
+        const bool terminal = find ? end_state == 0u : end_state >= accept_lo;
+        if (!terminal && k + 1 < a.spr && a.entry[v + 1] != end_state) {
+            a.entry[v + 1] = end_state;
+            *a.changed = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void spec_reduce_kernel(SpecArgs a) {
+    __shared__ uint32_t first_terminal;
+    __shared__ int32_t best;
+    const uint32_t per = a.stripe_bytes / a.char_width;
+    const bool find = a.op == OP_FIND;
+    const uint32_t accept_lo = a.hdr.accept_lo;
+    for (uint64_t row = blockIdx.x; row < a.n_rows; row += gridDim.x) {
+        if (threadIdx.x == 0) first_terminal = a.spr - 1, best = -1;
+        __syncthreads();
+        // the first stripe in which the row's story ends (see spec_fix_kernel); stripes behind it were never settled
+        uint32_t d = a.spr - 1;
+        for (uint32_t k = threadIdx.x; k < a.spr; k += blockDim.x) {
+            const uint32_t e = a.true_end_state[row * a.spr + k];
+            if (find ? e == 0u : e >= accept_lo) {
+                d = k;
+                break;
+            }
+        }
+        atomicMin(&first_terminal, d);
+        __syncthreads();
+        d = first_terminal;
+        int32_t m = -1;
+        for (uint32_t k = threadIdx.x; k <= d; k += blockDim.x) {
+            const int32_t l = a.true_last[row * a.spr + k];
+            if (l >= 0) {
+                const int32_t pos = find ? (int32_t)(k * per) + l : 1;
+                m = pos > m ? pos : m;
+            }
+        }
+        atomicMax(&best, m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (find) a.end[row] = best;
+            else if (best >= 0) atomicOr((unsigned long long *)(a.bitmap + (row >> 6)), 1ull << (row & 63));
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_spec_len(const SpecArgs &a, hipStream_t stream) {
+    const uint64_t total = a.n_rows * a.spr;
+    hipLaunchKernelGGL(spec_len_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_init(const SpecArgs &a, hipStream_t stream) {
+    const uint64_t total = a.n_rows * a.spr;
+    hipLaunchKernelGGL(spec_init_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_fix(const SpecArgs &a, hipStream_t stream) {
+    const uint64_t total = a.n_rows * a.spr;
+    const dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096));
+    if (a.char_width == 1) hipLaunchKernelGGL(spec_fix_kernel<1>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(spec_fix_kernel<2>, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_reduce(const SpecArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(spec_reduce_kernel, dim3((unsigned)(a.n_rows < 4096 ? a.n_rows : 4096)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -75,8 +75,9 @@ def test_random_regexes_on_random_haystacks(seed):
         assert (unpack_bitmap(fw, 1000) == of).all() and (fs.cpu().numpy() == os_).all() and (fe.cpu().numpy() == oe).all(), (regex, flags, "short full")
         assert (unpack_bitmap(p.contained_in_batch(ts), 1000) == o.batch_contained_in(full_s, threads=4)).all(), (regex, flags, "short full")
         # few long rows (the stripe path when the automaton lowers to packed functions; one row per lane otherwise)
-        long_rows = nrng.choice([c for c in ALPHABET if c < 256], (3, 40_000)).astype(np.uint8)
-        long_lens = np.array([40_000, 33_333, 4096], dtype=np.uint32)
+        # (67 stripes of 4 KiB: long enough for the speculative-stripe path of the table-mode automata as well)
+        long_rows = nrng.choice([c for c in ALPHABET if c < 256], (3, 274_432)).astype(np.uint8)
+        long_lens = np.array([274_432, 200_001, 4096], dtype=np.uint32)
         tl = torch.from_numpy(long_rows).cuda()
         tll = torch.from_numpy(long_lens.astype(np.int32)).cuda()
         fw, fs, fe = p.find_batch(tl, tll)

@@ -111,3 +111,43 @@ np.save(sys.argv[1], np.concatenate([c, m, unpack_bitmap(fw, 3000), fs.cpu().num
         subprocess.check_call([sys.executable, "-c", code, path], cwd=root, env=env)
         out.append(np.load(path))
     assert (out[0] == out[1]).all()
+
+
+TABLE_CASES = [
+    # regex, char width, noise alphabet, planted strings
+    ("Sherlock|Holmes|Watson|Irene|Adler|John|Baker", 1, "abcdefgh SHWIAJB\n", ["Sherlock", "Holmes", "Baker", "Watso"]),
+    ("[a-zA-Z]+ing", 1, "abging .,\n", ["running", "ing", "xing "]),
+    ("http://.+", 1, "htp:/ wxyz\n", ["http://a.b/c", "http:/", "http://"]),
+    ("(foo|bar)[a-z]{3,5}baz", 1, "fobarz xy\n", ["fooabcbaz", "barxyzzzbaz", "foobaz"]),
+    ("Holmes.{1,10}Watson|Watson.{1,10}Holmes", 2, "HolmesWat \n", ["Holmes and Watson", "Watson, Holmes", "HolmesWatson"]),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regex,cw,noise,plants", TABLE_CASES)
+def test_long_rows_of_table_mode_automata_take_speculative_stripes(regex, cw, noise, plants):
+    """Automata too big for function composition: every 4 KiB stripe is scanned from the start state, then re-walked
+    from its true entry state until the two runs meet.  Bit-exact with the oracle's sequential walk -- matches that
+    straddle stripe boundaries, rows that die early, ragged lengths."""
+    p, o = compiled(regex)
+    assert p.info()["kernel_mode"]["forwards"] != 0
+    rng = np.random.default_rng(8)
+    dtype = np.uint8 if cw == 1 else np.uint16
+    n, stride = 6, 512 * 1024 // cw
+    noise_a = np.array([ord(ch) for ch in noise])
+    rows = rng.choice(noise_a, (n, stride)).astype(dtype)
+
+    def plant(r, at, s):
+        rows[r, at:at + len(s)] = [ord(ch) for ch in s]
+
+    per = 4096 // cw
+    plant(1, 300_000 // cw, plants[0])
+    plant(2, 7 * per - 3, plants[0])            # straddles a stripe boundary
+    plant(2, 9 * per - 1, plants[1])
+    plant(3, stride - len(plants[0]), plants[0])  # at the very end
+    for at in rng.integers(0, stride - 40, 300):
+        plant(4, int(at), plants[int(at) % len(plants)])
+    rows[5, :] = rng.choice(noise_a[:3], stride)  # row 5: a tiny alphabet (long partial matches)
+    check(p, o, rows, None)
+    lens = np.array([stride, 300_000 // cw + 3, 7 * per + 2, stride - 1, 9 * per, 0], dtype=np.int64)
+    check(p, o, rows, lens)
