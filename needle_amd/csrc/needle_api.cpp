@@ -170,12 +170,12 @@ static int run_speculative_stripes(needle_pattern *p, int op, const needle_batch
     static const int force = getenv("NEEDLE_LONG_ROWS") ? atoi(getenv("NEEDLE_LONG_ROWS")) : -1;
     const uint64_t stride_bytes = v->row_stride * v->char_width;
     const bool wanted = force >= 0 ? force == 1 : (v->n_rows < 4096 && stride_bytes >= 64 * (uint64_t)kStripeBytes);
-    if (!wanted || op == OP_MATCHES) return NEEDLE_OK;
+    if (!wanted) return NEEDLE_OK;
     uint32_t stripe = kStripeBytes; // largest power of two <= 4 KiB that divides the row stride
     while (stripe > 256 && stride_bytes % stripe) stripe >>= 1;
     if (stride_bytes % stripe || stride_bytes / stripe < 2) return NEEDLE_OK;
-    const int which = op == OP_CONTAINED_IN ? W_CONTAINED_IN : W_FORWARDS;
-    if (p->t.dfa[which].accepting[0]) return NEEDLE_OK; // an accepting start state makes every stripe start look like a match
+    const int which = op == OP_MATCHES ? W_MATCHES : op == OP_CONTAINED_IN ? W_CONTAINED_IN : W_FORWARDS;
+    if (op != OP_MATCHES && p->t.dfa[which].accepting[0]) return NEEDLE_OK; // an accepting start state makes every stripe start look like a match
     const DevProgram *gp = nullptr, *fp = nullptr, *bp = nullptr;
     int n_cus = 0;
     int rc = get_program(p, which, (int)v->char_width, 3, &gp, &n_cus); // HBM-table layout: column maps + uint16 table

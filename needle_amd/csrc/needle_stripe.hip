@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void spec_fix_kernel(SpecArgs a) {
     const uint8_t *ptab = a.gprog + kLdsPtab2, *pages = a.gprog + kLdsPages2Table;
     const uint16_t *table = (const uint16_t *)(a.gprog + a.hdr.off_table);
     const uint32_t n_cols = a.hdr.n_cols, start = a.hdr.start, accept_lo = a.hdr.accept_lo;
-    const bool find = a.op == OP_FIND;
+    const bool find = a.op != OP_CONTAINED_IN; // find and matches(): the sink is the absorbing state; containedIn: accepts are
+    const bool positions = a.op == OP_FIND;
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t t = a.entry[v];
         if (a.entry_done[v] == t) continue; // results are already those of this entry state
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void spec_fix_kernel(SpecArgs a) {
         const uint32_t n = a.slen[v];
         uint32_t end_state;
         int32_t last;
-        const int32_t spec_last = find ? a.spec_last[v] : (((a.spec_bitmap[v >> 6] >> (v & 63)) & 1) ? 1 : -1);
+        const int32_t spec_last = positions ? a.spec_last[v] : (a.op == OP_MATCHES ? -1 : (((a.spec_bitmap[v >> 6] >> (v & 63)) & 1) ? 1 : -1));
         if (t == start || n == 0) { // the speculative run IS the true run (an empty stripe hands its entry state on)
             end_state = n == 0 ? t : a.spec_end_state[v];
             last = n == 0 ? -1 : spec_last;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void spec_fix_kernel(SpecArgs a) {
                 else col = pages[(((uint32_t)((const uint16_t *)ptab)[c >> 8])) + (c & 255u)];
                 qt = table[qt * n_cols + col];
                 qs = table[qs * n_cols + col];
-                if (qt >= accept_lo) last_t = find ? (int32_t)(i + 1) : 1;
+                if (qt >= accept_lo) last_t = positions ? (int32_t)(i + 1) : 1;
                 if (qt == qs) {
                     met = true;
                     ++i;
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(256) void spec_fix_kernel(SpecArgs a) {
             }
             if (met) { // from char i on the two runs are one
                 end_state = a.spec_end_state[v];
-                if (find) last = spec_last > (int32_t)i ? spec_last : last_t;
+                if (positions) last = spec_last > (int32_t)i ? spec_last : last_t;
+                else if (a.op == OP_MATCHES) last = -1;
                 // containedIn: accepting states are absorbing, so a speculative run that had accepted BEFORE the meeting
                 // point would have made the common state accepting (and last_t set): an accept it reports lies behind it
                 else last = (last_t > 0 || spec_last > 0) ? 1 : -1;
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void spec_reduce_kernel(SpecArgs a) {
     __shared__ uint32_t first_terminal;
     __shared__ int32_t best;
     const uint32_t per = a.stripe_bytes / a.char_width;
-    const bool find = a.op == OP_FIND;
+    const bool find = a.op != OP_CONTAINED_IN; // (the sink ends the story; containedIn: an accept does)
     const uint32_t accept_lo = a.hdr.accept_lo;
     for (uint64_t row = blockIdx.x; row < a.n_rows; row += gridDim.x) {
         if (threadIdx.x == 0) first_terminal = a.spr - 1, best = -1;
@@ -473,15 +475,21 @@ __global__ __launch_bounds__(256) void spec_reduce_kernel(SpecArgs a) {
         for (uint32_t k = threadIdx.x; k <= d; k += blockDim.x) {
             const int32_t l = a.true_last[row * a.spr + k];
             if (l >= 0) {
-                const int32_t pos = find ? (int32_t)(k * per) + l : 1;
+                const int32_t pos = a.op == OP_FIND ? (int32_t)(k * per) + l : 1;
                 m = pos > m ? pos : m;
             }
         }
         atomicMax(&best, m);
         __syncthreads();
         if (threadIdx.x == 0) {
-            if (find) a.end[row] = best;
-            else if (best >= 0) atomicOr((unsigned long long *)(a.bitmap + (row >> 6)), 1ull << (row & 63));
+            if (a.op == OP_FIND) a.end[row] = best;
+            else if (a.op == OP_CONTAINED_IN) {
+                if (best >= 0) atomicOr((unsigned long long *)(a.bitmap + (row >> 6)), 1ull << (row & 63));
+            } else { // matches(): no stripe ended in the sink, and the state behind the last char is accepting
+                const uint32_t e_last = a.true_end_state[row * a.spr + a.spr - 1];
+                const bool died = a.true_end_state[row * a.spr + first_terminal] == 0u;
+                if (!died && e_last >= accept_lo) atomicOr((unsigned long long *)(a.bitmap + (row >> 6)), 1ull << (row & 63));
+            }
         }
         __syncthreads();
     }

@@ -151,3 +151,37 @@ def test_long_rows_of_table_mode_automata_take_speculative_stripes(regex, cw, no
     check(p, o, rows, None)
     lens = np.array([stride, 300_000 // cw + 3, 7 * per + 2, stride - 1, 9 * per, 0], dtype=np.int64)
     check(p, o, rows, lens)
+
+
+@pytest.mark.gpu
+def test_matches_on_long_rows_of_a_table_mode_automaton():
+    """matches() is no search: a stripe entered in the middle of the language is nowhere near the start state, and the
+    speculative run usually dies at once -- the fix-up then simply IS the true run of that stripe (stripe-parallel
+    all the same).  Whole-row matches of 512 KiB, a row spoilt by one char deep inside, ragged lengths."""
+    regex = "((ab|cd|ef|gh|ij|kl)+ )+"
+    p, o = compiled(regex)
+    assert p.info()["kernel_mode"]["matches"] != 0
+    rng = np.random.default_rng(21)
+    pairs = ["ab", "cd", "ef", "gh", "ij", "kl"]
+    n, stride = 5, 512 * 1024
+    rows = np.zeros((n, stride), dtype=np.uint8)
+    for r in range(n):
+        out = []
+        size = 0
+        while size < stride:
+            word = "".join(rng.choice(pairs, int(rng.integers(1, 5)))) + " "
+            out.append(word)
+            size += len(word)
+        text = "".join(out)[:stride]
+        rows[r] = np.frombuffer(text.encode("latin-1"), dtype=np.uint8)
+    lens = np.array([stride, stride, stride, 300_001, 0], dtype=np.int64)
+    for r in range(n):  # make every row end on a word boundary inside its length
+        end = int(lens[r])
+        while end > 0 and rows[r, end - 1] != 32:
+            end -= 1
+        lens[r] = end
+    rows[2, 222_222] = ord("z")  # spoilt
+    m, c, f, fs, fe = gpu_all(p, rows, lens)
+    want = o.batch_matches(rows, lens.astype(np.uint32), threads=4)
+    assert (m == want).all()
+    assert want.tolist() == [True, True, False, True, False]
