@@ -169,7 +169,10 @@ static int run_speculative_stripes(needle_pattern *p, int op, const needle_batch
     *done = false;
     static const int force = getenv("NEEDLE_LONG_ROWS") ? atoi(getenv("NEEDLE_LONG_ROWS")) : -1;
     const uint64_t stride_bytes = v->row_stride * v->char_width;
-    const bool wanted = force >= 0 ? force == 1 : (v->n_rows < 4096 && stride_bytes >= 64 * (uint64_t)kStripeBytes);
+    // measured (scripts/mid_rows_table_rate.py): containedIn gains up to 60 000 rows; find breaks even around 20 000;
+    // matches() usually dies in the first chars of a row, which only the lane path turns into an early exit
+    const uint64_t max_rows = op == OP_CONTAINED_IN ? 65536 : op == OP_FIND ? 8192 : 256;
+    const bool wanted = force >= 0 ? force == 1 : (v->n_rows < max_rows && stride_bytes >= 8 * (uint64_t)kStripeBytes);
     if (!wanted) return NEEDLE_OK;
     uint32_t stripe = kStripeBytes; // largest power of two <= 4 KiB that divides the row stride
     while (stripe > 256 && stride_bytes % stripe) stripe >>= 1;
