@@ -185,3 +185,23 @@ def test_matches_on_long_rows_of_a_table_mode_automaton():
     want = o.batch_matches(rows, lens.astype(np.uint32), threads=4)
     assert (m == want).all()
     assert want.tolist() == [True, True, False, True, False]
+
+
+@pytest.mark.gpu
+def test_an_automaton_that_never_resynchronises_falls_back_to_the_lane_walk():
+    """`q.*z` under DOTALL: once a `q` is seen the true run sits in a state no run started later in the row ever reaches,
+    so every fix-up round settles just one more stripe; after the bounded number of rounds the rows are walked one lane
+    each.  Same bits either way."""
+    from needle_amd.pattern import DOTALL
+    p, o = compiled("q.*z#[0-9a-f]{6}", DOTALL)
+    assert p.info()["kernel_mode"]["forwards"] != 0
+    rng = np.random.default_rng(4)
+    n, stride = 4, 512 * 1024
+    rows = rng.choice(np.array([ord(c) for c in "abcdefgh \n"]), (n, stride)).astype(np.uint8)
+    rows[0, 10] = ord("q")                                # q, then never a z: no match, 128 unsettled stripes
+    rows[1, 10] = ord("q")
+    rows[1, 400_000:400_008] = [ord(c) for c in "z#00ff00"]   # q ... z#00ff00 far away
+    rows[2, 300_000:300_008] = [ord(c) for c in "z#00ff00"]   # no q at all
+    rows[3, 7] = ord("q")
+    rows[3, 4096 * 3 - 2:4096 * 3 + 6] = [ord(c) for c in "z#abcdef"]  # straddles a stripe boundary
+    check(p, o, rows, None)
