@@ -268,7 +268,7 @@ def main():
     # MI355X_MICROARCH.md) committed under profiles/ for this exact workload and size; null if none was taken.
     if args.rows == 10_000_000:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % args.workload)), reverse=True):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s.json" % args.workload)), reverse=True):
             try:
                 prof = json.load(open(f))
                 out["roofline"]["traffic"] = prof["traffic_bytes_per_launch"]
