@@ -302,7 +302,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // the tiled kernel forms per-lane row offsets in 32 bits (up to 63 x stride); only the stripe path above takes
     // rows of tens of megabytes and more
     if (v->row_stride * v->char_width >= (1ull << 26))
-        return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more are supported for automata of at most 5 states only (stripe path)");
+        return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more are only supported on the stripe paths (automata of at most 5 states, or ones that re-synchronise; not with NEEDLE_LONG_ROWS=0, per-row cursors or empty-matching patterns)");
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = (const uint8_t *)v->rows;
