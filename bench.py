@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- the BASELINE.json metric on MI355X: GB/s of haystack scanned (+ rows/s) by the DFA table-walk
-hot path on the 10M x 256-char synthetic batch.
+"""bench.py -- the BASELINE.json metric on MI355X: GB/s of haystack scanned (+ rows/s, matches/s) by the DFA
+table-walk hot path on the 10M x 256-char synthetic batch.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--rows R] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c3s|c5] [--also c3,c3s,c5|none]
+                    [--rows R] [--scaling strong|weak] [--graph auto|off|scan]
 
-One "step" = one pass of the hot path over the whole device-resident batch (one kernel launch per GPU; for
-N > 1 followed by the RCCL gather of the result bitmap to rank 0).  N > 1 is launched by the driver with
-torch.distributed.run, one rank per GPU; rows are sharded by contiguous row blocks, no data-path collective
-other than the result gather.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over the whole device-resident batch: one kernel launch per GPU and, for
+N > 1, the gathers that bring the results to rank 0 (bitmap: one RCCL all-gather; find(): plus a fan-in of start /
+end to rank 0).  N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; the SAME 10M-row batch
+is sharded by contiguous row blocks (config C4: strong scaling; `--scaling weak` gives every GPU its own 10M rows
+instead); there is no data-path collective.  Rank 0 prints ONE JSON line.
 
-  value       whole-job algorithmic GB/s (input bytes + result bytes, per step, all GPUs) over
-              the barrier-bracketed wall time of exactly K steps (max over ranks), inputs resident in HBM
-  roofline    the scan kernel alone: algorithmic bytes per launch / mean launch duration from HIP events
-              recorded on the launch stream inside the timed region; peak = 8 TB/s HBM3E
+  headline    `--workload` (default c2: '[0-9]+' containedIn(), the configuration BASELINE.json's metric is quoted
+              on).  value = whole-job algorithmic GB/s (input bytes + result bytes, per step, all
+              GPUs) over the barrier-bracketed wall time of exactly K steps (max over ranks), inputs resident in HBM.
+  workloads   the other BASELINE configs measured the same way in the same run (`--also`): c3 (union of 1k keywords,
+              find), c3s (its sparse-match variant: keywords of 6..8 chars, only the planted 25 % of the rows match,
+              every lane stays live to the end of its row), c5 (BMP class regex over UTF-16, find).
+  roofline    the scan kernel alone: algorithmic bytes per launch / mean launch duration from HIP events recorded on
+              the launch stream inside the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline  the CPU oracle (oracle/needle_walk.c, a port of the reference's generated loops -- NOT the JVM
-              bytecode path: no JDK on the box) on a bounded sample of the same rows, all host cores
+              bytecode path: no JDK on the box) on a bounded sample of the same rows: all usable host cores, and one.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,16 +35,30 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 ENGINE_CLOCK_MHZ = 2400.0  # MI355X peak engine clock (same guide); chars/clk/CU is quoted against it
+KERNEL_SOURCES = ["needle_kernels.hip", "needle_stripe.hip", "needle_walk.h", "needle_device.h", "needle_lower.cpp"]
+
+
+def kernel_source_sha():
+    """Identity of the kernels a profile was taken with: sha256 over the device sources + the lowering."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "needle_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def make_pattern(workload):
     from needle_amd import workload as W
-    from needle_amd.pattern import DFACompiler, LEFTMOST_LONGEST  # noqa: F401
+    from needle_amd.pattern import DFACompiler
     if workload == "c2":
         return DFACompiler.compile("[0-9]+", "DigitPlus"), "'[0-9]+' containedIn()", None
     if workload == "c3":
         words = W.keywords(1000)
-        return DFACompiler.compile("|".join(words), "Keywords1k"), "union-of-1k-keywords find()", words
+        return DFACompiler.compile("|".join(words), "Keywords1k"), "union-of-1k-keywords (3..5 chars) find()", words
+    if workload == "c3s":
+        words = W.keywords(1000, min_len=6, max_len=8)
+        return (DFACompiler.compile("|".join(words), "Keywords1kSparse"),
+                "union-of-1k-keywords, sparse-match variant (6..8 chars: only the planted 25 % of the rows match) find()", words)
     if workload == "c5":
         return DFACompiler.compile(W.script_regex(), "ScriptRuns"), "BMP char-class regex find() over UTF-16", None
     raise SystemExit("unknown workload " + workload)
@@ -54,7 +75,7 @@ def make_rows(workload, words, row0, n_rows, device):
         n = min(slab, n_rows - s)
         if workload == "c2":
             out[s:s + n] = W.digits_batch(torch, row0 + s, n, 256, device=device)
-        elif workload == "c3":
+        elif workload in ("c3", "c3s"):
             out[s:s + n] = W.keyword_batch(torch, words, row0 + s, n, 256, device=device)
         else:
             out[s:s + n] = W.script_batch(torch, row0 + s, n, 256, device=device)
@@ -73,32 +94,41 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(workload, pattern, rows_dev, op_name, budget_s=12.0):
-    """Times the CPU oracle on a bounded sample of the same rows (rank 0, N = 1 only)."""
+def cpu_baseline(workload, pattern, rows_dev, op_name, budget_s):
+    """Times the CPU oracle on a bounded sample of the same rows (rank 0, N = 1 only): all usable cores (OpenMP static
+    over rows), then ONE core on a smaller sample (SURVEY.md s8d asks for both)."""
     import numpy as np
     from oracle.walker import Dfa, OraclePattern
     t = pattern.tables()
     d = {k: Dfa(t["class_map"], t["stride"], v["table"], v["accepting"], v["max_char"]) for k, v in t["dfas"].items()}
     o = OraclePattern(d["matches"], d["contained_in"], d["forwards"], d["backwards"], t["fixed_len"], -1)
     cores = usable_cores()
-    n = min(rows_dev.shape[0], 1 << 20)
-    host = rows_dev[:n].cpu().numpy()
-    if host.dtype == np.int16:
-        host = host.view(np.uint16)
     fn = {"contained_in": o.batch_contained_in, "find": o.batch_find, "matches": o.batch_matches}[op_name]
-    fn(host[:4096], threads=cores)
-    passes, t0 = 0, time.perf_counter()
-    while True:
-        fn(host, threads=cores)
-        passes += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or passes >= 64:
-            break
-    rows_s = passes * n / el
-    in_bytes = host.shape[1] * host.dtype.itemsize
-    return {"value": rows_s * in_bytes / 1e9, "unit": "GB/s", "rows_per_s": rows_s, "cores": cores, "kind": "port",
+
+    def timed(n, threads, budget):
+        host = rows_dev[:n].cpu().numpy()
+        if host.dtype == np.int16:
+            host = host.view(np.uint16)
+        fn(host[:4096], threads=threads)
+        passes, t0 = 0, time.perf_counter()
+        while True:
+            fn(host, threads=threads)
+            passes += 1
+            el = time.perf_counter() - t0
+            if el > budget or passes >= 64:
+                break
+        rows_s = passes * n / el
+        return rows_s, rows_s * host.shape[1] * host.dtype.itemsize / 1e9, passes
+
+    n_all = min(rows_dev.shape[0], 1 << 20)
+    rows_s, gbs, passes = timed(n_all, cores, budget_s * 0.7)
+    n_one = min(rows_dev.shape[0], 1 << 17)
+    rows_s1, gbs1, passes1 = timed(n_one, 1, budget_s * 0.3)
+    return {"value": gbs, "unit": "GB/s", "rows_per_s": rows_s, "cores": cores, "kind": "port",
             "sample": "%d passes over the first %d rows of the same batch (%s), OpenMP static over rows; "
-                      "CPU restatement of the generated loops, not the JVM bytecode path" % (passes, n, workload)}
+                      "CPU restatement of the generated loops, not the JVM bytecode path" % (passes, n_all, workload),
+            "single_core": {"value": gbs1, "unit": "GB/s", "rows_per_s": rows_s1, "cores": 1,
+                            "sample": "%d passes over the first %d rows" % (passes1, n_one)}}
 
 
 def measured_read_ceiling(buf):
@@ -149,81 +179,80 @@ def must_read_bytes(workload, pattern, rows, cw):
     return int(chars.sum().item()) * cw, exact
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
-    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (weak) or in total (strong)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--regex", default=None, help="tuning runs: another regex over the chosen workload's rows")
-    ap.add_argument("--op", default=None, choices=["matches", "contained_in", "find"], help="tuning runs: another op")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the read-ceiling probe and the must-read byte count")
-    args = ap.parse_args()
+class Ctx:
+    pass
 
+
+def measure(workload, args, ctx, headline):
+    """One workload, measured as the contract says: W warm-up steps, then exactly K steps bracketed by barrier +
+    synchronize on both sides, max over ranks.  -> the dict that becomes the JSON line (headline) or an entry of
+    "workloads"."""
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    use_dist = world > 1 or "RANK" in os.environ  # also under `torch.distributed.run --nproc-per-node 1`
-    if world > 1:
-        # the scan kernel is one persistent workgroup per CU that owns the CU's whole LDS; leave a few CUs free so
-        # that the RCCL kernel gathering the PREVIOUS step's bitmap can run next to it instead of behind it
-        os.environ.setdefault("NEEDLE_RESERVE_CUS", "4")
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from needle_amd.sharding import shard_range, gather_bitmap_async
-    pattern, what, words = make_pattern(args.workload)
-    if args.regex is not None:  # not a BASELINE config: labelled as such in config.workload
+    from needle_amd.sharding import ShardedScan, shard_range
+    from needle_amd.pattern import unpack_bitmap
+    dev, world, rank, use_dist = ctx.dev, ctx.world, ctx.rank, ctx.use_dist
+    pattern, what, words = make_pattern(workload)
+    if headline and args.regex is not None:  # not a BASELINE config: labelled as such in config.workload
         from needle_amd.pattern import DFACompiler
         pattern, what = DFACompiler.compile(args.regex, "Custom"), "CUSTOM regex %r %s()" % (args.regex, args.op or "default op")
     total_rows = args.rows * world if args.scaling == "weak" else args.rows
     row0, n_rows = shard_range(total_rows, world, rank)
-    rows = make_rows(args.workload, words, row0, n_rows, dev)
+    rows = make_rows(workload, words, row0, n_rows, dev)
     cw = rows.element_size()
-    op_name = args.op or ("contained_in" if args.workload == "c2" else "find")
+    op_name = (args.op if headline and args.op else None) or ("contained_in" if workload == "c2" else "find")
     op = {"contained_in": pattern.contained_in_batch, "find": pattern.find_batch, "matches": pattern.matches_batch}[op_name]
     is_find = op_name == "find"
 
-    def step():
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        res = op(rows)
-        ev1.record()
-        words_ = res[0] if is_find else res
-        if use_dist:  # async on RCCL's stream, ordered after the kernel: the next step's kernel overlaps with it
-            pending.append(gather_bitmap_async(words_, total_rows, world, rank))
-        return res, (ev0, ev1)
+    def scan(bitmap, start, end):
+        op(rows, out=(bitmap, start, end) if is_find else bitmap)
 
-    pending = []
+    sh = ShardedScan(scan, total_rows, world, rank, is_find, dev, n_buffers=2)
+    for _ in range(2):  # first launches: program upload, kernel attributes (never part of a captured graph)
+        sh.scan_only()
+    torch.cuda.synchronize()
+    # Small shards (8 GPUs: 1.25M rows, a ~55 us scan): the scan is launched as a HIP graph so that the per-step host
+    # cost is one graph launch instead of the library's argument marshalling + launch.
+    graphs = None
+    want_graph = args.graph == "scan" or (args.graph == "auto" and n_rows <= 4_000_000)
+    if want_graph and n_rows:
+        try:
+            graphs = []
+            for i in range(len(sh.sets)):
+                sh.k = i
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    sh.scan_only()
+                graphs.append(g)
+            sh.k = 0
+            sh.scan_only = lambda: (graphs[sh.k % len(graphs)].replay(), sh.sets[sh.k % len(sh.sets)])[1]
+        except Exception as e:  # noqa: BLE001 -- capture is an optimisation; the eager path is always valid
+            graphs = None
+            sys.stderr.write("graph capture failed (%s): eager launches\n" % e)
+            torch.cuda.synchronize()
+
+    def step():
+        # scan (bracketed by the two events) + the gathers, asynchronous on RCCL's stream and ordered after the kernel:
+        # the next step's scan overlaps them.  Without a process group the gathers are no-ops.
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        return sh.step(ev), ev
 
     def fence():
-        for h in pending:  # every step's bitmap has landed on every rank before the clock stops
-            h.wait()
-        del pending[:]
+        sh.drain()  # every step's results have landed (bitmap on every rank, start / end on rank 0)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        res, _ev = step()
+        last, _ev = step()
     fence()
     t0 = time.perf_counter()
     events = []
     for _ in range(args.steps):
-        res, ev = step()
+        last, ev = step()
         events.append(ev)
+    t_issue = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -236,74 +265,180 @@ def main():
     per_row = 256 * cw + (8 if is_find else 0)
     bytes_gpu = n_rows * per_row + ((n_rows + 63) // 64) * 8
     bytes_job = total_rows * per_row + ((total_rows + 63) // 64) * 8
-    ms_per_step = elapsed / args.steps * 1e3
-    matched = None
-    if rank == 0:
-        from needle_amd.pattern import unpack_bitmap
-        w0 = res[0] if is_find else res
-        matched = int(unpack_bitmap(w0, n_rows).sum())
+    step_s = elapsed / args.steps
+    matched = int(unpack_bitmap(last["bitmap"], n_rows).sum()) if n_rows else 0
+    if use_dist:
+        mt = torch.tensor([matched], dtype=torch.int64, device=dev)
+        dist.all_reduce(mt)
+        matched = int(mt.item())
+    props = torch.cuda.get_device_properties(dev)
+    inf = pattern.info()
+    which = {"contained_in": "contained_in", "find": "forwards", "matches": "matches"}[op_name]
+    mode_names = {0: "packed functions", 1: "LDS table u8", 2: "LDS table u16", 3: "HBM table", 4: "LDS pair table", 5: "LDS hot rows + HBM table"}
     out = {
-        "metric": "GB/s haystack scanned (10M x 256-char batch per GPU, DFA table walk)",
-        "value": bytes_job / (elapsed / args.steps) / 1e9,
+        "value": bytes_job / step_s / 1e9,
         "unit": "GB/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": args.scaling,
-        "vs_baseline": None,
+        "ms_per_step": step_s * 1e3,
+        "rows_per_s": total_rows / step_s,
+        "matches_per_s": matched / step_s,
+        "matched_fraction": matched / max(1, total_rows),
         "dtype": "u8" if cw == 1 else "u16",
-        "data": "synthetic",
-        "rows_per_s": total_rows / (elapsed / args.steps),
-        "matches_per_s": None if matched is None else matched * world / (elapsed / args.steps),
-        "config": {"workload": "%s: %s over %d x 256 %s rows per GPU" % (args.workload, what, n_rows, "UTF-16" if cw == 2 else "ASCII"),
-                   "rows_total": total_rows, "row_chars": 256, "char_bytes": cw, "parallelism": "row-shard x%d" % world,
-                   "result": "bitmap" + ("+start/end int32" if is_find else ""), "pattern": pattern.info()},
+        "config": {"workload": "%s: %s over %s%d x 256 %s rows%s" % (
+                       workload, what, "" if world == 1 else "the SAME " if args.scaling == "strong" else "per-GPU ",
+                       total_rows if args.scaling == "strong" else args.rows, "UTF-16" if cw == 2 else "ASCII",
+                       "" if world == 1 else (", row-sharded over %d GPUs (%d rows per GPU)" % (world, n_rows))),
+                   "rows_total": total_rows, "rows_per_gpu": n_rows, "row_chars": 256, "char_bytes": cw,
+                   "parallelism": "row-shard x%d" % world,
+                   "result": "bitmap" + ("+start/end int32" if is_find else ""),
+                   "automaton": {"states": inf["n_states"][which], "classes": inf["stride"],
+                                 "kernel_mode": mode_names.get(inf["kernel_mode"][which], str(inf["kernel_mode"][which]))},
+                   "launch": "HIP graph replay" if graphs else "eager"},
         "roofline": {"bound": "hbm", "achieved": bytes_gpu / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_gpu / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "needle::scan_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_gpu},
+                     "kernel": "needle::scan_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_gpu,
+                     "chars_per_clk_per_cu": n_rows * 256 / (kernel_ms * 1e-3) / (ENGINE_CLOCK_MHZ * 1e6) / props.multi_processor_count},
+        "host_issue_us_per_step": t_issue / args.steps * 1e6,
     }
     # HBM traffic per launch comes from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per
-    # MI355X_MICROARCH.md) committed under profiles/ for this exact workload and size; null if none was taken.
-    if args.rows == 10_000_000:
+    # MI355X_MICROARCH.md) committed under profiles/ for this workload at this size -- and only if that profile was
+    # taken with the kernels being benchmarked now (hash of the device sources); otherwise null.
+    if args.rows == 10_000_000 and world == 1:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s.json" % args.workload)), reverse=True):
+        sha = kernel_source_sha()
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s.json" % workload)), reverse=True):
             try:
                 prof = json.load(open(f))
-                out["roofline"]["traffic"] = prof["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
+                if prof.get("kernel_source_sha") == sha:
+                    out["roofline"]["traffic"] = prof["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
+                else:
+                    out["roofline"]["traffic_note"] = "newest profile (%s) was taken with other kernel sources: not quoted" % os.path.relpath(f, ROOT)
                 break
             except (OSError, KeyError, ValueError):
                 pass
-    props = torch.cuda.get_device_properties(dev)
-    clk_hz = ENGINE_CLOCK_MHZ * 1e6
-    out["roofline"]["chars_per_clk_per_cu"] = n_rows * 256 / (kernel_ms * 1e-3) / clk_hz / props.multi_processor_count
-    out["roofline"]["device"] = {"name": props.name, "cus": props.multi_processor_count, "clock_mhz_nominal": ENGINE_CLOCK_MHZ}
-    if rank == 0 and world == 1 and not args.no_extras:
+    if use_dist:
+        # scan and gather reported separately (each blocking, nothing overlapped) beside the step time
+        # in which the gathers ARE overlapped with the next step's scan
+        def blocking(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps * 1e3
+        out["scan_ms"] = blocking(lambda: sh.scan_only())
+        out["gather_ms"] = blocking(lambda: sh.wait(sh.step())) - out["scan_ms"]
+        out["step_ms"] = out["ms_per_step"]
+        out["gather"] = {"bitmap": "all_gather_into_tensor (RCCL), %d B per rank" % (sh.per_words * 8),
+                         "start_end": ("gather to rank 0 (RCCL send/recv fan-in), 2 x %d B per rank" % (sh.per_words * 64 * 4)) if is_find else None,
+                         "note": "gather_ms = blocking (scan + gathers) - blocking scan; inside the timed steps the gathers overlap the next scan"}
+    if headline and rank == 0 and world == 1 and not args.no_extras:
+        out["roofline"]["device"] = {"name": props.name, "cus": props.multi_processor_count, "clock_mhz_nominal": ENGINE_CLOCK_MHZ}
         ceil = measured_read_ceiling(rows)
         if ceil:
             out["roofline"]["measured_read_ceiling"] = ceil
             out["roofline"]["frac_of_measured_ceiling"] = out["roofline"]["achieved"] / ceil
-        mr, exact = must_read_bytes(args.workload if args.regex is None and args.op is None else "custom", pattern, rows, cw)
-        out["must_read"] = {"bytes_per_step": mr, "GB/s": mr / (elapsed / args.steps) / 1e9, "exact": exact,
+        mr, exact = must_read_bytes(workload if args.regex is None and args.op is None else "custom", pattern, rows, cw)
+        out["must_read"] = {"bytes_per_step": mr, "GB/s": mr / step_s / 1e9, "exact": exact,
                             "note": "chars the reference loop touches before it stops x bytes/char (SURVEY.md s8d secondary denominator)"}
-    if use_dist:
-        # the gather reported separately (blocking, nothing overlapped with it) beside the step time in
-        # which it IS overlapped with the next step's scan
-        from needle_amd.sharding import gather_bitmap
-        w0 = res[0] if is_find else res
-        gather_bitmap(w0, total_rows, world, rank)
+    if rank == 0 and world == 1 and not args.no_extras:
+        # SURVEY.md s8d "results landed in host-visible memory": the same steps with the bitmap (and find()'s start /
+        # end) copied to pinned host memory after every scan.  PCIe-bound for find (8 B per row); never the `value`.
+        hb = torch.empty(sh.per_words, dtype=torch.int64).pin_memory()
+        hs = torch.empty(n_rows, dtype=torch.int32).pin_memory() if is_find else None
+        he = torch.empty(n_rows, dtype=torch.int32).pin_memory() if is_find else None
+
+        def landed():
+            s = sh.scan_only()
+            hb.copy_(s["bitmap"], non_blocking=True)
+            if is_find:
+                hs.copy_(s["start"][:n_rows], non_blocking=True)
+                he.copy_(s["end"][:n_rows], non_blocking=True)
+        landed()
         torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        for _ in range(10):
-            gather_bitmap(w0, total_rows, world, rank)
+        k2 = max(3, args.steps // 4)
+        t = time.perf_counter()
+        for _ in range(k2):
+            landed()
         torch.cuda.synchronize()
-        out["gather"] = {"collective": "all_gather_into_tensor (RCCL)", "bytes_per_rank": int(w0.numel() * 8),
-                         "ms_blocking": (time.perf_counter() - g0) / 10 * 1e3,
-                         "note": "inside the timed steps it is issued asynchronously and overlaps with the next scan"}
+        dt = (time.perf_counter() - t) / k2
+        out["host_landed"] = {"ms_per_step": dt * 1e3, "GB/s": bytes_job / dt / 1e9, "d2h_bytes_per_step": sh.per_words * 8 + (8 * n_rows if is_find else 0),
+                              "note": "scan + D2H of the results into pinned host memory, every step"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, pattern, rows, op_name)
+        out["cpu_baseline"] = cpu_baseline(workload, pattern, rows, op_name, 10.0 if headline else 4.0)
+    del rows, sh, graphs
+    torch.cuda.empty_cache()
+    return out, total_rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c5"], help="the headline workload")
+    ap.add_argument("--also", default=None, help="comma list of further workloads measured into \"workloads\" "
+                    "(default: c3,c3s,c5 at 1 GPU, c3 at N > 1; 'none' for profiling runs)")
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
+    ap.add_argument("--graph", default="auto", choices=["auto", "off", "scan"], help="launch the scan as a HIP graph (auto: shards of <= 4M rows)")
+    ap.add_argument("--regex", default=None, help="tuning runs: another regex over the chosen workload's rows")
+    ap.add_argument("--op", default=None, choices=["matches", "contained_in", "find"], help="tuning runs: another op")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the read-ceiling probe, the must-read byte count and the host-landed figure")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    ctx = Ctx()
+    ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    ctx.dev = dev = torch.device("cuda", local)
+    ctx.use_dist = use_dist = world > 1 or "RANK" in os.environ  # also under `torch.distributed.run --nproc-per-node 1`
+    if world > 1:
+        # the scan kernel is one persistent workgroup per CU that owns the CU's whole LDS; leave a few CUs free so
+        # that the RCCL kernels gathering the PREVIOUS step's results can run next to it instead of behind it
+        os.environ.setdefault("NEEDLE_RESERVE_CUS", "4")
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.also is None:
+        also = ["c3", "c3s", "c5"] if world == 1 else ["c3"]
+        if args.regex or args.op or args.rows != 10_000_000:
+            also = []
+    else:
+        also = [w for w in args.also.split(",") if w and w != "none"]
+    also = [w for w in also if w != args.workload]
+
+    head, total_rows = measure(args.workload, args, ctx, True)
+    out = {
+        "metric": "GB/s haystack scanned (10M x 256-char batch, DFA table walk)",
+        "value": head.pop("value"),
+        "unit": head.pop("unit"),
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": head.pop("ms_per_step"),
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": head.pop("dtype"),
+        "data": "synthetic",
+    }
+    out.update(head)
+    out["kernel_source_sha"] = kernel_source_sha()
+    if also:
+        out["workloads"] = {}
+        for w in also:
+            r, _ = measure(w, args, ctx, False)
+            out["workloads"][w] = r
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

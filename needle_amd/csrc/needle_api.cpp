@@ -90,7 +90,10 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
         DevProgram dp;
         dp.prog = lower(p->t, (Which)which, cw, variant == 3 ? 0 : max_prog_lds(), variant == 1, variant == 2);
         HIP_TRY(hipMalloc((void **)&dp.d_blob, dp.prog.blob.size()));
-        HIP_TRY(hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice));
+        if (hipError_t ce = hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice); ce != hipSuccess) {
+            (void)hipFree(dp.d_blob);
+            return hip_fail(ce, "hipMemcpy(program blob)");
+        }
         it = p->cache.emplace(key, std::move(dp)).first;
     }
     *out = &it->second;
@@ -108,6 +111,15 @@ static int check_view(const needle_batch_view *v, bool device) {
         if (((uintptr_t)v->rows) % 16 != 0) return fail(NEEDLE_ERR_INVALID, "rows must be 16-byte aligned");
         if (v->n_rows && v->row_stride == 0) return fail(NEEDLE_ERR_INVALID, "row_stride is 0");
     }
+    return NEEDLE_OK;
+}
+
+// Host batches: per-row lengths are readable here, so an oversized one is an argument error, not an out-of-bounds
+// read on the device (the kernels derive their chunk counts from the lengths and trust len <= row_stride).
+static int check_host_lengths(const needle_batch_view *v) {
+    if (!v->lengths) return NEEDLE_OK;
+    for (uint64_t r = 0; r < v->n_rows; ++r)
+        if (v->lengths[r] > v->row_stride) return fail(NEEDLE_ERR_INVALID, "lengths[r] > row_stride");
     return NEEDLE_OK;
 }
 
@@ -328,7 +340,8 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     a.start = d_start;
     a.end = d_end;
     a.end_state = d_end_state;
-    if (no_backward && op == OP_FIND) a.fixed_len = 0, a.bprog = nullptr; // (speculative pass: only lastMatch is wanted)
+    static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr; // measurement aid: start = end
+    if ((no_backward || dbg_no_backward) && op == OP_FIND) a.fixed_len = 0, a.bprog = nullptr; // (speculative pass: only lastMatch is wanted)
     HIP_TRY(launch_scan(op, (int)v->char_width, a, n_cus, (hipStream_t)stream));
     return NEEDLE_OK;
 }
@@ -432,6 +445,7 @@ static int run_host(const needle_pattern *p, int op, const needle_batch_view *v,
                     int32_t *end) {
     int rc = check_view(v, false);
     if (rc) return rc;
+    if ((rc = check_host_lengths(v))) return rc;
     static const uint64_t kHostChunkBytes = getenv("NEEDLE_HOST_CHUNK_BYTES") ? (uint64_t)atoll(getenv("NEEDLE_HOST_CHUNK_BYTES")) : (2ull << 30);
     const uint64_t row_bytes = std::max<uint64_t>(16, (v->row_stride * v->char_width + 15) & ~(uint64_t)15);
     uint64_t per = std::max<uint64_t>(64, (kHostChunkBytes / row_bytes) & ~(uint64_t)63);
@@ -548,6 +562,7 @@ static int run_packed_host(const needle_pattern *p, int op, const needle_packed_
         if (v->offsets[r + 1] < v->offsets[r]) return fail(NEEDLE_ERR_INVALID, "offsets must be non-decreasing");
         max_len = std::max<uint64_t>(max_len, v->offsets[r + 1] - v->offsets[r]);
     }
+    if (v->offsets[n] && !v->data) return fail(NEEDLE_ERR_INVALID, "data is NULL");
     const uint64_t total_bytes = v->offsets[n] * cw;
     const uint64_t padded = n * std::max<uint64_t>(16, (max_len * cw + 15) & ~(uint64_t)15);
     if (padded <= 4 * total_bytes + (64u << 10)) return run_packed_host_one(p, op, v, bitmap, start, end);

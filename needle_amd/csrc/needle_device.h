@@ -126,14 +126,16 @@ struct StripeArgs {
 
 // Fixed LDS byte offsets of the forward automaton (compile-time so that they fold into ds_read immediates).
 //   char_width 1:  packed: F[256][64] u32 at 0 (one copy per lane) table modes: cmap16[256] at 0, table at 512
-//   char_width 2:  ptab16[256] at 0 (page * 256);  packed: F[64] u32 at 512, pages8 (col * 4) at 768
-//                                                  table modes: pages8 (col * elem) at 512, table at hdr.off_table
+//   char_width 2:  packed: ptab32[256] at 0 (page * 1024), pagesF u32 [n_pages][256] at 1024 -- every page entry IS
+//                          the transition function F of its char: two dependent lookups per char, not three
+//                  table modes: ptab16[256] at 0 (page * 256), pages8 (col * elem) at 512, table at hdr.off_table
 constexpr uint32_t kLdsF1 = 0, kLdsCmap1 = 0, kLdsTable1 = 512;
 //                  pair mode: cmapA16[256] at 0 (col * n_cols * 2: first char of a pair), cmapB16[256] at 512 (col * 2)
 constexpr uint32_t kLdsCmapB1 = 512, kLdsPairTable1 = 1024;
-constexpr uint32_t kLdsPtab2 = 0, kLdsF2 = 512;
-// pages base differs by mode; the kernel selects with kLdsPages2 below through the MODE it is instantiated for
-constexpr uint32_t kLdsPages2Pack = 768, kLdsPages2Table = 512;
+constexpr uint32_t kLdsPtab2 = 0;
+constexpr uint32_t kLdsPagesF2 = 1024, kLdsPages2Table = 512;
+// packed mode on UTF-16 rows needs ptab32 + one KiB per distinct page in LDS next to the tiles
+constexpr uint32_t kMaxPackPagesBytes = 96u * 1024u;
 
 constexpr int kWavesPerBlock = 16;     // 1024 threads: one workgroup per CU shares one LDS copy of the tables
 // Largest automaton footprint that still leaves room for the smallest workgroup shape (4 waves x 64 rows x 64 B).

@@ -165,7 +165,10 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     }
 
     Mode mode;
-    if (n_dev <= 6 && (char_width == 1 || n_cols <= 64)) mode = MODE_PACK;
+    // packed functions on UTF-16 rows: the pages hold F itself (u32 per code unit of every DISTINCT page), which has
+    // to fit the LDS next to the tiles; automata over very many distinct pages take the table modes
+    const size_t pack2_bytes = kLdsPagesF2 + cm.pages.size() * 4;
+    if (n_dev <= 6 && (char_width == 1 || (pack2_bytes <= kMaxPackPagesBytes && pack2_bytes <= lds_table_budget))) mode = MODE_PACK;
     else if (n_dev <= 256) mode = MODE_TABLE8;
     else mode = MODE_TABLE16;
 
@@ -207,10 +210,9 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             for (int c = 0; c < 256; ++c)
                 for (int l = 0; l < 64; ++l) put32(kLdsF1 + 256 * c + 4 * l, pack(cm.cmap8[c]));
         } else {
-            p.blob.assign(kLdsPages2Pack + cm.pages.size(), 0);
-            for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
-            for (int k = 0; k < n_cols; ++k) put32(kLdsF2 + 4 * k, pack(k));
-            for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Pack + i] = (uint8_t)(cm.pages[i] * 4);
+            p.blob.assign(pack2_bytes, 0);
+            for (int hi = 0; hi < 256; ++hi) put32(kLdsPtab2 + 4 * hi, (uint32_t)cm.ptab[hi] * 1024u);
+            for (size_t i = 0; i < cm.pages.size(); ++i) put32(kLdsPagesF2 + 4 * i, pack(cm.pages[i]));
         }
         emit_backward_maps();
         p.hdr.lds_bytes = (uint32_t)p.blob.size();

@@ -530,14 +530,20 @@ __global__ __launch_bounds__(256) void find_all_collect_kernel(uint64_t n_rows, 
     bool hit_any = false;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
         const int32_t en = e[r], st = s[r];
+        const int32_t from = cursor[r]; // the cursor this round searched from (< 0: the row was exhausted already)
         if (k == 0) counts[r] = 0;
-        if (en >= 0) {
+        // en < st: a nullable pattern searched from cursor == length reports end = the literal 0 of
+        // DFAClassBuilder.java:356 with start = length; the reference's repeated find() would cycle for ever there.
+        // That wrapped pseudo-match is dropped and ends the row.
+        if (from >= 0 && en >= 0 && en >= st) {
             if (k < slots) {
                 starts[r * slots + k] = st;
                 ends[r * slots + k] = en;
                 counts[r] = k + 1;
             }
-            cursor[r] = (en == st) ? -1 : en;
+            // the row goes on only while the cursor advances (an empty match, or any match that does not end beyond
+            // the cursor it was searched from, is filed once and ends it)
+            cursor[r] = (en == st || en <= from) ? -1 : en;
             hit_any = true;
         } else {
             cursor[r] = -1;

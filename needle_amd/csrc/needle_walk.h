@@ -146,9 +146,13 @@ __device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_r
         else if (MODE == MODE_PAIR) col = lds_u16(shl_byte<K>(w, 1) + ((K & 1) ? kLdsCmapB1 : kLdsCmap1)); // first | second char of a pair
         else col = lds_u16(shl_byte<K>(w, 1) + kLdsCmap1);
     } else {
-        const uint32_t pg = lds_u16(shl_byte<(2 * K + 1) & 3>(w, 1) + kLdsPtab2);  // page base = page * 256
-        const uint32_t ce = lds_u8(or_byte<(2 * K) & 3>(pg, w) + (MODE == MODE_PACK ? kLdsPages2Pack : kLdsPages2Table));
-        col = (MODE == MODE_PACK) ? lds_u32(ce + kLdsF2) : ce; // pages hold column * 4 (packed) | * element size
+        if (MODE == MODE_PACK) { // ptab32[high byte] = page * 1024; pagesF[page][low byte] = F of the char
+            const uint32_t pg = lds_u32(shl_byte<(2 * K + 1) & 3>(w, 2) + kLdsPtab2);
+            col = lds_u32(pg + shl_byte<(2 * K) & 3>(w, 2) + kLdsPagesF2);
+        } else {
+            const uint32_t pg = lds_u16(shl_byte<(2 * K + 1) & 3>(w, 1) + kLdsPtab2);  // page base = page * 256
+            col = lds_u8(or_byte<(2 * K) & 3>(pg, w) + kLdsPages2Table);                // pages hold column * element size
+        }
     }
     if (GUARD) {
         col = in_row ? col : ((MODE == MODE_PAIR && (K & 1)) ? wk.pad_b : wk.pad_e);
@@ -183,35 +187,57 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
     // all state-independent lookups of the piece first (they pipeline in the LDS) ...
     uint32_t col[CPP];
     if (CW == 2) {
-        // UTF-16: three dependent lookups per char (page table -> page -> F).  Issued as three batches of 8
-        // with ONE wait between batches: left to the scheduler they come out as ~14 short waits per piece,
-        // each exposing a full LDS round trip.
-        constexpr uint32_t kPages = (MODE == MODE_PACK) ? kLdsPages2Pack : kLdsPages2Table;
-        uint32_t pg[CPP], ce[CPP];
+        // UTF-16: dependent lookups per char -- page table -> page entry, which in packed mode IS the char's transition
+        // function (two lookups), in the table modes its column (the table lookup follows on the state chain).  Issued
+        // as batches of 8 with ONE wait between batches: left to the scheduler they come out as ~14 short waits per
+        // piece, each exposing a full LDS round trip.
+        uint32_t pg[CPP];
+        if (MODE == MODE_PACK) {
+            uint32_t lo4[CPP];
+#define NEEDLE_PG(D, K)                                                                              \
+    pg[(D) * 2 + (K)] = lds_u32(shl_byte<(2 * (K) + 1) & 3>(w[D], 2) + kLdsPtab2);                   \
+    lo4[(D) * 2 + (K)] = shl_byte<(2 * (K)) & 3>(w[D], 2);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                NEEDLE_PG(d, 0)
+                NEEDLE_PG(d, 1)
+            }
+#undef NEEDLE_PG
+            lds_fence();
+#pragma unroll
+            for (int i = 0; i < CPP; ++i) {
+                uint32_t c = lds_u32(pg[i] + lo4[i] + kLdsPagesF2);
+                if (GUARD) {
+                    c = (p0 + i < rem) ? c : wk.pad_e;
+                    c = (p0 + i < skip) ? wk.pre_e : c;
+                }
+                col[i] = c;
+            }
+        } else {
 #define NEEDLE_PG(D, K) pg[(D) * 2 + (K)] = lds_u16(shl_byte<(2 * (K) + 1) & 3>(w[D], 1) + kLdsPtab2);
-#define NEEDLE_CE(D, K) ce[(D) * 2 + (K)] = lds_u8(or_byte<(2 * (K)) & 3>(pg[(D) * 2 + (K)], w[D]) + kPages);
+#define NEEDLE_CE(D, K) col[(D) * 2 + (K)] = lds_u8(or_byte<(2 * (K)) & 3>(pg[(D) * 2 + (K)], w[D]) + kLdsPages2Table);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            NEEDLE_PG(d, 0)
-            NEEDLE_PG(d, 1)
-        }
-        lds_fence();
+            for (int d = 0; d < 4; ++d) {
+                NEEDLE_PG(d, 0)
+                NEEDLE_PG(d, 1)
+            }
+            lds_fence();
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            NEEDLE_CE(d, 0)
-            NEEDLE_CE(d, 1)
-        }
-        lds_fence();
+            for (int d = 0; d < 4; ++d) {
+                NEEDLE_CE(d, 0)
+                NEEDLE_CE(d, 1)
+            }
 #undef NEEDLE_PG
 #undef NEEDLE_CE
-#pragma unroll
-        for (int i = 0; i < CPP; ++i) {
-            uint32_t c = (MODE == MODE_PACK) ? lds_u32(ce[i] + kLdsF2) : ce[i]; // pages hold column * 4 | * element size
             if (GUARD) {
-                c = (p0 + i < rem) ? c : wk.pad_e;
-                c = (p0 + i < skip) ? wk.pre_e : c;
+#pragma unroll
+                for (int i = 0; i < CPP; ++i) {
+                    uint32_t c = col[i];
+                    c = (p0 + i < rem) ? c : wk.pad_e;
+                    c = (p0 + i < skip) ? wk.pre_e : c;
+                    col[i] = c;
+                }
             }
-            col[i] = c;
         }
     } else {
 #define NEEDLE_LOOKUP(D, K)                                                                         \

@@ -194,7 +194,7 @@ class Pattern:
         return out
 
     # ---- batches
-    def _run(self, op, rows, lengths, stream):
+    def _run(self, op, rows, lengths, stream, out=None):
         L = _lib.lib()
         v = BatchView()
         if isinstance(rows, np.ndarray):  # host buffers: upload + run + download inside the library
@@ -228,22 +228,31 @@ class Pattern:
             v.lengths = lengths.data_ptr()
         with torch.cuda.device(rows.device):
             s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
-            words = torch.empty((n + 63) // 64, dtype=torch.int64, device=rows.device)
+            if out is not None:  # caller-owned result buffers (at least as large as the results): no allocation per call
+                words = out[0] if isinstance(out, (tuple, list)) else out
+                assert words.is_cuda and words.dtype == torch.int64 and words.numel() >= (n + 63) // 64
+            else:
+                words = torch.empty((n + 63) // 64, dtype=torch.int64, device=rows.device)
             if op == "find":
-                st = torch.empty(n, dtype=torch.int32, device=rows.device)
-                en = torch.empty(n, dtype=torch.int32, device=rows.device)
+                if out is not None:
+                    st, en = out[1], out[2]
+                    assert st.dtype == torch.int32 and en.dtype == torch.int32 and st.numel() >= n and en.numel() >= n
+                else:
+                    st = torch.empty(n, dtype=torch.int32, device=rows.device)
+                    en = torch.empty(n, dtype=torch.int32, device=rows.device)
                 _check(L.needle_find_dev(self._h, ctypes.byref(v), words.data_ptr(), st.data_ptr(), en.data_ptr(), s))
                 return words, st, en
             fn = L.needle_matches_dev if op == "matches" else L.needle_contained_in_dev
             _check(fn(self._h, ctypes.byref(v), words.data_ptr(), s))
             return words
 
-    def matches_batch(self, rows, lengths=None, stream=None):
-        """bitmap words (bit r&63 of word r>>6 = matches() of row r)."""
-        return self._run("matches", rows, lengths, stream)
+    def matches_batch(self, rows, lengths=None, stream=None, out=None):
+        """bitmap words (bit r&63 of word r>>6 = matches() of row r).  out: optional caller-owned int64 device tensor
+        for the bitmap words (device batches only)."""
+        return self._run("matches", rows, lengths, stream, out)
 
-    def contained_in_batch(self, rows, lengths=None, stream=None):
-        return self._run("contained_in", rows, lengths, stream)
+    def contained_in_batch(self, rows, lengths=None, stream=None, out=None):
+        return self._run("contained_in", rows, lengths, stream, out)
 
     def find_next_batch(self, rows, cursor, lengths=None, stream=None):
         """One Matcher.find() step per row from the per-row cursor (int32 device tensor; < 0 = exhausted).
@@ -311,7 +320,9 @@ class Pattern:
         """Every non-overlapping match of every row, as the reference's repeated find() would report them
         (DFACompilerTest.java:66-78,671-699): one launch per round over the rows that still have a cursor, results
         compacted on the device.  -> (offsets int64[n_rows + 1], start int32[m], end int32[m]) in CSR form.
-        An EMPTY match is reported once and ends its row (the reference's cursor does not advance past it)."""
+        A row ends where the reference's cursor stops advancing: an EMPTY match (or any match that does not end beyond
+        the cursor it was searched from) is reported once and ends its row; a nullable pattern's wrapped pseudo-match
+        at cursor == length (start = length, end = 0), on which the reference would cycle for ever, is dropped."""
         import torch
         n = rows.shape[0]
         dev = rows.device
@@ -329,15 +340,18 @@ class Pattern:
         ids = torch.arange(n, dtype=torch.int64, device=dev)
         counts = torch.zeros(n, dtype=torch.int64, device=dev)
         per_round = []  # round k holds the k-th match of every row that has one: no sort needed to build the CSR
-        while True:
+        round_cap = rows.shape[1] + 1  # a row of L chars has at most L non-empty matches (+ one empty one)
+        while len(per_round) < round_cap:
             _, st, en = self.find_next_batch(rows, cursor, lengths)
-            hit = en >= 0
+            # en < st: the reference's wrapped pseudo-match of a nullable pattern searched from cursor == length
+            # (end = the literal 0 of DFAClassBuilder.java:356); dropped, it ends the row (see needle_find_all_dev)
+            hit = (en >= 0) & (en >= st) & (cursor >= 0)
             if not bool(hit.any()):
                 break
             per_round.append((ids[hit], st[hit], en[hit]))
             counts += hit
-            empty = hit & (en == st)
-            cursor = torch.where(hit & ~empty, en, torch.full_like(en, -1))
+            stop = (en == st) | (en <= cursor)  # the row goes on only while the cursor advances
+            cursor = torch.where(hit & ~stop, en, torch.full_like(en, -1))
             if max_rounds is not None and len(per_round) >= max_rounds:
                 break
         offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
@@ -351,9 +365,10 @@ class Pattern:
             out_e[pos] = e_
         return offsets, out_s, out_e
 
-    def find_batch(self, rows, lengths=None, stream=None):
-        """(bitmap words, start int32[n], end int32[n]); unmatched rows have start = end = -1."""
-        return self._run("find", rows, lengths, stream)
+    def find_batch(self, rows, lengths=None, stream=None, out=None):
+        """(bitmap words, start int32[n], end int32[n]); unmatched rows have start = end = -1.  out: optional
+        caller-owned (bitmap int64, start int32, end int32) device tensors."""
+        return self._run("find", rows, lengths, stream, out)
 
     # ---- haystacks packed back to back (one char buffer + offsets: what a JNI host gets from a String[])
     def _run_packed_host(self, op, data, offsets):

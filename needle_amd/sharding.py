@@ -1,8 +1,16 @@
 """Row sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is RCCL on
 ROCm, "gloo" in the CPU tests).  Rows are independent units (a Matcher is per haystack, DFAClassBuilder.java:
-669-699), so there is no data-path collective: the only communication is ONE small collective per step that brings
-the per-shard result bitmap (156 KB per rank at 10M rows) to every rank over xGMI.  It is issued asynchronously
-(RCCL's own stream, ordered after the scan kernel) so that the next step's kernel overlaps with it."""
+669-699), so there is no data-path collective.  What moves, per step, are results only:
+
+  * the per-shard result BITMAP (156 KB per rank at 10M rows over 8 GPUs): one all-gather, every rank ends up with
+    the whole bitmap;
+  * for find(), the per-row start / end (2 x int32 per row: 10 MB per rank at 10M rows over 8 GPUs): a FAN-IN to
+    rank 0 -- every peer sends over its own direct xGMI link to the root (7 links in parallel).  An all-gather would
+    push the same 70 MB through every link of a ring and serve no one: only the host side of rank 0 consumes them.
+
+Both are issued asynchronously (RCCL's own stream, ordered after the scan kernel), so the next step's scan overlaps
+with them.  `ShardedScan` is the one implementation of a step: bench.py drives it with the HIP kernels, the gloo
+tests with the CPU oracle."""
 import torch
 import torch.distributed as dist
 
@@ -20,26 +28,33 @@ def _words_per_shard(total_rows, world):
     return -(-(-(-total_rows // world)) // 64)
 
 
-class _Pending:
-    """Handle of an in-flight gather: .wait() -> full bitmap (int64 words, ceil(total_rows / 64))."""
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
 
-    def __init__(self, work, out, n_words, keep):
-        self.work, self.out, self.n_words, self.keep = work, out, n_words, keep
+
+class _Pending:
+    """Handle of an in-flight gather: .wait() -> the gathered tensor (or None on the ranks that do not receive)."""
+
+    def __init__(self, work, out, n, keep):
+        self.work, self.out, self.n, self.keep = work, out, n, keep
 
     def wait(self):
         if self.work is not None:
             self.work.wait()
         out = self.out
+        if out is None:
+            return None
         if isinstance(out, list):
             out = torch.cat(out)
-        return out[:self.n_words]
+        return out[:self.n]
 
 
-def gather_bitmap_async(words, total_rows, world, rank):
+def gather_bitmap_async(words, total_rows, world, rank, out=None):
     """Start the all-gather of the per-shard bitmap words; returns a handle whose wait() yields the full bitmap on
-    every rank.  The caller may launch further work on its stream before waiting."""
+    every rank.  The caller may launch further work on its stream before waiting.  `words` may already be the padded
+    per-shard buffer (ShardedScan's are)."""
     n_words = (total_rows + 63) // 64
-    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+    if world == 1 and not _dist_on():
         return _Pending(None, words, n_words, None)
     per = _words_per_shard(total_rows, world)
     buf = words
@@ -47,7 +62,8 @@ def gather_bitmap_async(words, total_rows, world, rank):
         buf = torch.zeros(per, dtype=words.dtype, device=words.device)
         buf[:words.numel()] = words
     if buf.is_cuda:
-        out = torch.empty(per * world, dtype=words.dtype, device=words.device)
+        if out is None:
+            out = torch.empty(per * world, dtype=words.dtype, device=words.device)
         work = dist.all_gather_into_tensor(out, buf, async_op=True)
     else:  # gloo (CPU tests)
         out = [torch.empty(per, dtype=words.dtype) for _ in range(world)]
@@ -60,9 +76,29 @@ def gather_bitmap(words, total_rows, world, rank):
     return gather_bitmap_async(words, total_rows, world, rank).wait()
 
 
+def gather_rows_to_root_async(values, total_rows, world, rank, fill=-1, out=None):
+    """Fan-in of a per-row int32 result (find start / end) to rank 0: wait() -> the full array on rank 0, None on the
+    other ranks.  `values` may already be the padded per-shard buffer."""
+    if world == 1 and not _dist_on():
+        return _Pending(None, values, total_rows, None)
+    per = _words_per_shard(total_rows, world) * 64
+    buf = values
+    if values.numel() != per:
+        buf = torch.full((per,), fill, dtype=values.dtype, device=values.device)
+        buf[:values.numel()] = values
+    parts = None
+    if rank == 0:
+        if out is None:
+            out = torch.empty(per * world, dtype=values.dtype, device=values.device)
+        parts = list(out.view(world, per).unbind(0))
+    work = dist.gather(buf, gather_list=parts, dst=0, async_op=True)
+    return _Pending(work, out if rank == 0 else None, total_rows, (buf, parts))
+
+
 def gather_rows(values, total_rows, world, rank, fill=-1):
-    """All-gather a per-row int32 result (find start / end); returns the full array on every rank."""
-    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+    """All-gather a per-row int32 result; returns the full array on every rank (tests / small batches: the step
+    itself uses the fan-in above)."""
+    if world == 1 and not _dist_on():
         return values
     per = _words_per_shard(total_rows, world) * 64
     buf = values
@@ -77,3 +113,72 @@ def gather_rows(values, total_rows, world, rank, fill=-1):
         dist.all_gather(parts, buf)
         out = torch.cat(parts)
     return out[:total_rows]
+
+
+class ShardedScan:
+    """One step of the row-sharded job (config C4): scan this rank's rows, then bring the results to rank 0.
+
+    scan(bitmap, start, end): writes this shard's verdicts into the given buffers (int64 bitmap words; int32 start /
+    end, both None unless `is_find`); the buffers are the padded per-shard send buffers themselves, so a step moves
+    no byte more than the collectives do.  `n_buffers` result sets rotate so that step k + 1 may scan while the
+    gathers of step k are still in flight."""
+
+    def __init__(self, scan, total_rows, world, rank, is_find, device, n_buffers=2):
+        self.scan, self.total_rows, self.world, self.rank, self.is_find = scan, total_rows, world, rank, is_find
+        self.row0, self.n_rows = shard_range(total_rows, world, rank)
+        self.per_words = _words_per_shard(total_rows, world) if world > 1 or _dist_on() else (total_rows + 63) // 64
+        per_rows = self.per_words * 64
+        self.sets, self.k = [], 0
+        for _ in range(n_buffers):
+            s = {"bitmap": torch.zeros(self.per_words, dtype=torch.int64, device=device), "pending": None}
+            if is_find:
+                s["start"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
+                s["end"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
+            if _dist_on():  # receive buffers are part of the set: no allocation inside a step
+                cuda = torch.device(device).type == "cuda"
+                s["bitmap_all"] = torch.empty(self.per_words * world, dtype=torch.int64, device=device) if cuda else None
+                if is_find and rank == 0:
+                    s["start_all"] = torch.empty(per_rows * world, dtype=torch.int32, device=device)
+                    s["end_all"] = torch.empty(per_rows * world, dtype=torch.int32, device=device)
+            self.sets.append(s)
+
+    def scan_only(self):
+        """The scan of this rank's shard into the current buffer set (no communication)."""
+        s = self.sets[self.k % len(self.sets)]
+        if self.n_rows:
+            self.scan(s["bitmap"], s.get("start"), s.get("end"))
+        return s
+
+    def step(self, events=None):
+        """Scan + start the gathers; returns the buffer set, whose "pending" handles wait() completes.  events: an
+        optional pair of stream events recorded right before and right after the scan (the gathers run on the
+        collective library's own stream and are not between them)."""
+        s = self.sets[self.k % len(self.sets)]
+        if s["pending"] is not None:  # this set's previous gathers must have left before the scan overwrites it
+            for h in s["pending"]:
+                h.wait()
+        if events is not None:
+            events[0].record()
+        self.scan_only()
+        if events is not None:
+            events[1].record()
+        self.k += 1
+        pend = [gather_bitmap_async(s["bitmap"], self.total_rows, self.world, self.rank, out=s.get("bitmap_all"))]
+        if self.is_find:
+            pend.append(gather_rows_to_root_async(s["start"], self.total_rows, self.world, self.rank, out=s.get("start_all")))
+            pend.append(gather_rows_to_root_async(s["end"], self.total_rows, self.world, self.rank, out=s.get("end_all")))
+        s["pending"] = pend
+        return s
+
+    @staticmethod
+    def wait(s):
+        """-> (full bitmap words, start, end): the bitmap on every rank, start / end on rank 0 only (None elsewhere,
+        and None for matches / containedIn)."""
+        res = [h.wait() for h in s["pending"]]
+        s["pending"] = None
+        return res[0], (res[1] if len(res) > 1 else None), (res[2] if len(res) > 2 else None)
+
+    def drain(self):
+        for s in self.sets:
+            if s["pending"] is not None:
+                self.wait(s)

@@ -56,12 +56,14 @@ def digits_batch(xp, row0, n_rows, n_cols=256, seed=SEED, device=None):
     return out.astype(np.uint8) if xp is np else out.to(xp.uint8)
 
 
-def keywords(n=1000, seed=SEED):
-    """C3: n distinct keywords of length 3..5 over [a-z], in generated order (order matters: leftmost-first)."""
+def keywords(n=1000, seed=SEED, min_len=3, max_len=5):
+    """C3: n distinct keywords of length min_len..max_len (3..5: SURVEY.md s8d) over [a-z], in generated order (order
+    matters: leftmost-first).  The sparse-match variant of C3 uses 6..8: uniform [a-z ] text then matches a keyword
+    by chance in < 0.1 % of the rows, so only the planted 25 % match and every lane stays live over the whole row."""
     out, seen, i = [], set(), 0
     while len(out) < n:
         h = _h32i((seed ^ 0xC3) + i * 7919)
-        ln = 3 + h % 3
+        ln = min_len + h % (max_len - min_len + 1)
         w = "".join(chr(97 + _h32i(seed + i * 31 + j * 1000003) % 26) for j in range(ln))
         i += 1
         if w not in seen:

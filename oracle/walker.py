@@ -151,14 +151,17 @@ class OraclePattern:
 
     def find_all(self, h, limit=100000):
         """Repeated find() on one Matcher (nextStart = end, DFAClassBuilder.java:616-659) -> [(start, end), ...].
-        An empty match is reported once and ends the enumeration (the reference's cursor would not advance)."""
+        The enumeration ends where the reference's cursor stops advancing: an empty match is reported once and ends
+        it; so does any match that does not end beyond the cursor it was searched from.  A nullable pattern searched
+        from cursor == length reports end = the literal 0 of DFAClassBuilder.java:356 with start = length (end <
+        start): the reference would cycle (0,len),(len,0),... for ever; that wrapped pseudo-match is dropped here."""
         out, cur = [], 0
         while len(out) < limit:
             found, s, e = self.find(h, start=cur)
-            if not found:
+            if not found or e < s:
                 break
             out.append((s, e))
-            if e == s:
+            if e == s or e <= cur:
                 break
             cur = e
         return out

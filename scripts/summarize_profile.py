@@ -58,6 +58,7 @@ out["hbm_write_bytes_per_launch"] = write_b
 out["traffic_bytes_per_launch"] = fetch_b + write_b
 bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
 out["bench_line_under_profiler"] = bench
+out["kernel_source_sha"] = bench.get("kernel_source_sha")  # bench.py quotes this profile's traffic only for the same kernels
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / alg
 out["achieved_GBs_from_trace_avg"] = alg / out["avg_ns"]

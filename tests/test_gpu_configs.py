@@ -285,3 +285,54 @@ def test_find_next_with_cursor_edge_cases():
         for i, h in enumerate(hs):
             f, s, e = o2.find(h, start=cur[i])
             assert f and (int(st[i]), int(en[i])) == (s, e), (h, cur[i], int(st[i]), int(en[i]), s, e)
+
+
+NULLABLE_CASES = [("a*", ["aa", "baa", "aab", "", "b", "aaaa" * 8]), ("(ab)*", ["abab", "xabab", "ab", "aba", ""]),
+                  ("(a|b)*c?", ["abc", "abab", "cab", "ccc"])]
+
+
+@pytest.mark.parametrize("regex,hs", NULLABLE_CASES)
+def test_oracle_find_all_terminates_on_nullable_patterns(regex, hs):
+    """a nullable pattern whose non-empty match ends exactly at the row end made the repeated find() cycle
+    (0,len),(len,0),...: the literal-0 lastMatch of DFAClassBuilder.java:356.  The enumeration ends where the cursor
+    stops advancing and the wrapped pseudo-match (end < start) is dropped."""
+    from needle_amd.pattern import DFACompiler
+    from oracle.walker import Dfa, OraclePattern
+    t = DFACompiler.compile(regex).tables()
+    d = {k: Dfa(t["class_map"], t["stride"], v["table"], v["accepting"], v["max_char"]) for k, v in t["dfas"].items()}
+    o = OraclePattern(d["matches"], d["contained_in"], d["forwards"], d["backwards"], t["fixed_len"], -1)
+    for h in hs:
+        got = o.find_all(h.encode("latin-1"), limit=1000)
+        assert len(got) <= len(h) + 1, (regex, h, got[:8])
+        assert all(s <= e for s, e in got), (regex, h, got)
+        ends = [e for _, e in got]
+        assert ends == sorted(ends)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regex,hs", NULLABLE_CASES)
+def test_find_all_terminates_on_nullable_patterns(regex, hs):
+    """The same on the GPU: the CSR form (library rounds, then the Python rounds with max_rounds=None never reached),
+    the dense slots of needle_find_all_dev / needle_find_all_host, all equal to the oracle's enumeration."""
+    import torch
+    p, o = compiled(regex)
+    rows, lens = rows_from_strings(hs, np.uint8, stride=32)
+    t = torch.from_numpy(rows).cuda()
+    tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    want = [o.find_all(rows[i, :lens[i]]) for i in range(len(hs))]
+    offsets, st, en = p.find_all_batch(t, tl)
+    offsets, st, en = offsets.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+    for i in range(len(hs)):
+        got = list(zip(st[offsets[i]:offsets[i + 1]].tolist(), en[offsets[i]:offsets[i + 1]].tolist()))
+        assert got == want[i], (regex, hs[i], got, want[i])
+    # the Python round loop (what find_all_batch falls into when a row has more than 64 matches), bounded
+    offsets2, st2, en2 = p.find_all_batch(t, tl, max_rounds=40)
+    assert offsets2.cpu().numpy().tolist() == offsets.tolist() and st2.cpu().numpy().tolist() == st.tolist()
+    most = max(1, max(len(w) for w in want))
+    for dense_rows, dense_lens in ((t, tl), (rows, lens)):
+        counts, ds, de, more = p.find_all_dense(dense_rows, most, dense_lens)
+        if not isinstance(counts, np.ndarray):
+            counts, ds, de = counts.cpu().numpy(), ds.cpu().numpy(), de.cpu().numpy()
+        assert not more
+        for i in range(len(hs)):
+            assert list(zip(ds[i, :counts[i]].tolist(), de[i, :counts[i]].tolist())) == want[i], (regex, hs[i])

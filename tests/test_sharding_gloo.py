@@ -33,20 +33,47 @@ def _worker(rank, world, port, total_rows, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from needle_amd import workload as W
-        from needle_amd.sharding import gather_bitmap, gather_rows, shard_range
+        from needle_amd.sharding import ShardedScan, gather_bitmap, gather_rows, shard_range
         from oracle.walker import OraclePattern
         o = OraclePattern.from_fixture(load_snapshot("DigitPlus"), backwards_as_dfa=True)
         row0, n = shard_range(total_rows, world, rank)
         assert row0 % 64 == 0 or n == 0
         rows = W.digits_batch(np, row0, n, 64) if n else np.zeros((0, 64), dtype=np.uint8)
-        bits = o.batch_contained_in(rows) if n else np.zeros(0, dtype=bool)
-        m, s, e = o.batch_find(rows) if n else (bits, np.zeros(0, np.int32), np.zeros(0, np.int32))
-        full = gather_bitmap(_pack(bits), total_rows, world, rank)
-        ends = gather_rows(torch.from_numpy(e.astype(np.int32)), total_rows, world, rank)
+
+        # ShardedScan is the step bench.py times (there the scan is the HIP kernel, here the CPU oracle): scan into the
+        # padded per-shard buffers, all-gather of the bitmap, fan-in of start / end to rank 0 -- two steps in flight
+        def scan(bitmap, start, end):
+            m, s, e = o.batch_find(rows)
+            bitmap[:(n + 63) // 64] = _pack(m)
+            start[:n] = torch.from_numpy(s.astype(np.int32))
+            end[:n] = torch.from_numpy(e.astype(np.int32))
+
+        sh = ShardedScan(scan, total_rows, world, rank, True, "cpu", n_buffers=2)
+        assert (sh.row0, sh.n_rows) == (row0, n)
+        s1 = sh.step()
+        s2 = sh.step()
+        full, st, en = sh.wait(s1)
+        full2, st2, en2 = sh.wait(s2)
+        assert full.shape[0] == (total_rows + 63) // 64 and (full == full2).all()
         if rank == 0:
-            q.put((full.numpy().copy(), ends.numpy().copy()))
-        else:  # the all-gather leaves the same full result on every rank
-            assert full.shape[0] == (total_rows + 63) // 64 and ends.shape[0] == total_rows
+            assert st.shape[0] == total_rows and (st == st2).all() and (en == en2).all()
+        else:
+            assert st is None and en is None
+        # the contained_in step (bitmap only) and the plain helpers
+        bits = o.batch_contained_in(rows) if n else np.zeros(0, dtype=bool)
+
+        def scan_c(bitmap, start, end):
+            assert start is None and end is None
+            bitmap[:(n + 63) // 64] = _pack(bits)
+
+        shc = ShardedScan(scan_c, total_rows, world, rank, False, "cpu")
+        full_c, _, _ = shc.wait(shc.step())
+        assert (full_c == gather_bitmap(_pack(bits), total_rows, world, rank)).all()
+        _, _, e = o.batch_find(rows) if n else (None, None, np.zeros(0, np.int32))
+        ends_all = gather_rows(torch.from_numpy(e.astype(np.int32)), total_rows, world, rank)
+        if rank == 0:
+            assert (ends_all == en).all()
+            q.put((full.numpy().copy(), full_c.numpy().copy(), st.numpy().copy(), en.numpy().copy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -60,7 +87,7 @@ def test_row_sharding_and_gather(world, total_rows, oracle_lib):
     procs = [ctx.Process(target=_worker, args=(r, world, port, total_rows, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, ends = q.get(timeout=120)
+    full, full_c, starts, ends = q.get(timeout=120)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -70,10 +97,11 @@ def test_row_sharding_and_gather(world, total_rows, oracle_lib):
     o = OraclePattern.from_fixture(load_snapshot("DigitPlus"), backwards_as_dfa=True)
     rows = W.digits_batch(np, 0, total_rows, 64)
     want = o.batch_contained_in(rows)
-    assert full.shape[0] == (total_rows + 63) // 64
-    assert (unpack_bitmap(full, total_rows) == want).all()
-    _, _, e = o.batch_find(rows)
-    assert (ends == e).all()
+    assert full_c.shape[0] == (total_rows + 63) // 64
+    assert (unpack_bitmap(full_c, total_rows) == want).all()
+    m, s, e = o.batch_find(rows)
+    assert (unpack_bitmap(full, total_rows) == m).all()
+    assert (ends == e).all() and (starts == s).all()
 
 
 def test_shard_ranges_partition_the_batch():
