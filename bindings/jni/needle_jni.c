@@ -31,37 +31,55 @@ NATIVE(jint, compile)(JNIEnv *env, jclass c, jcharArray regex, jint flags, jlong
 
 NATIVE(jint, fromTables)(JNIEnv *env, jclass c, jbyteArray classMap, jint stride, jintArray nStates, jintArray maxChar,
                          jobjectArray tables, jobjectArray accepting, jint fixedLen, jlongArray out) {
+    /* Everything the C ABI will read is checked against the Java arrays' real lengths first: needle_pattern_from_tables
+     * copies n_states * stride shorts, n_states bytes and 65536 class-map bytes from raw pointers. */
+    if (!classMap || !nStates || !maxChar || !tables || !accepting || !out) return NEEDLE_ERR_INVALID;
+    if ((*env)->GetArrayLength(env, classMap) < 65536 || (*env)->GetArrayLength(env, nStates) < 4 ||
+        (*env)->GetArrayLength(env, maxChar) < 4 || (*env)->GetArrayLength(env, tables) < 4 ||
+        (*env)->GetArrayLength(env, accepting) < 4 || (*env)->GetArrayLength(env, out) < 1 || stride < 1 || stride > 255)
+        return NEEDLE_ERR_INVALID;
     needle_table_desc d;
     memset(&d, 0, sizeof(d));
     jint ns[4], mc[4];
     (*env)->GetIntArrayRegion(env, nStates, 0, 4, ns);
     (*env)->GetIntArrayRegion(env, maxChar, 0, 4, mc);
-    jbyte *cm = (*env)->GetByteArrayElements(env, classMap, NULL);
+    if ((*env)->ExceptionCheck(env)) return NEEDLE_ERR_INVALID;
     needle_dfa_desc *ds[4] = {&d.matches, &d.contained_in, &d.forwards, &d.backwards};
-    jshortArray ta[4];
-    jbyteArray aa[4];
-    jshort *tp[4];
-    jbyte *ap[4];
-    for (int i = 0; i < 4; i++) {
+    jshortArray ta[4] = {0};
+    jbyteArray aa[4] = {0};
+    jshort *tp[4] = {0};
+    jbyte *ap[4] = {0};
+    jbyte *cm = NULL;
+    int rc = NEEDLE_OK;
+    for (int i = 0; i < 4 && rc == NEEDLE_OK; i++) {
         ta[i] = (jshortArray)(*env)->GetObjectArrayElement(env, tables, i);
         aa[i] = (jbyteArray)(*env)->GetObjectArrayElement(env, accepting, i);
+        if (!ta[i] || !aa[i] || ns[i] < 1 || ns[i] > 16383 ||
+            (jlong)(*env)->GetArrayLength(env, ta[i]) < (jlong)ns[i] * stride || (*env)->GetArrayLength(env, aa[i]) < ns[i])
+            rc = NEEDLE_ERR_INVALID;
+    }
+    if (rc == NEEDLE_OK && !(cm = (*env)->GetByteArrayElements(env, classMap, NULL))) rc = NEEDLE_ERR_INVALID;
+    for (int i = 0; i < 4 && rc == NEEDLE_OK; i++) {
         tp[i] = (*env)->GetShortArrayElements(env, ta[i], NULL);
         ap[i] = (*env)->GetByteArrayElements(env, aa[i], NULL);
+        if (!tp[i] || !ap[i]) rc = NEEDLE_ERR_INVALID; /* OutOfMemoryError pending */
         ds[i]->n_states = ns[i];
         ds[i]->max_char = mc[i];
         ds[i]->table = (const int16_t *)tp[i];
         ds[i]->accepting = (const uint8_t *)ap[i];
     }
-    d.class_map = (const uint8_t *)cm;
-    d.stride = stride;
-    d.fixed_len = fixedLen;
     needle_pattern *p = NULL;
-    int rc = needle_pattern_from_tables(&d, &p); /* copies everything it needs */
-    for (int i = 0; i < 4; i++) {
-        (*env)->ReleaseShortArrayElements(env, ta[i], tp[i], JNI_ABORT);
-        (*env)->ReleaseByteArrayElements(env, aa[i], ap[i], JNI_ABORT);
+    if (rc == NEEDLE_OK) {
+        d.class_map = (const uint8_t *)cm;
+        d.stride = stride;
+        d.fixed_len = fixedLen;
+        rc = needle_pattern_from_tables(&d, &p); /* copies everything it needs */
     }
-    (*env)->ReleaseByteArrayElements(env, classMap, cm, JNI_ABORT);
+    for (int i = 0; i < 4; i++) {
+        if (tp[i]) (*env)->ReleaseShortArrayElements(env, ta[i], tp[i], JNI_ABORT);
+        if (ap[i]) (*env)->ReleaseByteArrayElements(env, aa[i], ap[i], JNI_ABORT);
+    }
+    if (cm) (*env)->ReleaseByteArrayElements(env, classMap, cm, JNI_ABORT);
     jlong h = (jlong)(intptr_t)p;
     (*env)->SetLongArrayRegion(env, out, 0, 1, &h);
     return rc;

@@ -22,10 +22,12 @@
 // distances keep the FIRST priority, StateSet.java:16-27), so sets of NFA states are kept in a small emulation of
 // java.util.HashMap's bucket order (JOrder below; no treeified bins -- not reachable with these key patterns).
 //
-// Not supported (reported as NEEDLE_ERR_UNSUPPORTED, never silently approximated): UNICODE_CHARACTER_CLASS forms
-// of \d \s \w (they come from the JDK's Character database, RegexParser.java:40-63) and UNICODE_CASE folding of
-// non-ASCII letters (Character.toUpperCase/toLowerCase tables).
+// UNICODE_CHARACTER_CLASS forms of \d \s \w and UNICODE_CASE folding come, in the reference, from whatever Unicode
+// version the running JDK's java.lang.Character carries (RegexParser.java:40-63,277-291).  Here they come from
+// needle_unicode_tables.h, generated (scripts/gen_unicode_tables.py) from the Unicode Character Database 13.0.0 -- what
+// JDK 15..18 answer; a reference running on an older or newer JDK differs exactly where Unicode itself changed.
 #include "needle_regex.h"
+#include "needle_unicode_tables.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -52,6 +54,40 @@ struct Unsupported : std::runtime_error { using std::runtime_error::runtime_erro
 struct CR { int start, end; }; // inclusive char range, 0..0xFFFF
 inline bool operator==(const CR &a, const CR &b) { return a.start == b.start && a.end == b.end; }
 inline bool cr_less(const CR &a, const CR &b) { return a.start != b.start ? a.start < b.start : a.end < b.end; }
+
+// ------------------------------------------------------------------------------------------------ Unicode data
+// java.lang.Character's answers for the BMP (needle_unicode_tables.h): the char sets behind \d \s \w under
+// UNICODE_CHARACTER_CLASS and Character.toUpperCase / toLowerCase(char) behind UNICODE_CASE.
+struct UniData {
+    std::vector<uint16_t> upper, lower;             // simple case mappings, identity where none
+    std::vector<std::vector<uint16_t>> by_key;      // key = toLowerCase(toUpperCase(x)) -> every x < 0xFFFF with that key, ascending
+    std::vector<int> digits, spaces, words;         // members, ascending (U+FFFF never is one)
+    UniData() : upper(65536), lower(65536), by_key(65536) {
+        for (int c = 0; c < 65536; ++c) upper[c] = lower[c] = (uint16_t)c;
+        for (int i = 0; i < needle_unicode::kUpper_n; ++i) upper[needle_unicode::kUpper[i][0]] = needle_unicode::kUpper[i][1];
+        for (int i = 0; i < needle_unicode::kLower_n; ++i) lower[needle_unicode::kLower[i][0]] = needle_unicode::kLower[i][1];
+        for (int x = 0; x < 0xFFFF; ++x) by_key[lower[upper[x]]].push_back((uint16_t)x); // `candidate < Character.MAX_VALUE`
+        auto expand = [](const uint16_t (*r)[2], int n, std::vector<int> &out) {
+            for (int i = 0; i < n; ++i)
+                for (int c = r[i][0]; c <= r[i][1]; ++c) out.push_back(c);
+        };
+        expand(needle_unicode::kDigit, needle_unicode::kDigit_n, digits);
+        expand(needle_unicode::kSpace, needle_unicode::kSpace_n, spaces);
+        expand(needle_unicode::kWord, needle_unicode::kWord_n, words);
+    }
+};
+const UniData &uni() {
+    static const UniData d;
+    return d;
+}
+// capacity of a java.util.HashMap after n insertions (16 buckets, doubling above a load of 3/4)
+struct JOrderLite {
+    int cap = 16, size = 0;
+    void on_insert() {
+        ++size;
+        if (size > cap / 4 * 3) cap *= 2;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ AST
 enum Kind { K_LITERAL, K_RANGE, K_CONCAT, K_UNION, K_REP, K_COUNTED, K_LPAREN };
@@ -311,6 +347,7 @@ class Parser {
         if (uci) {
             std::vector<int> cs = unicode_case_variants(c);
             if (cs.size() > 1) {
+                cs = hash_set_order(cs); // `for (var caseChar : characters)`, RegexParser.java:218
                 NodeP u;
                 for (int v : cs) { NodeP l = lit(std::u16string(1, (char16_t)v)); u = u ? make_union(u, l, false) : l; }
                 push(u);
@@ -322,20 +359,26 @@ class Parser {
         else if (c >= u'a' && c <= u'z') push(make_union(n, lit(std::u16string(1, (char16_t)(c - 32))), false));
         else push(n);
     }
-    // RegexParser.addCaseInsensitiveMatches :277-291 restricted to what can be stated without the JDK's case
-    // tables: ASCII letters (their only non-ASCII partners are U+212A, U+017F, U+0130, U+0131).
-    std::vector<int> unicode_case_variants(int c) {
-        if (c >= 128) {
-            if (c == 0x212A || c == 0x017F || c == 0x0130 || c == 0x0131 || c > 0xBF)
-                throw Unsupported("UNICODE_CASE folding of non-ASCII characters needs the JDK's case tables");
-            return {c};
-        }
-        const int lo = (c >= 'A' && c <= 'Z') ? c + 32 : c;
-        if (!(lo >= 'a' && lo <= 'z')) return {c};
-        std::vector<int> out = {lo - 32, lo};
-        if (lo == 'k') out.push_back(0x212A);
-        if (lo == 's') out.push_back(0x017F);
-        if (lo == 'i') { out.push_back(0x0130); out.push_back(0x0131); }
+    // RegexParser.addCaseInsensitiveMatches :277-291: c itself, and -- when c is cased, i.e. toLowerCase(toUpperCase(c))
+    // differs from toUpperCase(c) -- every x < U+FFFF with the same toLowerCase(toUpperCase(x)).  (Not an equivalence
+    // relation: U+1E9E finds U+00DF, U+00DF alone finds nothing.)  In insertion order: c, then the others ascending.
+    static std::vector<int> unicode_case_variants(int c) {
+        const UniData &u = uni();
+        std::vector<int> out = {c};
+        const int up = u.upper[c], lo = u.lower[up];
+        if (lo != up)
+            for (uint16_t x : u.by_key[lo])
+                if (x != c) out.push_back(x);
+        return out;
+    }
+    // the iteration order of the reference's HashSet<Character> holding those chars (hash = the char value)
+    static std::vector<int> hash_set_order(const std::vector<int> &inserted) {
+        JOrderLite jo;
+        for (size_t i = 0; i < inserted.size(); ++i) jo.on_insert();
+        std::vector<std::vector<int>> buckets((size_t)jo.cap);
+        for (int v : inserted) buckets[(size_t)(v & (jo.cap - 1))].push_back(v);
+        std::vector<int> out;
+        for (const auto &b : buckets) out.insert(out.end(), b.begin(), b.end());
         return out;
     }
     void collapse_literals() { // :297-321
@@ -418,22 +461,22 @@ class Parser {
         case u'a': return range(7, 7);
         case u'A': case u'B': case u'b': case u'c': case u'G': case u'p': case u'Z': case u'z':
             throw err("escape not supported yet");
-        case u'd': if (ucc) throw Unsupported("\\d under UNICODE_CHARACTER_CLASS needs the JDK's Character tables"); return range('0', '9');
-        case u'D': if (ucc) throw Unsupported("\\D under UNICODE_CHARACTER_CLASS needs the JDK's Character tables"); return complement_ranges({CR{'0', '9'}});
+        case u'd': if (ucc) return of_chars(uni().digits); return range('0', '9');       // :393-399
+        case u'D': if (ucc) return complement_chars(uni().digits); return complement_ranges({CR{'0', '9'}});
         case u'e': return range(0x1B, 0x1B);
         case u'f': return range(0xC, 0xC);
         case u'H': return complement_chars(chars_of(HSPACE));
         case u'h': return of_chars(chars_of(HSPACE));
         case u'n': return range('\n', '\n');
         case u'r': return range('\r', '\r');
-        case u's': if (ucc) throw Unsupported("\\s under UNICODE_CHARACTER_CLASS needs the JDK's Character tables"); return of_chars(chars_of(SPACE));
-        case u'S': if (ucc) throw Unsupported("\\S under UNICODE_CHARACTER_CLASS needs the JDK's Character tables"); return complement_chars(chars_of(SPACE));
+        case u's': if (ucc) return of_chars(uni().spaces); return of_chars(chars_of(SPACE));           // :433-439
+        case u'S': if (ucc) return complement_chars(uni().spaces); return complement_chars(chars_of(SPACE));
         case u't': return range('\t', '\t');
         case u'w':
-            if (ucc) throw Unsupported("\\w under UNICODE_CHARACTER_CLASS needs the JDK's Character tables");
+            if (ucc) return of_chars(uni().words); // :452-455
             return make_union(range('0', '9'), make_union(range('_', '_'), make_union(range('a', 'z'), range('A', 'Z'), false), false), false);
         case u'W':
-            if (ucc) throw Unsupported("\\W under UNICODE_CHARACTER_CLASS needs the JDK's Character tables");
+            if (ucc) return complement_chars(uni().words);
             return complement_ranges({CR{'0', '9'}, CR{'_', '_'}, CR{'a', 'z'}, CR{'A', 'Z'}});
         case u'x': {
             int count = 0, v = 0;

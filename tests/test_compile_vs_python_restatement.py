@@ -16,7 +16,7 @@ from oracle.walker import class_map_from_runs
 
 KEYS = {"matches": "Matches", "contained_in": "ContainedIn", "forwards": "Forwards", "backwards": "Backwards"}
 FLAG_SETS = [0, nc.DOTALL, nc.CASE_INSENSITIVE, nc.LEFTMOST_LONGEST, nc.CASE_INSENSITIVE | nc.UNICODE_CASE,
-             nc.DOTALL | nc.LEFTMOST_LONGEST]
+             nc.DOTALL | nc.LEFTMOST_LONGEST, nc.UNICODE_CHARACTER_CLASS, nc.CASE_INSENSITIVE | nc.UNICODE_CHARACTER_CLASS]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -60,7 +60,7 @@ def random_regex(rng, depth=0):
             return rng.choice(SETS)
         if k < 0.9:
             return rng.choice(ESCAPES)
-        return rng.choice(["é", "Ж", "中", "￿"])
+        return rng.choice(["é", "Ж", "中", "￿", "µ", "ß", "ẞ", "K", "ǅ", "[α-γ]", "İ"])
     if r < 0.55:
         return random_regex(rng, depth + 1) + random_regex(rng, depth + 1)
     if r < 0.7:
@@ -120,3 +120,40 @@ def test_rejected_regexes_are_rejected_alike(regex):
     for flags in (0, nc.CASE_INSENSITIVE):
         py, py_err, cc, cc_err = both(regex, flags)
         assert py_err == cc_err, (regex, py_err, cc_err)
+
+
+UNICODE_KNOWN = [
+    # (regex, flags, haystack, matches()) -- facts of the Unicode standard behind java.lang.Character
+    ("µ", nc.CASE_INSENSITIVE | nc.UNICODE_CASE, "\u039c", True),   # MICRO SIGN folds with GREEK MU
+    ("µ", nc.CASE_INSENSITIVE | nc.UNICODE_CASE, "\u03bc", True),
+    ("µ", nc.CASE_INSENSITIVE, "\u03bc", False),                    # ASCII-only folding without UNICODE_CASE
+    ("k", nc.CASE_INSENSITIVE | nc.UNICODE_CASE, "\u212a", True),   # KELVIN SIGN
+    ("s", nc.CASE_INSENSITIVE | nc.UNICODE_CASE, "\u017f", True),   # LONG S
+    ("i", nc.CASE_INSENSITIVE | nc.UNICODE_CASE, "\u0130", True),   # dotted capital I: toLowerCase = i
+    ("ß", nc.CASE_INSENSITIVE | nc.UNICODE_CASE, "\u1e9e", False),  # toUpperCase(ß) = ß: not cased for the reference
+    ("\u1e9e", nc.CASE_INSENSITIVE | nc.UNICODE_CASE, "ß", True),   # ... but toLowerCase(U+1E9E) = ß
+    ("[а-в]", nc.CASE_INSENSITIVE | nc.UNICODE_CASE, "Б", True),     # Cyrillic range
+    ("ǆ", nc.CASE_INSENSITIVE | nc.UNICODE_CHARACTER_CLASS, "ǅ", True),  # titlecase digraph (UCC implies UNICODE_CASE)
+    ("\\d+", nc.UNICODE_CHARACTER_CLASS, "\u0663\uff15", True),    # ARABIC-INDIC / FULLWIDTH digits
+    ("\\d", nc.UNICODE_CHARACTER_CLASS, "\u00b2", False),          # SUPERSCRIPT TWO is No, not Nd
+    ("\\d", 0, "\u0663", False),
+    ("\\w+", nc.UNICODE_CHARACTER_CLASS, "h\u00e9llo_\u0661\u0301\u2160\u24b6", True),  # letters, Pc, Nd, Mn, Nl, Other_Alphabetic
+    ("\\w", nc.UNICODE_CHARACTER_CLASS, "-", False),
+    ("\\W", nc.UNICODE_CHARACTER_CLASS, "\u00e9", False),
+    ("\\s", nc.UNICODE_CHARACTER_CLASS, "\u2028", True),
+    ("\\s", nc.UNICODE_CHARACTER_CLASS, "\u00a0", False),          # NO-BREAK SPACE is not Character.isWhitespace
+    ("\\s", nc.UNICODE_CHARACTER_CLASS, "\u001f", True),
+    ("\\S", nc.UNICODE_CHARACTER_CLASS, "\u3000", False),
+]
+
+
+@pytest.mark.parametrize("regex,flags,h,want", UNICODE_KNOWN)
+def test_unicode_flags_known_answers(regex, flags, h, want, oracle_lib):
+    """UNICODE_CASE / UNICODE_CHARACTER_CLASS (RegexParser.java:40-63,212-247,277-291) on the Unicode 13.0.0 data of
+    needle_unicode_tables.h: both generators agree table for table, and the oracle walker gives the known answer."""
+    from oracle.walker import Dfa, OraclePattern
+    assert assert_same(regex, flags)
+    t = nc.compile_regex(regex, flags)
+    d = {k: Dfa(t["class_map"][:65536], t["stride"], v["table"], v["accepting"], v["max_char"]) for k, v in t["dfas"].items()}
+    o = OraclePattern(d["matches"], d["contained_in"], d["forwards"], d["backwards"], t["fixed_len"], -1)
+    assert o.matches(h) == want, (regex, flags, h)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from test_compile_matches_txt import flag_sets, needs_jdk_tables, oracle_for
+from test_compile_matches_txt import flag_sets, oracle_for
 from test_gpu_parity import gpu_run, rows_from_strings
 
 
@@ -118,8 +118,6 @@ def test_matches_txt_rows_through_gpu_matcher():
     n = 0
     for row in doc["rows"]:
         flags = flag_sets(row)[0]
-        if needs_jdk_tables(row, flags):
-            continue
         key = (row["pattern"], flags)
         if key not in cache:
             cache[key] = DFACompiler.compile(row["pattern"], "t", flags)

@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from test_compile_matches_txt import DOC, flag_sets, needs_jdk_tables
+from test_compile_matches_txt import DOC, flag_sets
 from test_gpu_configs import compiled
 
 
@@ -48,7 +48,7 @@ def test_every_matches_txt_pattern_over_a_batch():
     for row in DOC["rows"]:
         for flags in flag_sets(row):
             key = (row["pattern"], flags)
-            if key in seen or needs_jdk_tables(row, flags):
+            if key in seen:
                 continue
             seen.add(key)
             try:
