@@ -49,6 +49,9 @@ struct ProgHeader {
     // rest; the backward table itself is walked out of HBM/L2)
     uint32_t off_bcmap, off_bptab, off_bpages;
     uint32_t off_btable; // != 0: the backward uint16 table is small and staged in LDS too (else read bprog from HBM/L2)
+    uint32_t off_bpack;  // != 0: the backward automaton has <= 6 states and rides along as packed functions: 8-bit rows
+                         // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)
+                         // followed by its F area.  The backward walk then needs no state-dependent lookup.
 };
 
 struct ScanArgs {
@@ -126,15 +129,21 @@ struct StripeArgs {
 
 // Fixed LDS byte offsets of the forward automaton (compile-time so that they fold into ds_read immediates).
 //   char_width 1:  packed: F[256][64] u32 at 0 (one copy per lane) table modes: cmap16[256] at 0, table at 512
-//   char_width 2:  packed: ptab32[256] at 0 (page * 1024), pagesF u32 [n_pages][256] at 1024 -- every page entry IS
-//                          the transition function F of its char: two dependent lookups per char, not three
+//   char_width 2:  packed: ptab64[256] at 0 = {base, mask} per high byte, F area at 2048: the F of char (hi, lo) is the
+//                          u32 at  2048 + (base | (lo * 4 & mask)).  A page whose 256 entries differ is stored whole
+//                          (base = k * 1024, mask = 0x3FC); a page on which F is CONSTANT is one shared dword (mask = 0):
+//                          every lane reading such a page hits the same address and the LDS broadcasts it -- no bank
+//                          conflicts however mixed the text (plain ASCII under a non-Latin class regex, CJK, ...).
+//                          Two dependent lookups per char, not three.  (Tried instead: a flat 64 KiB code unit -> column
+//                          map, one VALU op less per char -- but it only leaves room for 64-byte tiles: 0.96 -> 1.00 ms.)
+//                          The packed BACKWARD automaton of find() rides along in the same form with absolute addresses.
 //                  table modes: ptab16[256] at 0 (page * 256), pages8 (col * elem) at 512, table at hdr.off_table
 constexpr uint32_t kLdsF1 = 0, kLdsCmap1 = 0, kLdsTable1 = 512;
 //                  pair mode: cmapA16[256] at 0 (col * n_cols * 2: first char of a pair), cmapB16[256] at 512 (col * 2)
 constexpr uint32_t kLdsCmapB1 = 512, kLdsPairTable1 = 1024;
 constexpr uint32_t kLdsPtab2 = 0;
-constexpr uint32_t kLdsPagesF2 = 1024, kLdsPages2Table = 512;
-// packed mode on UTF-16 rows needs ptab32 + one KiB per distinct page in LDS next to the tiles
+constexpr uint32_t kLdsPagesF2 = 2048, kLdsPages2Table = 512;
+// packed mode on UTF-16 rows needs ptab64 + one KiB per distinct non-constant page in LDS next to the tiles
 constexpr uint32_t kMaxPackPagesBytes = 96u * 1024u;
 
 constexpr int kWavesPerBlock = 16;     // 1024 threads: one workgroup per CU shares one LDS copy of the tables

@@ -146,18 +146,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     int32_t last;
     int32_t cursor = 0;  // OP_FIND with per-row cursors: Matcher.nextStart (FROM of find(FROM, TO)); < 0 = exhausted
     bool dead = false;
-    // OP_FIND with a backward automaton: the three dwords of row text ending with the one that holds the char at
-    // lastMatch - 1 (copied out of the LDS tile while it is there), and the last two dwords of the previous tile.
-    // indexBackwards then starts on registers: going back to the row in memory costs a second fetch of its 128-byte
-    // line from HBM per matched row (C3: +1.28 GB on a 2.56 GB batch).
-    constexpr int CPD = 4 / CW;            // chars per dword
-    constexpr int HN = (CW == 1) ? 3 : 5; // snapshot dwords: >= 9 chars back from lastMatch - 1 at any alignment
-    // (native vectors, constant indices after unrolling: plain arrays captured by the lambdas end up in scratch)
-    u32x8 hist = {0, 0, 0, 0, 0, 0, 0, 0}; // [0 .. HN)
-    u32x4 carry = {0, 0, 0, 0};            // carry[i]: dword (last - i) of the previous tile
-    auto tile_dword = [&](uint32_t j) __attribute__((always_inline)) -> uint32_t {
-        return lds_u32(tile.row_addr + ((((j >> 2) ^ (uint32_t)G::swz(lane))) << 4) + ((j & 3u) << 2));
-    };
+    // OP_FIND with a backward automaton: a snapshot of the row text around lastMatch, copied out of the LDS tile while
+    // it is there: snapA = the 16-byte piece holding the char at lastMatch - 1, snapB = the piece before it (the
+    // previous tile's last piece -- `carry` -- when snapA is a tile's first).  indexBackwards then starts on registers
+    // (16 .. 31 bytes of text): going back to the row in memory costs a second fetch of its 128-byte line from HBM per
+    // matched row (C3: +1.28 GB on a 2.56 GB batch).  Longer matches read on from memory.
+    // (native vectors: plain arrays captured by the lambdas end up in scratch)
+    u32x4 snapA = {0, 0, 0, 0}, snapB = {0, 0, 0, 0}, carry = {0, 0, 0, 0};
+    int32_t snap_pi = 0; // index of snapA's piece inside its row (16-byte units)
     auto begin_group = [&](uint64_t grp) __attribute__((always_inline)) {
         my_row = (grp << 6) + lane;
         row_ok = my_row < a.n_rows;
@@ -226,19 +222,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         if (OP == OP_FIND) {
             if (a.fixed_len < 0) { // wave-uniform
                 if (last_rel >= 0) {
-                    const uint32_t de = (uint32_t)(last_rel - 1) / CPD; // tile dword holding the accepting char
-#pragma unroll
-                    for (int i = 0; i < HN; ++i) {
-                        const uint32_t t = tile_dword(de >= (uint32_t)i ? de - i : 0);
-                        const uint32_t back = (uint32_t)i - de - 1u; // when de < i: how far into the previous tile
-                        uint32_t c = carry[0];
-#pragma unroll
-                        for (int k = 1; k < HN - 1; ++k) c = back == (uint32_t)k ? carry[k] : c; // back <= i - 1 <= HN - 2
-                        hist[i] = de >= (uint32_t)i ? t : c;
-                    }
+                    const uint32_t pi = ((uint32_t)(last_rel - 1) * CW) >> 4; // tile piece holding the accepting char
+                    snapA = tile_piece<CHB>(tile, lane, (int)pi);
+                    const u32x4 before = tile_piece<CHB>(tile, lane, (int)(pi ? pi - 1 : 0));
+                    snapB = pi ? before : carry;
+                    snap_pi = (int32_t)(ck * G::kPieces + pi);
                 }
-                const u32x4 tail = tile_piece<CHB>(tile, lane, G::kPieces - 1);
-                carry = tail.wzyx;
+                carry = tile_piece<CHB>(tile, lane, G::kPieces - 1);
             }
             last = last_rel >= 0 ? (int32_t)idx0 + last_rel : last;
         }
@@ -269,11 +259,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
             const uint16_t *bt = a.hdr.off_btable ? (const uint16_t *)(smem + a.hdr.off_btable)
                                                    : (const uint16_t *)(a.bprog + a.bhdr.off_table);
-            const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo;
+            const uint32_t bscale = a.hdr.off_bpack ? 5u : 1u; // packed: a state is the bit offset of its field in F
+            const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo * bscale;
             const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
             int32_t idx_b = last - 1;
-            const int32_t hist_dword = (last > 0 ? last - 1 : 0) / CPD; // row dword index of hist0
-            uint32_t bs = a.bhdr.start;
+            uint32_t bs = a.bhdr.start * bscale;
             int32_t lastb = a.bhdr.root_accepting ? cursor : INT_MAX; // :543-547 (LENGTH var = FROM)
             bool active = res;
             while (__ballot(active) != 0ull) {
@@ -283,17 +273,40 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                     const int32_t p = idx_b - k;
                     cs[k] = 0;
                     if (active && p >= cursor) {
-                        const int32_t rel = hist_dword - p / CPD; // 0 .. HN-1: still inside the snapshot
-                        if (rel < HN) {
-                            uint32_t word = hist[0];
-#pragma unroll
-                            for (int i = 1; i < HN; ++i) word = rel == i ? hist[i] : word;
-                            cs[k] = (word >> ((uint32_t)(p % CPD) * (8u * CW))) & (CW == 1 ? 0xFFu : 0xFFFFu);
+                        const uint32_t bp = (uint32_t)p * CW;                 // byte offset of the char in its row
+                        const int32_t rel = snap_pi - (int32_t)(bp >> 4);     // 0: in snapA, 1: in snapB, more: not held
+                        if (rel <= 1) {
+                            const u32x4 sp = rel == 0 ? snapA : snapB;
+                            const uint32_t d = (bp >> 2) & 3u;
+                            const uint32_t word = d == 0 ? sp[0] : d == 1 ? sp[1] : d == 2 ? sp[2] : sp[3];
+                            cs[k] = (word >> ((bp & 3u) * 8u)) & (CW == 1 ? 0xFFu : 0xFFFFu);
                         } else {
                             cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p]; // a match longer than the snapshot
                         }
                     }
                 }
+                if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton -- 8 independent char -> F lookups, then bfe
+                    uint32_t fb[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (CW == 1) {
+                            fb[k] = lds_u32(a.hdr.off_bpack + (cs[k] << 2));
+                        } else {
+                            const u32x2 pg = lds_u32x2(a.hdr.off_bpack + ((cs[k] >> 8) << 3));
+                            fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]); // absolute address (needle_lower.cpp)
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool in_range = active && idx_b >= cursor; // loop bound `index >= FROM`, :549
+                        const uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
+                        const bool alive = in_range && nb != 0u;
+                        lastb = (alive && nb >= bacc) ? idx_b : lastb;
+                        bs = alive ? nb : bs;
+                        idx_b = alive ? idx_b - 1 : idx_b;
+                        active = alive;
+                    }
+                } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (active) {
@@ -310,6 +323,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                             }
                         }
                     }
+                }
                 }
             }
             s = res ? lastb : -1;

@@ -165,9 +165,19 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     }
 
     Mode mode;
-    // packed functions on UTF-16 rows: the pages hold F itself (u32 per code unit of every DISTINCT page), which has
-    // to fit the LDS next to the tiles; automata over very many distinct pages take the table modes
-    const size_t pack2_bytes = kLdsPagesF2 + cm.pages.size() * 4;
+    // packed functions on UTF-16 rows: the pages hold F itself (u32 per code unit of every DISTINCT non-constant page;
+    // one shared dword per constant page value), which has to fit the LDS next to the tiles; automata over very many
+    // distinct pages take the table modes
+    std::vector<int> page_const(p.hdr.n_pages, -1); // column of a constant page, else -1
+    size_t n_full = 0;
+    for (uint32_t g = 0; g < p.hdr.n_pages; ++g) {
+        const uint8_t *pg = &cm.pages[(size_t)g * 256];
+        bool same = true;
+        for (int i = 1; i < 256 && same; ++i) same = pg[i] == pg[0];
+        if (same) page_const[g] = pg[0];
+        else ++n_full;
+    }
+    const size_t pack2_bytes = kLdsPagesF2 + n_full * 1024 + (size_t)n_cols * 4;
     if (n_dev <= 6 && (char_width == 1 || (pack2_bytes <= kMaxPackPagesBytes && pack2_bytes <= lds_table_budget))) mode = MODE_PACK;
     else if (n_dev <= 256) mode = MODE_TABLE8;
     else mode = MODE_TABLE16;
@@ -192,6 +202,27 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         const Program bp = lower(t, W_BACKWARDS, char_width, lds_table_budget, true, false);
         const size_t tbytes = bp.blob.size() - bp.hdr.off_table;
         if (tbytes <= 2048) p.hdr.off_btable = append(p.blob, bp.blob.data() + bp.hdr.off_table, tbytes);
+        // ... and a backward automaton of <= 6 states as packed functions (same device numbering as `bp`): its walk is
+        // then 8 independent char -> F lookups and a chain of v_bfe_u32, not 8 x (2-3 dependent lookups)
+        const Program pk = lower(t, W_BACKWARDS, char_width, 64u << 10, false, false);
+        if (pk.hdr.mode == MODE_PACK && (char_width == 1 || pk.hdr.lds_bytes <= (24u << 10))) {
+            if (char_width == 1) { // the forward layout replicates F per lane (64 KiB): one copy is plenty here
+                std::vector<uint32_t> f(256);
+                for (int c = 0; c < 256; ++c) memcpy(&f[c], &pk.blob[kLdsF1 + 256 * (size_t)c], 4);
+                p.hdr.off_bpack = append(p.blob, f.data(), 1024);
+            } else {
+                while (p.blob.size() % 1024) p.blob.push_back(0); // F pages stay 1 KiB aligned: base | (lo * 4 & mask)
+                const uint32_t o = (uint32_t)p.blob.size();
+                p.blob.insert(p.blob.end(), pk.blob.begin(), pk.blob.begin() + pk.hdr.lds_bytes);
+                for (int hi = 0; hi < 256; ++hi) { // relative F offsets -> absolute LDS addresses
+                    uint32_t base;
+                    memcpy(&base, &p.blob[o + kLdsPtab2 + 8 * (size_t)hi], 4);
+                    base += o + kLdsPagesF2;
+                    memcpy(&p.blob[o + kLdsPtab2 + 8 * (size_t)hi], &base, 4);
+                }
+                p.hdr.off_bpack = o;
+            }
+        }
     };
     auto put16 = [&](size_t off, uint32_t v) { p.blob[off] = (uint8_t)(v & 255); p.blob[off + 1] = (uint8_t)(v >> 8); };
     auto put32 = [&](size_t off, uint32_t v) { put16(off, v & 0xFFFF); put16(off + 2, v >> 16); };
@@ -211,8 +242,27 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                 for (int l = 0; l < 64; ++l) put32(kLdsF1 + 256 * c + 4 * l, pack(cm.cmap8[c]));
         } else {
             p.blob.assign(pack2_bytes, 0);
-            for (int hi = 0; hi < 256; ++hi) put32(kLdsPtab2 + 4 * hi, (uint32_t)cm.ptab[hi] * 1024u);
-            for (size_t i = 0; i < cm.pages.size(); ++i) put32(kLdsPagesF2 + 4 * i, pack(cm.pages[i]));
+            // F area: the non-constant pages first (1 KiB each, so that base | (lo * 4) needs no add), then one dword
+            // per column for the constant pages
+            const uint32_t const_base = (uint32_t)(n_full * 1024);
+            for (int k = 0; k < n_cols; ++k) put32(kLdsPagesF2 + const_base + 4 * k, pack(k));
+            std::vector<uint32_t> page_base(p.hdr.n_pages), page_mask(p.hdr.n_pages);
+            uint32_t next_full = 0;
+            for (uint32_t g = 0; g < p.hdr.n_pages; ++g) {
+                if (page_const[g] >= 0) {
+                    page_base[g] = const_base + 4u * (uint32_t)page_const[g];
+                    page_mask[g] = 0;
+                } else {
+                    page_base[g] = next_full * 1024u;
+                    page_mask[g] = 0x3FCu;
+                    for (int lo = 0; lo < 256; ++lo) put32(kLdsPagesF2 + page_base[g] + 4 * lo, pack(cm.pages[(size_t)g * 256 + lo]));
+                    ++next_full;
+                }
+            }
+            for (int hi = 0; hi < 256; ++hi) {
+                put32(kLdsPtab2 + 8 * hi, page_base[cm.ptab[hi]]);
+                put32(kLdsPtab2 + 8 * hi + 4, page_mask[cm.ptab[hi]]);
+            }
         }
         emit_backward_maps();
         p.hdr.lds_bytes = (uint32_t)p.blob.size();

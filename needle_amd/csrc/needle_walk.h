@@ -108,6 +108,8 @@ __device__ __forceinline__ uint32_t or_byte(uint32_t a, uint32_t w) { // a | (by
 __device__ __forceinline__ uint32_t lds_u8(uint32_t a) { return *(NEEDLE_LDS(uint8_t))(uintptr_t)(a); }
 __device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *(NEEDLE_LDS(uint16_t))(uintptr_t)(a); }
 __device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *(NEEDLE_LDS(uint32_t))(uintptr_t)(a); }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 lds_u32x2(uint32_t a) { return *(NEEDLE_LDS(u32x2))(uintptr_t)(a); }
 
 // One wait for every LDS read issued so far, and nothing scheduled across it.
 __device__ __forceinline__ void lds_fence() {
@@ -146,9 +148,9 @@ __device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_r
         else if (MODE == MODE_PAIR) col = lds_u16(shl_byte<K>(w, 1) + ((K & 1) ? kLdsCmapB1 : kLdsCmap1)); // first | second char of a pair
         else col = lds_u16(shl_byte<K>(w, 1) + kLdsCmap1);
     } else {
-        if (MODE == MODE_PACK) { // ptab32[high byte] = page * 1024; pagesF[page][low byte] = F of the char
-            const uint32_t pg = lds_u32(shl_byte<(2 * K + 1) & 3>(w, 2) + kLdsPtab2);
-            col = lds_u32(pg + shl_byte<(2 * K) & 3>(w, 2) + kLdsPagesF2);
+        if (MODE == MODE_PACK) { // ptab64[high byte] = {base, mask}; F of the char at base | (low byte * 4 & mask)
+            const u32x2 pg = lds_u32x2(shl_byte<(2 * K + 1) & 3>(w, 3) + kLdsPtab2);
+            col = lds_u32(((shl_byte<(2 * K) & 3>(w, 2) & pg[1]) | pg[0]) + kLdsPagesF2);
         } else {
             const uint32_t pg = lds_u16(shl_byte<(2 * K + 1) & 3>(w, 1) + kLdsPtab2);  // page base = page * 256
             col = lds_u8(or_byte<(2 * K) & 3>(pg, w) + kLdsPages2Table);                // pages hold column * element size
@@ -187,15 +189,16 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
     // all state-independent lookups of the piece first (they pipeline in the LDS) ...
     uint32_t col[CPP];
     if (CW == 2) {
-        // UTF-16: dependent lookups per char -- page table -> page entry, which in packed mode IS the char's transition
-        // function (two lookups), in the table modes its column (the table lookup follows on the state chain).  Issued
-        // as batches of 8 with ONE wait between batches: left to the scheduler they come out as ~14 short waits per
-        // piece, each exposing a full LDS round trip.
+        // UTF-16: two dependent lookups per char before the state chain -- packed mode: page table -> F; table modes:
+        // page table -> page -> column (the table lookup follows on the state chain).  Issued as batches of 8 with ONE
+        // wait between batches: left to the scheduler they come out as ~14 short waits per piece, each exposing a full
+        // LDS round trip.
         uint32_t pg[CPP];
         if (MODE == MODE_PACK) {
             uint32_t lo4[CPP];
+            u32x2 bm[CPP]; // {base, mask} of the char's page
 #define NEEDLE_PG(D, K)                                                                              \
-    pg[(D) * 2 + (K)] = lds_u32(shl_byte<(2 * (K) + 1) & 3>(w[D], 2) + kLdsPtab2);                   \
+    bm[(D) * 2 + (K)] = lds_u32x2(shl_byte<(2 * (K) + 1) & 3>(w[D], 3) + kLdsPtab2);                 \
     lo4[(D) * 2 + (K)] = shl_byte<(2 * (K)) & 3>(w[D], 2);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -206,7 +209,7 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
             lds_fence();
 #pragma unroll
             for (int i = 0; i < CPP; ++i) {
-                uint32_t c = lds_u32(pg[i] + lo4[i] + kLdsPagesF2);
+                uint32_t c = lds_u32(((lo4[i] & bm[i][1]) | bm[i][0]) + kLdsPagesF2); // v_and_or_b32
                 if (GUARD) {
                     c = (p0 + i < rem) ? c : wk.pad_e;
                     c = (p0 + i < skip) ? wk.pre_e : c;
