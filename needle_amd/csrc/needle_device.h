@@ -72,6 +72,8 @@ struct ScanArgs {
     int32_t *start;
     int32_t *end;
     uint32_t *end_state;    // optional: the automaton state (device id) in which every row's walk stopped
+    uint32_t defer_max_live; // survivor pool (needle_kernels.hip): a group with at most this many unresolved rows after
+                             // a 128-byte line hands them to its wave's pool and ends; 0 = off
 };
 
 // Long rows of table-mode automata (needle_stripe.hip, "speculative stripes"): every stripe is first scanned as a row of

@@ -14,6 +14,16 @@
 // requested exactly once: by one `nt` load instruction (CHB = 128) or by the two halves of a fetch unit issued back to
 // back (CHB = 64).  The per-char code itself (all automaton modes) is walk_piece() in needle_walk.h.
 //
+// Survivor pool.  Rows are independent, but a wave walks 64 of them in lockstep: once most of its rows have their
+// verdict (find() after the match, matches() after the first mismatch, containedIn() after the first hit) every
+// further tile costs the full instruction stream for a handful of live lanes.  So after each 128-byte line a group
+// whose unresolved rows are few hands them over -- row, next chunk, automaton state, lastMatch: four registers --
+// to free lanes of the wave's POOL (a cross-lane compaction with ds_permute / ds_bpermute, no memory involved) and
+// ends.  When the pool is nearly full the wave runs a pool step: one more line of up to 64 pooled rows, gathered by
+// per-lane row addresses into the same LDS tile and walked by the same code, each lane from its own row offset;
+// rows that resolve are written out (bitmap bit by atomicOr into the word their group already stored), the others
+// stay pooled.  Resolved rows' remaining lines are never fetched.
+//
 // The loops restated here (reference: needle-compiler/src/main/java/com/justinblank/strings/
 // DFAClassBuilder.java): matches() :892-910, containedIn() :1004-1022, indexForwards() :438-468,
 // indexBackwards() :565-583, find() :629-657.  Dead state (-1), the `c > maxChar` exits and "index past the row
@@ -26,6 +36,10 @@ namespace needle {
 template <int OP, int CW, int MODE, bool GUARD, int CHB>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArgs a) {
     using G = Geom<CHB>;
+    // The survivor pool is compiled into the kernels of the big-table automata (64-byte tiles: the shape the launcher
+    // picks when the table fills the LDS).  Packed mode has no use for it (its lanes cost the same dead or alive and its
+    // scans run at the HBM rate), and the 128-byte-tile kernels have no registers to spare (128 VGPRs at 16 waves).
+    constexpr bool POOL = MODE != MODE_PACK && CHB == 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,6 +168,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     // (native vectors: plain arrays captured by the lambdas end up in scratch)
     u32x4 snapA = {0, 0, 0, 0}, snapB = {0, 0, 0, 0}, carry = {0, 0, 0, 0};
     int32_t snap_pi = 0; // index of snapA's piece inside its row (16-byte units)
+    bool snapB_ok = true, carry_ok = true; // (pool steps: the previous tile in LDS belonged to other rows)
+    // survivor pool: lane l's slot holds one unresolved row when bit l of pool_mask is set
+    uint32_t p_row = 0, p_ck = 0, p_st = 0;
+    int32_t p_last = -1;
+    uint64_t pool_mask = 0; // wave-uniform
     auto begin_group = [&](uint64_t grp) __attribute__((always_inline)) {
         my_row = (grp << 6) + lane;
         row_ok = my_row < a.n_rows;
@@ -168,14 +187,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             dead = cursor < 0; // find(): `if nextStart == -1 return false`, DFAClassBuilder.java:629-630
             if (dead) cursor = 0, st = 0; // parked in the sink: no lookups, and an all-exhausted wave leaves after one tile
         }
+        snapB_ok = carry_ok = true;
         last = -1; // OP_FIND: lastMatch of indexForwards
         // :356 literal 0, then the first loop iteration's wasAccepted check (:440) moves it to FROM if FROM < length
         if (OP == OP_FIND && a.hdr.root_accepting) last = ((uint32_t)cursor < len) ? cursor : 0;
     };
 
-    // Walk the tile in LDS (chunk ck of the current group).  Returns true when no lane needs a further chunk.
-    auto walk_tile = [&](uint32_t ck) __attribute__((always_inline)) -> bool {
-        const uint32_t idx0 = ck * (CHB / CW);           // index of the tile's first char
+    // Walk the tile in LDS: per lane the chars [idx0, idx0 + CHB / CW) of its row (piece0 = idx0 in 16-byte pieces;
+    // both wave-uniform for a group walked in place, per lane in a pool step).  Returns the mask of lanes that need a
+    // further chunk.
+    auto walk_tile = [&](uint32_t idx0, uint32_t piece0) __attribute__((always_inline)) -> uint64_t {
         const uint32_t rem = len > idx0 ? len - idx0 : 0; // GUARD: chars of this row inside the tile and beyond
         const uint32_t skip = (uint32_t)cursor > idx0 ? (uint32_t)cursor - idx0 : 0; // GUARD: chars before the cursor
         int32_t last_rel = -1;                            // OP_FIND: last accepting position inside this tile
@@ -226,7 +247,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                     snapA = tile_piece<CHB>(tile, lane, (int)pi);
                     const u32x4 before = tile_piece<CHB>(tile, lane, (int)(pi ? pi - 1 : 0));
                     snapB = pi ? before : carry;
-                    snap_pi = (int32_t)(ck * G::kPieces + pi);
+                    snapB_ok = pi != 0u || carry_ok;
+                    snap_pi = (int32_t)(piece0 + pi);
                 }
                 carry = tile_piece<CHB>(tile, lane, G::kPieces - 1);
             }
@@ -237,16 +259,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         if (OP == OP_CONTAINED_IN) live = st < accept_lo;
         else live = st != 0;
         if (GUARD) live = live && (idx0 + CHB / CW < len);
-        return __ballot(live) == 0ull;
+        return __ballot(live);
     };
 
-    // Verdicts of the finished group: bitmap word, and for find() the start index (DFAClassBuilder.java:640-656).
-    auto finish_group = [&](uint64_t grp) __attribute__((always_inline)) {
+    // Verdicts of the rows with row_ok: bitmap, and for find() the start index (DFAClassBuilder.java:640-656).  A group
+    // finished in place stores its whole bitmap word (rows it deferred to the pool count as 0 for now); pooled rows OR
+    // their bit in later.
+    auto finish_rows = [&](uint64_t grp, auto pooled_c) __attribute__((always_inline)) {
+        constexpr bool POOLED = decltype(pooled_c)::value;
         bool res;
         if (OP == OP_FIND) res = row_ok && !dead && (last >= 0);
         else res = row_ok && (st >= accept_lo);
-        const uint64_t word = __ballot(res);
-        if (lane == 0) a.bitmap[grp] = word;
+        if (!POOLED) {
+            const uint64_t word = __ballot(res);
+            if (lane == 0) a.bitmap[grp] = word;
+        } else if (res) {
+            atomicOr((unsigned long long *)&a.bitmap[my_row >> 6], 1ull << (my_row & 63));
+        }
         if (a.end_state && row_ok) a.end_state[my_row] = st / SCALE; // (speculative stripes: the state at the stripe's end)
         if (OP != OP_FIND) return;
         int32_t s = -1;
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                     if (active && p >= cursor) {
                         const uint32_t bp = (uint32_t)p * CW;                 // byte offset of the char in its row
                         const int32_t rel = snap_pi - (int32_t)(bp >> 4);     // 0: in snapA, 1: in snapB, more: not held
-                        if (rel <= 1) {
+                        if (rel == 0 || (rel == 1 && snapB_ok)) {
                             const u32x4 sp = rel == 0 ? snapA : snapB;
                             const uint32_t d = (bp >> 2) & 3u;
                             const uint32_t word = d == 0 ? sp[0] : d == 1 ? sp[1] : d == 2 ? sp[2] : sp[3];
@@ -343,13 +372,91 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         const uint64_t safe = a.total_bytes >= (uint64_t)(NT * CHB) ? (a.total_bytes - NT * CHB) / group_bytes : 0;
         if (safe < last_group) last_group = safe;
     }
+    // ---- survivor pool: hand the unresolved rows of the current group (lanes of `live`, all continuing at chunk
+    // next_ck) to free pool lanes.  The caller has checked that there are enough free lanes.
+    auto defer_rows = [&](uint64_t live, uint32_t next_ck) __attribute__((always_inline)) {
+        const bool is_live = (live >> lane) & 1ull;
+        const uint32_t n_live = (uint32_t)__builtin_popcountll(live);
+        const uint64_t free = ~pool_mask;
+        // rank of this lane among the live lanes / among the free lanes below it
+        const uint32_t q = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+        const uint32_t rf = __builtin_amdgcn_mbcnt_hi((uint32_t)(free >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free, 0u));
+        // push every lane's index to a distinct lane -- the r-th live lane to lane r -- so that lane r holds "the
+        // r-th live lane"; the r-th free pool lane then pulls that lane's row context
+        const uint32_t dest = is_live ? q : n_live + ((uint32_t)lane - q);
+        const uint32_t nth_live = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), lane);
+        const bool take = ((free >> lane) & 1ull) && rf < n_live;
+        const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rf & 63u) << 2), (int)nth_live) << 2;
+        const uint32_t t_row = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)(uint32_t)my_row);
+        const uint32_t t_st = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)st);
+        p_row = take ? t_row : p_row;
+        p_st = take ? t_st : p_st;
+        p_ck = take ? next_ck : p_ck;
+        if (OP == OP_FIND) {
+            const int32_t t_last = __builtin_amdgcn_ds_bpermute((int)src, last);
+            p_last = take ? t_last : p_last;
+        }
+        pool_mask |= __ballot(take);
+        row_ok = row_ok && !is_live; // the deferred rows' verdicts come later
+    };
+
+    // One pool step: the next 128-byte line of every pooled row.  Uses (and clobbers) the tile registers R and the
+    // per-group state.  Rows that resolve are written out and leave the pool.
+    auto pool_step = [&]() __attribute__((always_inline)) {
+        const bool in_pool = (pool_mask >> lane) & 1ull;
+        my_row = p_row;
+        row_ok = in_pool;
+        len = 0;
+        if (in_pool) len = a.lengths ? a.lengths[p_row] : a.row_len;
+        st = in_pool ? p_st : 0u;
+        last = p_last;
+        cursor = 0;
+        dead = false;
+        snap_pi = INT_MAX / 2; // nothing of the row's earlier text is held: indexBackwards reads it from memory
+        snapB_ok = false;
+        carry_ok = false;
+        const uint32_t unit = p_ck / NT;
+        // gather: slot s of the LDS tile = the row of pool lane s
+#pragma unroll
+        for (int j = 0; j < G::kInstrs; ++j) {
+            const uint32_t slot = (uint32_t)(j * G::kRowsPerInstr) + row_in_instr;
+            const uint32_t srow = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slot << 2), (int)p_row);
+            const uint32_t sunit = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slot << 2), (int)unit);
+            const uint32_t kk = p_in_row ^ (uint32_t)G::swz((int)slot);
+            const uint8_t *ptr = a.rows + (uint64_t)srow * a.stride_bytes + (uint64_t)sunit * (NT * CHB) + kk * 16u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) R[t][j] = load_row16<NT == 1>(ptr + t * CHB);
+        }
+        uint64_t live = pool_mask;
+        for (int t = 0; t < NT; ++t) { // (a run-time loop: one copy of the tile walk; R[1] moves down for the second tile)
+#pragma unroll
+            for (int j = 0; j < G::kInstrs; ++j) store_piece(tile, j, R[0][j]);
+            live = walk_tile((p_ck + (uint32_t)t) * (CHB / CW), (p_ck + (uint32_t)t) * G::kPieces);
+            carry_ok = true;
+            if (live == 0ull) break;
+            if (NT == 2) {
+#pragma unroll
+                for (int j = 0; j < G::kInstrs; ++j) R[0][j] = R[NT - 1][j];
+            }
+        }
+        uint32_t n_ch = (len * CW + CHB - 1) / CHB;
+        if (n_ch == 0) n_ch = 1;
+        const bool more = in_pool && ((live >> lane) & 1ull) && (p_ck + NT < n_ch);
+        row_ok = in_pool && !more;
+        pool_mask &= ~__ballot(row_ok);
+        finish_rows(0, std::true_type{});
+        p_st = st;
+        p_last = last;
+        p_ck += NT;
+    };
+
     if (g < last_group) {
         uint32_t ck = 0;
         uint32_t pred_exit = 0xFFFFFFFFu; // chunk after which the previous group left early (prefetch predictor)
         begin_group(g);
         fetch(g, 0);
-        // One tile: stage it, prefetch, walk it.  Returns 0 = same group continues with the next tile, 1 = a new
-        // group was begun (its unit 0 is in R or in flight), 2 = no safe group left for this wave.
+        // One tile: stage it, prefetch, walk it.  Returns 0 = same group continues with the next tile; the group ended
+        // and g moved on: 1 = the unit 0 of the new g is in R or in flight, 3 = it still has to be fetched.
         auto step = [&](auto tc) __attribute__((always_inline)) -> int {
             constexpr int T = decltype(tc)::value;
             // Prefetch while this tile is walked whenever the unit's registers are all free after staging it: at
@@ -359,26 +466,45 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             const uint64_t pf_g = pf_same ? g : g + wave_cnt;
             stage_and_fetch(tc, do_pf && pf_g < last_group, pf_g, pf_same ? (ck + 1) / NT : 0u);
             asm volatile("" ::: "memory"); // keep the prefetch issued ahead of the walk
-            const bool group_done = walk_tile(ck) || (ck + 1 >= n_chunks);
+            const uint64_t live = walk_tile(ck * (CHB / CW), ck * G::kPieces);
+            bool group_done = live == 0ull || (ck + 1 >= n_chunks);
+            if (POOL && !group_done && T == NT - 1 && a.defer_max_live) {
+                // few unresolved rows after a whole line: they go to the pool, the group ends here
+                const uint32_t n_live = (uint32_t)__builtin_popcountll(live);
+                if (n_live <= a.defer_max_live && n_live <= 64u - (uint32_t)__builtin_popcountll(pool_mask)) {
+                    defer_rows(live, ck + 1);
+                    group_done = true;
+                }
+            }
             if (!group_done) {
                 if (do_pf && !pf_same) fetch(g, (ck + 1) / NT); // predicted an exit that did not happen
                 ++ck;
                 return 0;
             }
-            finish_group(g);
+            finish_rows(g, std::false_type{});
             pred_exit = (ck + 1 < n_chunks) ? ck : 0xFFFFFFFFu;
-            const uint64_t ng = g + wave_cnt;
-            g = ng;
-            if (ng >= last_group) return 2;
-            if (!do_pf || pf_same) fetch(ng, 0); // nothing (or this group's next unit) was prefetched: (re)direct
-            ck = 0;
-            begin_group(g);
-            return 1;
+            g += wave_cnt;
+            return (!do_pf || pf_same) ? 3 : 1; // 3: nothing (or this group's next unit) was prefetched
         };
         for (;;) {
             int r = step(std::integral_constant<int, 0>{});
             if (NT == 2 && r == 0) r = step(std::integral_constant<int, NT - 1>{});
-            if (r == 2) break;
+            if (r == 0) continue;
+            // a group ended.  Run pool steps while the pool could not take another group's survivors -- or, after this
+            // wave's last pipelined group, until it is empty.
+            const bool more_groups = g < last_group;
+            bool have_unit = r == 1;
+            if (POOL) {
+                const uint32_t keep = more_groups ? 64u - a.defer_max_live : 0u;
+                while ((uint32_t)__builtin_popcountll(pool_mask) > keep) {
+                    pool_step();
+                    have_unit = false; // R was used
+                }
+            }
+            if (!more_groups) break;
+            if (!have_unit) fetch(g, 0);
+            ck = 0;
+            begin_group(g);
         }
     }
     // ---- the batch's last group(s): clamped loads, no pipelining (at most a couple of waves in the whole grid)
@@ -387,9 +513,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         for (uint32_t ck = 0; ck < n_chunks; ++ck) {
             fetch_clamped(g, ck);
             stage_and_fetch(std::integral_constant<int, 0>{}, false, 0, 0);
-            if (walk_tile(ck)) break;
+            if (walk_tile(ck * (CHB / CW), ck * G::kPieces) == 0ull) break;
         }
-        finish_group(g);
+        finish_rows(g, std::false_type{});
     }
 }
 
@@ -493,6 +619,11 @@ hipError_t launch_scan(int op, int char_width, const ScanArgs &a_in, int n_cus, 
     if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
     sh.grid = (int)blocks;
     sh.lds = ((a.hdr.lds_bytes + 15u) & ~15u) + (size_t)(sh.waves - (in_f ? 4 : 0)) * 64 * sh.chb;
+    // survivor pool (see the file header): on unless per-row cursors / end states are wanted (find_next, the speculative
+    // stripe pass) or row indices do not fit the pool's 32-bit slots.  NEEDLE_DEFER=<n>: threshold (0 = off; tuning)
+    static const int defer_env = getenv("NEEDLE_DEFER") ? atoi(getenv("NEEDLE_DEFER")) : 16;
+    a.defer_max_live = 0;
+    if (defer_env > 0 && defer_env <= 32 && !a.from && !a.end_state && a.n_rows < (1ull << 32)) a.defer_max_live = (uint32_t)defer_env;
     // unguarded kernels assume every row fills a whole number of tiles
     const bool guard = a.lengths != nullptr || a.from != nullptr || a.row_len == 0 ||
                        ((uint64_t)a.row_len * char_width) % sh.chb != 0;
