@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 ENGINE_CLOCK_MHZ = 2400.0  # MI355X peak engine clock (same guide); chars/clk/CU is quoted against it
-KERNEL_SOURCES = ["needle_kernels.hip", "needle_stripe.hip", "needle_walk.h", "needle_device.h", "needle_lower.cpp"]
+KERNEL_SOURCES = ["needle_scan.h", "needle_kernels.hip", "needle_stripe.hip", "needle_walk.h", "needle_device.h", "needle_lower.cpp"]
 
 
 def kernel_source_sha():

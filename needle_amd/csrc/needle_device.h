@@ -14,6 +14,10 @@ enum Mode : int {
     MODE_TABLE8 = 1,  // [state][column] uint8 next-state table in LDS
     MODE_TABLE16 = 2, // [state][column] uint16 next-state table in LDS
     MODE_GLOBAL = 3,  // uint16 table too large for LDS: walked out of HBM/L2
+    MODE_HYBRID = 5,  // uint16 table too large for LDS, but automata live in few states: the rows of the first `hot`
+                      // states in breadth-first order from the start state are in LDS, the whole table in HBM; a lane
+                      // in a colder state fetches its entry through the scalar cache.  Entries carry the "accepting" bit
+                      // (bit 15) so that the numbering is free to follow the breadth-first order.
     MODE_PAIR = 4,    // 8-bit rows, <= 256 states, n_states * n_cols^2 entries fit the LDS: TWO chars per dependent
                       // lookup -- uint16 [state][col1][col2] = next state after both | code << 8 (find: 0 no accept,
                       // 1 accepted after the first char only, 2 accepted after the second)
@@ -49,6 +53,8 @@ struct ProgHeader {
     // rest; the backward table itself is walked out of HBM/L2)
     uint32_t off_bcmap, off_bptab, off_bpages;
     uint32_t off_btable; // != 0: the backward uint16 table is small and staged in LDS too (else read bprog from HBM/L2)
+    uint32_t hot_bytes;  // MODE_HYBRID: bytes of the table prefix (whole rows) that is in LDS at off_table
+    uint32_t off_gtable; // MODE_HYBRID: the whole table inside the blob in HBM (after lds_bytes)
     uint32_t off_bpack;  // != 0: the backward automaton has <= 6 states and rides along as packed functions: 8-bit rows
                          // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)
                          // followed by its F area.  The backward walk then needs no state-dependent lookup.

@@ -10,6 +10,7 @@
 //   * ragged rows              -> a PAD column (identity for matches/containedIn, sink for the index walks)
 //   * wasAccepted<X>(state)    -> states renumbered so that accepted(s) == (s >= A0)
 #include "needle_lower.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -320,6 +321,69 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget) {
             mode = MODE_GLOBAL;
             build(mode);
+            // Hot rows in LDS + the whole table in HBM.  Search automata on real text sit in the few states near their
+            // start state (a 1000-keyword union over random text: 99.8 % of the steps are in states of depth <= 3), so
+            // the rows of the first states in breadth-first order are the ones worth the LDS.  The hot prefix is sized
+            // to leave room for 16 waves x 64-byte tiles.  NEEDLE_HYBRID=0: plain HBM table (tests, A/B).
+            static const bool hybrid_on = !(getenv("NEEDLE_HYBRID") && atoi(getenv("NEEDLE_HYBRID")) == 0);
+            const size_t row_bytes = (size_t)n_cols * 2;
+            const bool cols_ok = char_width == 1 || row_bytes <= 255;
+            const size_t room = std::min<size_t>(lds_table_budget, 96u << 10);
+            const size_t fixed = p.hdr.lds_bytes + 64; // column maps (+ backward maps) as just built for the HBM-table layout
+            const size_t hot_rows = room > fixed ? std::min<size_t>((room - fixed) / row_bytes, (size_t)n_dev) : 0;
+            if (hybrid_on && cols_ok && hot_rows >= 32 && n_dev <= 0x8000) {
+                // breadth-first numbering from the start state (0 stays the sink)
+                std::vector<int> bfs(n_ref, -1), order;
+                bfs[0] = 1;
+                order.push_back(0);
+                for (size_t h = 0; h < order.size(); ++h)
+                    for (int k = 0; k < N; ++k) {
+                        const int16_t tgt = d.table[(size_t)order[h] * N + k];
+                        if (tgt >= 0 && bfs[tgt] < 0) {
+                            bfs[tgt] = (int)order.size() + 1;
+                            order.push_back(tgt);
+                        }
+                    }
+                for (int st = 0; st < n_ref; ++st) // (unreachable states, if any, go last)
+                    if (bfs[st] < 0) { bfs[st] = (int)order.size() + 1; order.push_back(st); }
+                auto flagged = [&](int ref_state) { return (uint16_t)(bfs[ref_state] | (d.accepting[ref_state] ? 0x8000 : 0)); };
+                const uint16_t dead_h = contained ? flagged(0) : (uint16_t)0;
+                std::vector<uint16_t> nh((size_t)n_dev * n_cols, 0);
+                for (int st = 0; st < n_ref; ++st) {
+                    uint16_t *row = &nh[(size_t)bfs[st] * n_cols];
+                    if (contained && d.accepting[st]) {
+                        for (int k = 0; k < n_cols; ++k) row[k] = flagged(st);
+                        continue;
+                    }
+                    for (int k = 0; k < N; ++k) {
+                        const int16_t tgt = d.table[(size_t)st * N + k];
+                        row[k] = tgt < 0 ? dead_h : flagged(tgt);
+                    }
+                    row[OVER] = dead_h;
+                    row[PAD] = (which == W_MATCHES || contained) ? flagged(st) : (uint16_t)0;
+                    row[PRE] = flagged(st);
+                }
+                // layout: column maps (element size 2) | hot rows | backward maps || whole table (HBM only)
+                p.blob.clear();
+                p.hdr.off_bcmap = p.hdr.off_bptab = p.hdr.off_bpages = p.hdr.off_btable = p.hdr.off_bpack = 0;
+                if (char_width == 1) {
+                    p.blob.assign(512, 0);
+                    for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, cm.cmap8[c] * 2u);
+                } else {
+                    p.blob.assign(kLdsPages2Table + cm.pages.size(), 0);
+                    for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
+                    for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Table + i] = (uint8_t)(cm.pages[i] * 2u);
+                }
+                p.hdr.hot_bytes = (uint32_t)(hot_rows * row_bytes);
+                p.hdr.off_table = append(p.blob, nh.data(), p.hdr.hot_bytes);
+                emit_backward_maps();
+                while (p.blob.size() % 16) p.blob.push_back(0);
+                p.hdr.lds_bytes = (uint32_t)p.blob.size();
+                p.hdr.off_gtable = append(p.blob, nh.data(), nh.size() * 2);
+                p.hdr.start = flagged(0);
+                p.hdr.accept_lo = 0x8000;
+                mode = MODE_HYBRID;
+            }
         }
     }
     while (p.blob.size() % 16) p.blob.push_back(0);

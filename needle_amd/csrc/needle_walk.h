@@ -126,7 +126,8 @@ struct Walk {
     uint32_t pad_b, pre_b; // pair mode: PAD / PRE as the SECOND char of a pair (pad_e / pre_e: as the first)
     uint32_t table_off; // char_width 2 table modes: LDS byte offset of the table
     uint32_t lane4;     // lane * 4 (byte 0 of the packed-mode F address)
-    const uint16_t *gtable; // MODE_GLOBAL
+    const uint16_t *gtable; // MODE_GLOBAL / MODE_HYBRID: the whole table in HBM
+    uint32_t hot_bytes;     // MODE_HYBRID: bytes of the table prefix held in LDS
 };
 
 template <int CW>
@@ -166,6 +167,25 @@ __device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_r
 template <int MODE, int CW>
 __device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t col) {
     if (MODE == MODE_PACK) return __builtin_amdgcn_ubfe(col, st, 5);
+    if (MODE == MODE_HYBRID) {
+        // st carries the "accepting" flag in bit 15 (so that accepted(s) stays s >= accept_lo = 0x8000 whatever the
+        // numbering); rows of the hot states come from LDS, colder ones through the scalar cache: a per-lane HBM load
+        // would have to be waited for with vmcnt, behind the tile prefetch that is in flight.
+        const uint32_t i = __umul24(st & 0x7FFFu, wk.ncols_e) + col; // byte offset into the table
+        const bool hot = i < wk.hot_bytes;
+        uint32_t v = lds_u16((hot ? i : 0u) + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off));
+        uint64_t cold = __ballot(!hot);
+        while (cold != 0ull) { // rare: one scalar load per cold lane
+            const int l = __builtin_ctzll(cold);
+            cold &= cold - 1ull;
+            const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)i, l);
+            typedef __attribute__((address_space(4))) const uint32_t *cptr_t; // constant address space: s_load_dword
+            const uint32_t word = *(cptr_t)((uintptr_t)wk.gtable + (ci & ~3u));
+            const uint32_t e = (word >> ((ci & 2u) * 8u)) & 0xFFFFu;
+            v = (__lane_id() == (unsigned)l) ? e : v;
+        }
+        return v;
+    }
     const uint32_t i = __umul24(st, wk.ncols_e) + col;
     if (MODE == MODE_GLOBAL) return wk.gtable[i];
     const uint32_t addr = i + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off);

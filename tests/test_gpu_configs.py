@@ -155,9 +155,12 @@ def test_host_buffer_entry_points_match_device_entry_points():
 
 
 @pytest.mark.gpu
-def test_hbm_resident_table_mode_matches_oracle():
-    """MODE_GLOBAL (automaton too large for the 160 KiB LDS): forced through NEEDLE_MAX_PROG_LDS in a child process
-    on the 1k-keyword pattern; same parity bar as the LDS-table mode."""
+@pytest.mark.parametrize("hybrid,lds,mode", [("0", "4096", 3), ("1", "4096", 5), ("1", "20000", 5)])
+def test_hbm_resident_table_modes_match_oracle(hybrid, lds, mode):
+    """Automata too large for the LDS: forced through NEEDLE_MAX_PROG_LDS in a child process on a keyword-union
+    pattern; same parity bar as the LDS-table mode.  Mode 3 = whole table walked out of HBM / L2 (NEEDLE_HYBRID=0);
+    mode 5 = the rows of the first states in breadth-first order in LDS (a few dozen rows at 4 KiB -- most steps then take
+    the cold path through the scalar cache -- or about half the automaton at 20 KB), the whole table in HBM."""
     import subprocess
     import sys
     code = r'''
@@ -169,7 +172,7 @@ from test_compile_matches_txt import oracle_for
 words = W.keywords(300)
 rx = "|".join(words)
 p = DFACompiler.compile(rx, "t", 0)
-assert p.info()["kernel_mode"]["forwards"] == 3, p.info()
+assert p.info()["kernel_mode"]["forwards"] == int(sys.argv[1]), p.info()
 o, _ = oracle_for(rx, 0)
 n = 20000
 rows = W.keyword_batch(torch, words, 5, n, 256, device="cuda")
@@ -185,8 +188,8 @@ assert (unpack_bitmap(fw, n) == of).all() and (fs.cpu().numpy() == ofs).all() an
 print("GLOBAL-MODE-OK")
 '''
     import os
-    env = dict(os.environ, NEEDLE_MAX_PROG_LDS="4096")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+    env = dict(os.environ, NEEDLE_MAX_PROG_LDS=lds, NEEDLE_HYBRID=hybrid)
+    r = subprocess.run([sys.executable, "-c", code, str(mode)], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "GLOBAL-MODE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
