@@ -39,9 +39,41 @@ public final class GpuPattern implements Pattern, AutoCloseable {
         return new GpuPattern(h[0]);
     }
 
+    /** The precompiled-pattern blob -- what Precompile writes as a .class file in the reference (Precompile.java:30-53). */
+    public byte[] toBytes() {
+        byte[] blob = Native.serialize(handle);
+        if (blob == null) {
+            throw new IllegalStateException(Native.lastError());
+        }
+        return blob;
+    }
+
+    public static GpuPattern fromBytes(byte[] blob) {
+        long[] h = new long[1];
+        check(Native.deserialize(blob, h), null);
+        return new GpuPattern(h[0]);
+    }
+
+    /**
+     * A single haystack: one 1-row batch on the GPU per call (tens of microseconds of launch latency) -- correct, and
+     * orders of magnitude slower than the reference's generated class.  Single strings belong on the JVM path; the GPU
+     * earns its keep on the *Batch entry points.
+     */
     @Override
     public Matcher matcher(String s) {
         return new GpuMatcher(handle, s);
+    }
+
+    /**
+     * op 0 matches, 1 containedIn, 2 find over a host batch split across several GPUs of the node (row blocks on 64-row
+     * boundaries; the results are gathered to devices[0] over xGMI and downloaded).  The handle is reusable.
+     */
+    public long[] scanBatchMulti(GpuDevices devices, int op, ByteBuffer rows, int charWidth, long nRows, long rowStride,
+                                 int rowLen, ByteBuffer lengths, int[] start, int[] end) {
+        long[] bitmap = new long[(int) ((nRows + 63) / 64)];
+        check(Native.scanHostMulti(devices.handle(), handle, op, rows, charWidth, nRows, rowStride, rowLen, lengths, bitmap,
+                start, end), null);
+        return bitmap;
     }
 
     /** bit (r &amp; 63) of word (r &gt;&gt; 6) = containedIn() of row r. */

@@ -55,6 +55,23 @@ final class Native {
     static native int findAllHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
                                   java.nio.ByteBuffer lengths, int maxPerRow, int[] counts, int[] start, int[] end, int[] more);
 
+    /** needle_pattern_serialize / needle_pattern_deserialize: the precompiled-pattern blob (Precompile's analogue). */
+    static native byte[] serialize(long handle);
+
+    static native int deserialize(byte[] blob, long[] handleOut);
+
+    /**
+     * Row sharding over several GPUs of one node from this JVM (needle_multi_*): devices[0] is the root the results are
+     * gathered to (one group of RCCL send / receive pairs over xGMI).  scanHostMulti splits a host batch into contiguous
+     * row blocks on 64-row boundaries, one per device; op: 0 matches, 1 containedIn, 2 find.
+     */
+    static native int multiCreate(int[] devices, int flags, long[] handleOut);
+
+    static native void multiDestroy(long multi);
+
+    static native int scanHostMulti(long multi, long pattern, int op, java.nio.ByteBuffer rows, int charWidth, long nRows,
+                                    long rowStride, int rowLen, java.nio.ByteBuffer lengths, long[] bitmap, int[] start, int[] end);
+
     // one Matcher (reference cursor semantics)
     static native int matcherCreate(long pattern, char[] s, long[] handleOut);
 

@@ -168,6 +168,62 @@ NATIVE(jint, packedHost)(JNIEnv *env, jclass c, jlong h, jint op, jcharArray dat
     return rc;
 }
 
+NATIVE(jbyteArray, serialize)(JNIEnv *env, jclass c, jlong h) {
+    size_t need = 0;
+    const needle_pattern *p = (const needle_pattern *)(intptr_t)h;
+    if (needle_pattern_serialize(p, NULL, 0, &need) != NEEDLE_OK || need > 0x7FFFFFFF) return NULL;
+    jbyteArray out = (*env)->NewByteArray(env, (jsize)need);
+    if (!out) return NULL;
+    jbyte *b = (*env)->GetByteArrayElements(env, out, NULL);
+    if (!b) return NULL;
+    int rc = needle_pattern_serialize(p, b, need, &need);
+    (*env)->ReleaseByteArrayElements(env, out, b, 0);
+    return rc == NEEDLE_OK ? out : NULL;
+}
+
+NATIVE(jint, deserialize)(JNIEnv *env, jclass c, jbyteArray blob, jlongArray out) {
+    if (!blob || !out || (*env)->GetArrayLength(env, out) < 1) return NEEDLE_ERR_INVALID;
+    jsize n = (*env)->GetArrayLength(env, blob);
+    jbyte *b = (*env)->GetByteArrayElements(env, blob, NULL);
+    if (!b) return NEEDLE_ERR_INVALID;
+    needle_pattern *p = NULL;
+    int rc = needle_pattern_deserialize(b, (size_t)n, &p); /* validates every length and value itself */
+    (*env)->ReleaseByteArrayElements(env, blob, b, JNI_ABORT);
+    jlong h = (jlong)(intptr_t)p;
+    (*env)->SetLongArrayRegion(env, out, 0, 1, &h);
+    return rc;
+}
+
+NATIVE(jint, multiCreate)(JNIEnv *env, jclass c, jintArray devices, jint flags, jlongArray out) {
+    if (!devices || !out || (*env)->GetArrayLength(env, out) < 1) return NEEDLE_ERR_INVALID;
+    jsize n = (*env)->GetArrayLength(env, devices);
+    jint *d = (*env)->GetIntArrayElements(env, devices, NULL);
+    if (!d) return NEEDLE_ERR_INVALID;
+    needle_multi *m = NULL;
+    int rc = needle_multi_create((const int *)d, (int)n, (unsigned)flags, &m);
+    (*env)->ReleaseIntArrayElements(env, devices, d, JNI_ABORT);
+    jlong h = (jlong)(intptr_t)m;
+    (*env)->SetLongArrayRegion(env, out, 0, 1, &h);
+    return rc;
+}
+NATIVE(void, multiDestroy)(JNIEnv *env, jclass c, jlong m) { needle_multi_destroy((needle_multi *)(intptr_t)m); }
+
+NATIVE(jint, scanHostMulti)(JNIEnv *env, jclass c, jlong m, jlong h, jint op, jobject rows, jint cw, jlong n, jlong stride, jint rowLen,
+                            jobject lengths, jlongArray bitmap, jintArray start, jintArray end) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    if (!bitmap || (*env)->GetArrayLength(env, bitmap) < (jsize)((n + 63) / 64)) return NEEDLE_ERR_INVALID;
+    if (op == 2 && (!start || !end || (*env)->GetArrayLength(env, start) < n || (*env)->GetArrayLength(env, end) < n)) return NEEDLE_ERR_INVALID;
+    jlong *bm = (*env)->GetLongArrayElements(env, bitmap, NULL);
+    jint *s = (op == 2) ? (*env)->GetIntArrayElements(env, start, NULL) : NULL;
+    jint *e = (op == 2) ? (*env)->GetIntArrayElements(env, end, NULL) : NULL;
+    int rc = needle_scan_host_multi((needle_multi *)(intptr_t)m, (const needle_pattern *)(intptr_t)h, op, &v, (uint64_t *)bm, (int32_t *)s, (int32_t *)e);
+    (*env)->ReleaseLongArrayElements(env, bitmap, bm, 0);
+    if (s) (*env)->ReleaseIntArrayElements(env, start, s, 0);
+    if (e) (*env)->ReleaseIntArrayElements(env, end, e, 0);
+    return rc;
+}
+
 NATIVE(jint, matcherCreate)(JNIEnv *env, jclass c, jlong pattern, jcharArray s, jlongArray out) {
     jsize n = (*env)->GetArrayLength(env, s);
     jchar *u = (*env)->GetCharArrayElements(env, s, NULL);

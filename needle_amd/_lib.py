@@ -16,6 +16,8 @@ EXPORTS = [
     "needle_matcher_matches", "needle_matcher_contained_in", "needle_matcher_find", "needle_matcher_find_range",
     "needle_matcher_start", "needle_matcher_end", "needle_rows_from_packed_dev", "needle_matches_packed_host",
     "needle_contained_in_packed_host", "needle_find_packed_host",
+    "needle_multi_create", "needle_multi_destroy", "needle_multi_device_count", "needle_multi_stream", "needle_multi_scan",
+    "needle_multi_sync", "needle_scan_host_multi",
 ]
 
 
@@ -98,6 +100,15 @@ def lib():
     L.needle_matcher_find_range.argtypes = [VP, I, I, P(I)]
     L.needle_matcher_start.argtypes = [VP]
     L.needle_matcher_end.argtypes = [VP]
+    L.needle_multi_create.argtypes = [P(I), I, ctypes.c_uint, P(VP)]
+    L.needle_multi_destroy.argtypes = [VP]
+    L.needle_multi_destroy.restype = None
+    L.needle_multi_device_count.argtypes = [VP]
+    L.needle_multi_stream.argtypes = [VP, I]
+    L.needle_multi_stream.restype = VP
+    L.needle_multi_scan.argtypes = [VP, VP, I, P(BatchView), VP, VP, VP]
+    L.needle_multi_sync.argtypes = [VP]
+    L.needle_scan_host_multi.argtypes = [VP, VP, I, P(BatchView), VP, VP, VP]
     _lib = L
     return L
 

@@ -39,6 +39,10 @@ static int fail(int code, const std::string &msg) {
     return code;
 }
 
+namespace needle {
+int set_error(int code, const std::string &msg) { return fail(code, msg); } // (needle_multi.cpp reports through the same channel)
+} // namespace needle
+
 static int hip_fail(hipError_t e, const char *what) {
     return fail(NEEDLE_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }

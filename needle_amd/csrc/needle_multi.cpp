@@ -1,0 +1,355 @@
+// Row sharding over several devices of one node from ONE host process (config C4): what a JVM host
+// uses.  Rows are independent units (a Matcher is per haystack, DFAClassBuilder.java:669-699), so every device scans
+// its contiguous block of rows with the ordinary kernels on its own stream and there is no data-path collective; the
+// only communication is the gather of the RESULTS to the root device (devices[0]): bitmap words, and for find() the
+// per-row start / end.  Over RCCL that gather is one group of ncclSend / ncclRecv pairs -- every peer sends over its
+// own direct xGMI link to the root (7 links in parallel) -- which is how NCCL / RCCL express a gather.  RCCL is loaded
+// lazily (dlopen) the first time a handle over more than one distinct device is created: single-device use of the
+// library never touches it.  When all shards sit on one device (tests, or oversubscribing one GPU) the gather is a
+// device-to-device copy.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/needle_hip.h"
+
+namespace needle {
+int set_error(int code, const std::string &msg); // needle_api.cpp: the calling thread's needle_last_error()
+}
+
+namespace {
+
+// ---- the few RCCL entry points used, resolved at run time (types as in rccl.h: ncclResult_t / ncclDataType_t are ints,
+// ncclComm_t an opaque pointer; ncclUint64 = 5, ncclInt32 = 2)
+typedef void *comm_t;
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load(std::string &err) {
+        if (h) return true;
+        // a process that already has an RCCL mapped (e.g. PyTorch's bundled one) must keep using that one
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+        }
+        if (!h)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+            }
+        if (!h) {
+            err = std::string("RCCL not found: ") + dlerror();
+            return false;
+        }
+#define NEEDLE_SYM(field, sym)                                                 \
+    *(void **)(&field) = dlsym(h, sym);                                        \
+    if (!field) {                                                              \
+        err = std::string("RCCL symbol missing: ") + sym;                      \
+        return false;                                                          \
+    }
+        NEEDLE_SYM(CommInitAll, "ncclCommInitAll")
+        NEEDLE_SYM(CommDestroy, "ncclCommDestroy")
+        NEEDLE_SYM(GroupStart, "ncclGroupStart")
+        NEEDLE_SYM(GroupEnd, "ncclGroupEnd")
+        NEEDLE_SYM(Send, "ncclSend")
+        NEEDLE_SYM(Recv, "ncclRecv")
+        NEEDLE_SYM(GetErrorString, "ncclGetErrorString")
+#undef NEEDLE_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+constexpr int kNcclInt32 = 2, kNcclUint64 = 5;
+
+int fail(int code, const std::string &msg) { return needle::set_error(code, msg); } // -> needle_last_error()
+
+struct DeviceGuard { // restores the caller's current device
+    int prev = 0;
+    DeviceGuard() { (void)hipGetDevice(&prev); }
+    ~DeviceGuard() { (void)hipSetDevice(prev); }
+};
+
+} // namespace
+
+struct needle_multi {
+    std::vector<int> dev;
+    std::vector<hipStream_t> stream;
+    std::vector<hipEvent_t> done;
+    std::vector<comm_t> comm; // per rank, when RCCL carries the gather
+    bool rccl = false, loopback = false;
+    struct Buf {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+    };
+    std::vector<Buf> local; // per shard: results of a shard that is not written in place (bitmap | start | end)
+};
+
+extern "C" {
+
+int needle_multi_create(const int *devices, int n_devices, unsigned flags, needle_multi **out) {
+    if (!out) return fail(NEEDLE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) return fail(NEEDLE_ERR_INVALID, "devices: 1..64 entries");
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < 1) return fail(NEEDLE_ERR_DEVICE, "no HIP device");
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i) {
+        if (devices[i] < 0 || devices[i] >= have) return fail(NEEDLE_ERR_INVALID, "device index out of range");
+        for (int j = 0; j < i; ++j) distinct = distinct && devices[j] != devices[i];
+    }
+    DeviceGuard guard;
+    needle_multi *m = new needle_multi();
+    m->dev.assign(devices, devices + n_devices);
+    m->stream.assign(n_devices, nullptr);
+    m->done.assign(n_devices, nullptr);
+    m->local.resize(n_devices);
+    m->loopback = (flags & NEEDLE_MULTI_LOOPBACK) != 0;
+    for (int i = 0; i < n_devices; ++i) {
+        hipError_t e = hipSetDevice(m->dev[i]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->done[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            needle_multi_destroy(m);
+            return fail(NEEDLE_ERR_DEVICE, std::string("stream/event creation: ") + hipGetErrorString(e));
+        }
+    }
+    // RCCL carries the gather between distinct devices (and, for tests of the plumbing on a single GPU, a one-rank
+    // communicator sending to itself: NEEDLE_MULTI_LOOPBACK).  Shards that share a device are gathered by copies.
+    if ((n_devices > 1 && distinct) || (m->loopback && n_devices == 1)) {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        std::string err;
+        if (!g_rccl.load(err)) {
+            needle_multi_destroy(m);
+            return fail(NEEDLE_ERR_DEVICE, err);
+        }
+        m->comm.assign(n_devices, nullptr);
+        int rc = g_rccl.CommInitAll(m->comm.data(), n_devices, m->dev.data());
+        if (rc != 0) {
+            m->comm.clear();
+            needle_multi_destroy(m);
+            return fail(NEEDLE_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc));
+        }
+        m->rccl = true;
+    }
+    *out = m;
+    return NEEDLE_OK;
+}
+
+void needle_multi_destroy(needle_multi *m) {
+    if (!m) return;
+    DeviceGuard guard;
+    for (size_t i = 0; i < m->dev.size(); ++i) {
+        (void)hipSetDevice(m->dev[i]);
+        if (i < m->stream.size() && m->stream[i]) (void)hipStreamSynchronize(m->stream[i]);
+        if (i < m->comm.size() && m->comm[i]) (void)g_rccl.CommDestroy(m->comm[i]);
+        if (i < m->local.size() && m->local[i].p) (void)hipFree(m->local[i].p);
+        if (i < m->done.size() && m->done[i]) (void)hipEventDestroy(m->done[i]);
+        if (i < m->stream.size() && m->stream[i]) (void)hipStreamDestroy(m->stream[i]);
+    }
+    delete m;
+}
+
+int needle_multi_device_count(const needle_multi *m) { return m ? (int)m->dev.size() : 0; }
+void *needle_multi_stream(const needle_multi *m, int i) { return (m && i >= 0 && i < (int)m->stream.size()) ? (void *)m->stream[i] : nullptr; }
+
+int needle_multi_sync(needle_multi *m) {
+    if (!m) return fail(NEEDLE_ERR_INVALID, "handle is NULL");
+    DeviceGuard guard;
+    for (size_t i = 0; i < m->dev.size(); ++i) {
+        hipError_t e = hipSetDevice(m->dev[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->stream[i]);
+        if (e != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("stream synchronize: ") + hipGetErrorString(e));
+    }
+    return NEEDLE_OK;
+}
+
+// op: 0 matches, 1 containedIn, 2 find.  shards[g] is resident on devices[g]; every shard but the last holds a multiple
+// of 64 rows (whole bitmap words).  Results land in the root device's buffers, rows in shard order.
+int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const needle_batch_view *shards, uint64_t *d_bitmap,
+                      int32_t *d_start, int32_t *d_end) {
+    if (!m || !p || !shards) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    if (op < 0 || op > 2) return fail(NEEDLE_ERR_INVALID, "op: 0 matches, 1 containedIn, 2 find");
+    const int n = (int)m->dev.size();
+    const bool find = op == 2;
+    if (!d_bitmap || (find && (!d_start || !d_end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    std::vector<uint64_t> row0(n + 1, 0);
+    for (int g = 0; g < n; ++g) {
+        if (shards[g].n_rows && row0[g] % 64 != 0)
+            return fail(NEEDLE_ERR_INVALID, "every shard but the last non-empty one must hold a multiple of 64 rows (whole bitmap words)");
+        row0[g + 1] = row0[g] + shards[g].n_rows;
+    }
+    DeviceGuard guard;
+    auto scan = [&](int g, uint64_t *bm, int32_t *st, int32_t *en) -> int {
+        if (shards[g].n_rows == 0) return NEEDLE_OK;
+        switch (op) {
+        case 0: return needle_matches_dev(p, &shards[g], bm, m->stream[g]);
+        case 1: return needle_contained_in_dev(p, &shards[g], bm, m->stream[g]);
+        default: return needle_find_dev(p, &shards[g], bm, st, en, m->stream[g]);
+        }
+    };
+    struct Part { // where shard g's results sit before the gather (g > 0, or g == 0 in loopback mode)
+        uint64_t *bm;
+        int32_t *st, *en;
+    };
+    std::vector<Part> part(n, Part{nullptr, nullptr, nullptr});
+    for (int g = 0; g < n; ++g) {
+        hipError_t e = hipSetDevice(m->dev[g]);
+        if (e != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        const uint64_t rows = shards[g].n_rows, words = (rows + 63) / 64;
+        const bool in_place = g == 0 && !m->loopback; // the root's own shard is the first block of the result
+        if (in_place) {
+            int rc = scan(g, d_bitmap, d_start, d_end);
+            if (rc) return fail(rc, needle_last_error());
+            continue;
+        }
+        const size_t o_st = (size_t)words * 8, o_en = o_st + (find ? (size_t)rows * 4 : 0), total = o_en + (find ? (size_t)rows * 4 : 0);
+        needle_multi::Buf &b = m->local[g];
+        if (b.cap < total) {
+            if (b.p) {
+                (void)hipStreamSynchronize(m->stream[g]);
+                (void)hipFree(b.p);
+            }
+            b.p = nullptr;
+            b.cap = 0;
+            size_t want = total + total / 4 + 256;
+            if ((e = hipMalloc((void **)&b.p, want)) != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+            b.cap = want;
+        }
+        part[g] = Part{(uint64_t *)b.p, (int32_t *)(b.p + o_st), (int32_t *)(b.p + o_en)};
+        int rc = scan(g, part[g].bm, part[g].st, part[g].en);
+        if (rc) return fail(rc, needle_last_error());
+    }
+    // ---- gather to the root
+    if (m->rccl) {
+        int rc = g_rccl.GroupStart();
+        for (int g = 0; g < n && rc == 0; ++g) {
+            if (!part[g].bm || shards[g].n_rows == 0) continue;
+            const uint64_t rows = shards[g].n_rows, words = (rows + 63) / 64;
+            (void)hipSetDevice(m->dev[g]);
+            rc = g_rccl.Send(part[g].bm, words, kNcclUint64, 0, m->comm[g], m->stream[g]);
+            if (rc == 0 && find) rc = g_rccl.Send(part[g].st, rows, kNcclInt32, 0, m->comm[g], m->stream[g]);
+            if (rc == 0 && find) rc = g_rccl.Send(part[g].en, rows, kNcclInt32, 0, m->comm[g], m->stream[g]);
+            (void)hipSetDevice(m->dev[0]);
+            if (rc == 0) rc = g_rccl.Recv(d_bitmap + row0[g] / 64, words, kNcclUint64, g, m->comm[0], m->stream[0]);
+            if (rc == 0 && find) rc = g_rccl.Recv(d_start + row0[g], rows, kNcclInt32, g, m->comm[0], m->stream[0]);
+            if (rc == 0 && find) rc = g_rccl.Recv(d_end + row0[g], rows, kNcclInt32, g, m->comm[0], m->stream[0]);
+        }
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc == 0) rc = rc2;
+        if (rc != 0) return fail(NEEDLE_ERR_DEVICE, std::string("RCCL gather: ") + g_rccl.GetErrorString(rc));
+    } else {
+        for (int g = 0; g < n; ++g) {
+            if (!part[g].bm || shards[g].n_rows == 0) continue;
+            const uint64_t rows = shards[g].n_rows, words = (rows + 63) / 64;
+            hipError_t e = hipSetDevice(m->dev[g]);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_bitmap + row0[g] / 64, part[g].bm, words * 8, hipMemcpyDefault, m->stream[g]);
+            if (e == hipSuccess && find) e = hipMemcpyAsync(d_start + row0[g], part[g].st, rows * 4, hipMemcpyDefault, m->stream[g]);
+            if (e == hipSuccess && find) e = hipMemcpyAsync(d_end + row0[g], part[g].en, rows * 4, hipMemcpyDefault, m->stream[g]);
+            if (e == hipSuccess) e = hipEventRecord(m->done[g], m->stream[g]);
+            if (e == hipSuccess && g != 0) {
+                (void)hipSetDevice(m->dev[0]);
+                e = hipStreamWaitEvent(m->stream[0], m->done[g], 0); // the root's stream is the one to wait on
+            }
+            if (e != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("gather copy: ") + hipGetErrorString(e));
+        }
+    }
+    return NEEDLE_OK;
+}
+
+// A host batch sharded over the devices: contiguous row blocks on 64-row boundaries, upload, scan, gather to the root,
+// download (PCIe-inclusive; the Java host's one-call form, GpuPattern.*Batch with several devices).
+int needle_scan_host_multi(needle_multi *m, const needle_pattern *p, int op, const needle_batch_view *rows, uint64_t *bitmap,
+                           int32_t *start, int32_t *end) {
+    if (!m || !p || !rows) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    if (rows->char_width != 1 && rows->char_width != 2) return fail(NEEDLE_ERR_INVALID, "char_width must be 1 or 2");
+    if (rows->n_rows == 0) return NEEDLE_OK;
+    if (!rows->rows || !bitmap || (op == 2 && (!start || !end))) return fail(NEEDLE_ERR_INVALID, "buffer is NULL");
+    if (rows->row_len > rows->row_stride) return fail(NEEDLE_ERR_INVALID, "row_len > row_stride");
+    if (rows->lengths)
+        for (uint64_t r = 0; r < rows->n_rows; ++r)
+            if (rows->lengths[r] > rows->row_stride) return fail(NEEDLE_ERR_INVALID, "lengths[r] > row_stride");
+    const int n = (int)m->dev.size();
+    const uint64_t total = rows->n_rows, cw = rows->char_width;
+    uint64_t per = (total + n - 1) / n;
+    per = (per + 63) / 64 * 64;
+    const uint64_t src_stride = rows->row_stride * cw;
+    uint64_t dst_stride = (src_stride + 15) & ~(uint64_t)15;
+    if (dst_stride == 0) dst_stride = 16;
+    DeviceGuard guard;
+    std::vector<needle_batch_view> shards(n);
+    std::vector<void *> d_rows(n, nullptr), d_len(n, nullptr);
+    void *d_bm = nullptr, *d_st = nullptr, *d_en = nullptr;
+    auto cleanup = [&]() {
+        (void)needle_multi_sync(m);
+        for (int g = 0; g < n; ++g) {
+            (void)hipSetDevice(m->dev[g]);
+            if (d_rows[g]) (void)hipFree(d_rows[g]);
+            if (d_len[g]) (void)hipFree(d_len[g]);
+        }
+        (void)hipSetDevice(m->dev[0]);
+        for (void *q : {d_bm, d_st, d_en})
+            if (q) (void)hipFree(q);
+    };
+    auto bail = [&](int code, const std::string &msg) {
+        cleanup();
+        return fail(code, msg);
+    };
+    for (int g = 0; g < n; ++g) {
+        const uint64_t r0 = std::min<uint64_t>((uint64_t)g * per, total), cnt = std::min<uint64_t>(per, total - r0);
+        needle_batch_view &v = shards[g];
+        v = *rows;
+        v.n_rows = cnt;
+        v.row_stride = dst_stride / cw;
+        v.rows = nullptr;
+        v.lengths = nullptr;
+        if (cnt == 0) continue;
+        hipError_t e = hipSetDevice(m->dev[g]);
+        if (e == hipSuccess) e = hipMalloc(&d_rows[g], cnt * dst_stride);
+        const uint8_t *src = (const uint8_t *)rows->rows + r0 * src_stride;
+        if (e == hipSuccess) {
+            if (dst_stride == src_stride) e = hipMemcpyAsync(d_rows[g], src, cnt * src_stride, hipMemcpyHostToDevice, m->stream[g]);
+            else {
+                e = hipMemsetAsync(d_rows[g], 0, cnt * dst_stride, m->stream[g]);
+                if (e == hipSuccess && src_stride)
+                    e = hipMemcpy2DAsync(d_rows[g], dst_stride, src, src_stride, src_stride, cnt, hipMemcpyHostToDevice, m->stream[g]);
+            }
+        }
+        if (e == hipSuccess && rows->lengths) {
+            e = hipMalloc(&d_len[g], cnt * 4);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_len[g], rows->lengths + r0, cnt * 4, hipMemcpyHostToDevice, m->stream[g]);
+        }
+        if (e != hipSuccess) return bail(NEEDLE_ERR_DEVICE, std::string("shard upload: ") + hipGetErrorString(e));
+        v.rows = d_rows[g];
+        v.lengths = (const uint32_t *)d_len[g];
+    }
+    const uint64_t words = (total + 63) / 64;
+    hipError_t e = hipSetDevice(m->dev[0]);
+    if (e == hipSuccess) e = hipMalloc(&d_bm, words * 8);
+    if (e == hipSuccess && op == 2) e = hipMalloc(&d_st, total * 4);
+    if (e == hipSuccess && op == 2) e = hipMalloc(&d_en, total * 4);
+    if (e != hipSuccess) return bail(NEEDLE_ERR_DEVICE, std::string("result buffers: ") + hipGetErrorString(e));
+    int rc = needle_multi_scan(m, p, op, shards.data(), (uint64_t *)d_bm, (int32_t *)d_st, (int32_t *)d_en);
+    if (rc == NEEDLE_OK) rc = needle_multi_sync(m);
+    if (rc) {
+        const std::string msg = needle_last_error();
+        return bail(rc, msg);
+    }
+    (void)hipSetDevice(m->dev[0]);
+    e = hipMemcpy(bitmap, d_bm, words * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && op == 2) e = hipMemcpy(start, d_st, total * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && op == 2) e = hipMemcpy(end, d_en, total * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail(NEEDLE_ERR_DEVICE, std::string("download: ") + hipGetErrorString(e));
+    cleanup();
+    return NEEDLE_OK;
+}
+
+} // extern "C"

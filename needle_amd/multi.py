@@ -1,0 +1,74 @@
+"""Row sharding over several devices from ONE host process: the ctypes mirror of needle_multi_* (include/needle_hip.h).
+This is the entry a JVM host uses (bindings/java GpuPattern.*Batch with several devices); the one-process-per-GPU
+form used by bench.py lives in needle_amd/sharding.py."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import BatchView
+from .pattern import _check
+
+OPS = {"matches": 0, "contained_in": 1, "find": 2}
+
+
+class MultiDevice:
+    def __init__(self, devices, loopback=False):
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = ctypes.c_void_p()
+        _check(_lib.lib().needle_multi_create(arr, len(self.devices), 1 if loopback else 0, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and _lib._lib is not None:
+            _lib._lib.needle_multi_destroy(h)
+
+    def scan(self, pattern, op, shards, lengths=None):
+        """shards: one 2-D device tensor per device (every one but the last with a multiple of 64 rows), lengths: None or
+        one int32 device tensor per shard.  -> (bitmap int64 words, start, end) on the root device (start / end None
+        unless op == "find"), complete when this returns."""
+        import torch
+        n = len(self.devices)
+        assert len(shards) == n
+        views = (BatchView * n)()
+        total = 0
+        for g, t in enumerate(shards):
+            assert t.is_cuda and t.dim() == 2 and t.is_contiguous() and t.device.index == self.devices[g]
+            v = views[g]
+            v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = t.data_ptr(), t.element_size(), t.shape[0], t.shape[1], t.shape[1]
+            if lengths is not None and lengths[g] is not None:
+                assert lengths[g].dtype == torch.int32 and lengths[g].shape == (t.shape[0],) and lengths[g].device == t.device
+                v.lengths = lengths[g].data_ptr()
+            total += t.shape[0]
+        root = torch.device("cuda", self.devices[0])
+        words = torch.empty((total + 63) // 64, dtype=torch.int64, device=root)
+        st = en = None
+        if op == "find":
+            st = torch.empty(total, dtype=torch.int32, device=root)
+            en = torch.empty(total, dtype=torch.int32, device=root)
+        torch.cuda.synchronize()  # the shards were produced on torch's streams; the library runs on its own
+        _check(_lib.lib().needle_multi_scan(self._h, pattern._h, OPS[op], views, words.data_ptr(),
+                                            st.data_ptr() if st is not None else None, en.data_ptr() if en is not None else None))
+        _check(_lib.lib().needle_multi_sync(self._h))
+        return words, st, en
+
+    def scan_host(self, pattern, op, rows, lengths=None):
+        """A host batch (2-D uint8 / uint16 numpy array) split over the devices -> (bitmap uint64 words, start, end)."""
+        rows = np.ascontiguousarray(rows)
+        if rows.dtype == np.int16:
+            rows = rows.view(np.uint16)
+        assert rows.ndim == 2 and rows.dtype in (np.uint8, np.uint16)
+        n, stride = rows.shape
+        v = BatchView()
+        v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.ctypes.data, rows.dtype.itemsize, n, stride, stride
+        if lengths is not None:
+            lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+            v.lengths = lengths.ctypes.data
+        words = np.zeros((n + 63) // 64, dtype=np.uint64)
+        st = np.full(n, -1, dtype=np.int32) if op == "find" else None
+        en = np.full(n, -1, dtype=np.int32) if op == "find" else None
+        _check(_lib.lib().needle_scan_host_multi(self._h, pattern._h, OPS[op], ctypes.byref(v), words.ctypes.data,
+                                                 st.ctypes.data if st is not None else None, en.ctypes.data if en is not None else None))
+        return words, st, en

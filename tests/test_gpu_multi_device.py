@@ -1,0 +1,83 @@
+"""needle_multi_* (include/needle_hip.h): row sharding over several devices from one host process (config C4 as a JVM host
+would drive it).  The GPU box has ONE device, so: (a) several shards on device 0 -- every code path but the RCCL calls
+(per-shard streams and result buffers, the root's in-place first block, the gather into shard order) -- equal to the
+unsharded scan and to the oracle; (b) the RCCL plumbing itself (dlopen, communicator, grouped ncclSend / ncclRecv on the
+shard streams) with a one-rank communicator sending to itself (NEEDLE_MULTI_LOOPBACK)."""
+import numpy as np
+import pytest
+
+from test_gpu_configs import compiled
+
+
+def _batch(n, width=128, seed=3):
+    from needle_amd import workload as W
+    return W.digits_batch(np, seed, n, width)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards,total", [(2, 64 * 500 + 17), (3, 64 * 301), (4, 100), (2, 64)])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_shards_on_one_device_equal_the_unsharded_scan(n_shards, total, ragged):
+    import torch
+    from needle_amd.multi import MultiDevice
+    from needle_amd.pattern import unpack_bitmap
+    from needle_amd.sharding import shard_range
+    p, o = compiled("[0-9]+")
+    host = _batch(total)
+    lens = ((np.arange(total, dtype=np.uint64) * 2654435761) % 129).astype(np.uint32) if ragged else None
+    md = MultiDevice([0] * n_shards)
+    shards, slens = [], []
+    for g in range(n_shards):
+        r0, cnt = shard_range(total, n_shards, g)
+        shards.append(torch.from_numpy(host[r0:r0 + cnt]).cuda().contiguous())
+        slens.append(None if lens is None else torch.from_numpy(lens[r0:r0 + cnt].astype(np.int32)).cuda())
+    rows = torch.from_numpy(host).cuda()
+    tl = None if lens is None else torch.from_numpy(lens.astype(np.int32)).cuda()
+    for op, single in (("matches", p.matches_batch), ("contained_in", p.contained_in_batch), ("find", p.find_batch)):
+        words, st, en = md.scan(p, op, shards, slens if ragged else None)
+        want = single(rows, tl)
+        if op == "find":
+            assert (unpack_bitmap(words, total) == unpack_bitmap(want[0], total)).all()
+            assert (st == want[1]).all() and (en == want[2]).all()
+        else:
+            assert (unpack_bitmap(words, total) == unpack_bitmap(want, total)).all()
+    m, s, e = o.batch_find(host, lens, threads=4)
+    words, st, en = md.scan(p, "find", shards, slens if ragged else None)
+    assert (unpack_bitmap(words, total) == m).all() and (st.cpu().numpy() == s).all() and (en.cpu().numpy() == e).all()
+    # the host form: split, upload, scan, gather, download
+    hw, hs, he = md.scan_host(p, "find", host, lens)
+    assert (unpack_bitmap(hw, total) == m).all() and (hs == s).all() and (he == e).all()
+    assert (unpack_bitmap(md.scan_host(p, "contained_in", host, lens)[0], total) == o.batch_contained_in(host, lens, threads=4)).all()
+
+
+@pytest.mark.gpu
+def test_rccl_gather_plumbing_on_one_device():
+    """One-rank RCCL communicator, the shard's results sent to itself: the same ncclSend / ncclRecv group a multi-GPU
+    handle issues, so dlopen + symbol resolution + stream ordering are exercised on the single-GPU box."""
+    import torch
+    from needle_amd.multi import MultiDevice
+    from needle_amd.pattern import unpack_bitmap
+    p, o = compiled("[0-9]+")
+    total = 64 * 400 + 5
+    host = _batch(total, seed=9)
+    md = MultiDevice([0], loopback=True)
+    rows = torch.from_numpy(host).cuda()
+    m, s, e = o.batch_find(host, threads=4)
+    for _ in range(3):
+        words, st, en = md.scan(p, "find", [rows])
+        assert (unpack_bitmap(words, total) == m).all() and (st.cpu().numpy() == s).all() and (en.cpu().numpy() == e).all()
+    words, _, _ = md.scan(p, "contained_in", [rows])
+    assert (unpack_bitmap(words, total) == o.batch_contained_in(host, threads=4)).all()
+
+
+@pytest.mark.gpu
+def test_multi_argument_errors():
+    import torch
+    from needle_amd.multi import MultiDevice
+    p, _ = compiled("[0-9]+")
+    with pytest.raises(ValueError):
+        MultiDevice([7])  # no such device on the box
+    md = MultiDevice([0, 0])
+    a = torch.zeros((65, 32), dtype=torch.uint8, device="cuda")  # not a multiple of 64 rows in a non-last shard
+    with pytest.raises(ValueError):
+        md.scan(p, "matches", [a, a])
