@@ -3,7 +3,7 @@
 table-walk hot path on the 10M x 256-char synthetic batch.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c3s|c5] [--also c3,c3s,c5|none]
-                    [--rows R] [--scaling strong|weak] [--graph auto|off|scan]
+                    [--rows R] [--scaling strong|weak] [--graph off|scan]
 
 One "step" = one pass of the hot path over the whole device-resident batch: one kernel launch per GPU and, for
 N > 1, the gathers that bring the results to rank 0 (bitmap: one RCCL all-gather; find(): plus a fan-in of start /
@@ -17,6 +17,10 @@ instead); there is no data-path collective.  Rank 0 prints ONE JSON line.
   workloads   the other BASELINE configs measured the same way in the same run (`--also`): c3 (union of 1k keywords,
               find), c3s (its sparse-match variant: keywords of 6..8 chars, only the planted 25 % of the rows match,
               every lane stays live to the end of its row), c5 (BMP class regex over UTF-16, find).
+  N > 1       the gathers are issued by the library itself (needle_multi_*: its own RCCL communicator, ONE call per
+              step, queued on the scan's stream right behind the kernel); torch.distributed only carries the
+              communicator id, the barrier and the max-over-ranks of the clock.  Reported beside the step time: scan_ms,
+              gather_ms (blocking, separately).
   roofline    the scan kernel alone: algorithmic bytes per launch / mean launch duration from HIP events recorded on
               the launch stream inside the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline  the CPU oracle (oracle/needle_walk.c, a port of the reference's generated loops -- NOT the JVM
@@ -207,14 +211,17 @@ def measure(workload, args, ctx, headline):
     def scan(bitmap, start, end):
         op(rows, out=(bitmap, start, end) if is_find else bitmap)
 
-    sh = ShardedScan(scan, total_rows, world, rank, is_find, dev, n_buffers=2)
+    sh = ShardedScan(scan, total_rows, world, rank, is_find, dev, n_buffers=args.buffers, comm=ctx.comm, overlap=args.overlap == "on")
     for _ in range(2):  # first launches: program upload, kernel attributes (never part of a captured graph)
         sh.scan_only()
     torch.cuda.synchronize()
     # Small shards (8 GPUs: 1.25M rows, a ~55 us scan): the scan is launched as a HIP graph so that the per-step host
     # cost is one graph launch instead of the library's argument marshalling + launch.
     graphs = None
-    want_graph = args.graph == "scan" or (args.graph == "auto" and n_rows <= 4_000_000)
+    # (measured on 1.25M-row shards: graph replay 72 us per step against 63 us for plain launches -- the library's launch
+    # path costs the host ~20 us, less than the 57 us scan it overlaps with, and a HIP graph launch is not cheaper.  So
+    # the default is plain launches; --graph scan keeps the experiment reproducible.)
+    want_graph = args.graph == "scan"
     if want_graph and n_rows:
         try:
             graphs = []
@@ -330,8 +337,9 @@ def measure(workload, args, ctx, headline):
         out["scan_ms"] = blocking(lambda: sh.scan_only())
         out["gather_ms"] = blocking(lambda: sh.wait(sh.step())) - out["scan_ms"]
         out["step_ms"] = out["ms_per_step"]
-        out["gather"] = {"bitmap": "all_gather_into_tensor (RCCL), %d B per rank" % (sh.per_words * 8),
-                         "start_end": ("gather to rank 0 (RCCL send/recv fan-in), 2 x %d B per rank" % (sh.per_words * 64 * 4)) if is_find else None,
+        out["gather"] = {"collective": ("ONE gather to rank 0 (RCCL send/recv fan-in) of start | end | bitmap: %d B per rank" % (sh.sets[0]["buf"].numel() * 4)) if is_find
+                                       else ("ONE all-gather (RCCL) of the bitmap words: %d B per rank" % (sh.per_words * 8)),
+                         "issued_by": "libneedle_hip.so (needle_multi_*)" if ctx.comm is not None else "torch.distributed",
                          "note": "gather_ms = blocking (scan + gathers) - blocking scan; inside the timed steps the gathers overlap the next scan"}
     if headline and rank == 0 and world == 1 and not args.no_extras:
         out["roofline"]["device"] = {"name": props.name, "cus": props.multi_processor_count, "clock_mhz_nominal": ENGINE_CLOCK_MHZ}
@@ -382,7 +390,10 @@ def main():
                     "(default: c3,c3s,c5 at 1 GPU, c3 at N > 1; 'none' for profiling runs)")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
-    ap.add_argument("--graph", default="auto", choices=["auto", "off", "scan"], help="launch the scan as a HIP graph (auto: shards of <= 4M rows)")
+    ap.add_argument("--graph", default="off", choices=["off", "scan"], help="launch the scan as a HIP graph (experiment; plain launches are faster)")
+    ap.add_argument("--buffers", type=int, default=2, help="result buffer sets rotating through the steps (N > 1: gathers in flight)")
+    ap.add_argument("--overlap", default="off", choices=["on", "off"], help="N > 1: gather on a side stream beside the next scan (costs ~25 us of event handshakes per step)")
+    ap.add_argument("--collectives", default="rccl", choices=["rccl", "torch"], help="N > 1: gathers through the library's RCCL communicator (default) or torch.distributed")
     ap.add_argument("--regex", default=None, help="tuning runs: another regex over the chosen workload's rows")
     ap.add_argument("--op", default=None, choices=["matches", "contained_in", "find"], help="tuning runs: another op")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -400,7 +411,7 @@ def main():
     torch.cuda.set_device(local)
     ctx.dev = dev = torch.device("cuda", local)
     ctx.use_dist = use_dist = world > 1 or "RANK" in os.environ  # also under `torch.distributed.run --nproc-per-node 1`
-    if world > 1:
+    if use_dist:
         # the scan kernel is one persistent workgroup per CU that owns the CU's whole LDS; leave a few CUs free so
         # that the RCCL kernels gathering the PREVIOUS step's results can run next to it instead of behind it
         os.environ.setdefault("NEEDLE_RESERVE_CUS", "4")
@@ -409,6 +420,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    ctx.comm = None
+    if use_dist and args.collectives == "rccl":
+        # the gathers go through the library's own RCCL communicator (one C call per step); torch.distributed only
+        # carries the communicator id, the barrier and the max-over-ranks reduction of the clock
+        from needle_amd.multi import RankComm
+        ctx.comm = RankComm.from_torch_distributed(dev)
     if args.also is None:
         also = ["c3", "c3s", "c5"] if world == 1 else ["c3"]
         if args.regex or args.op or args.rows != 10_000_000:

@@ -17,7 +17,8 @@ EXPORTS = [
     "needle_matcher_start", "needle_matcher_end", "needle_rows_from_packed_dev", "needle_matches_packed_host",
     "needle_contained_in_packed_host", "needle_find_packed_host",
     "needle_multi_create", "needle_multi_destroy", "needle_multi_device_count", "needle_multi_stream", "needle_multi_scan",
-    "needle_multi_sync", "needle_scan_host_multi",
+    "needle_multi_sync", "needle_scan_host_multi", "needle_multi_unique_id", "needle_multi_create_rank",
+    "needle_multi_all_gather_u64", "needle_multi_gather_i32",
 ]
 
 
@@ -109,6 +110,10 @@ def lib():
     L.needle_multi_scan.argtypes = [VP, VP, I, P(BatchView), VP, VP, VP]
     L.needle_multi_sync.argtypes = [VP]
     L.needle_scan_host_multi.argtypes = [VP, VP, I, P(BatchView), VP, VP, VP]
+    L.needle_multi_unique_id.argtypes = [VP]
+    L.needle_multi_create_rank.argtypes = [VP, I, I, I, P(VP)]
+    L.needle_multi_all_gather_u64.argtypes = [VP, VP, ctypes.c_uint64, VP, VP]
+    L.needle_multi_gather_i32.argtypes = [VP, VP, ctypes.c_uint64, VP, VP]
     _lib = L
     return L
 

@@ -26,9 +26,15 @@ namespace {
 // ---- the few RCCL entry points used, resolved at run time (types as in rccl.h: ncclResult_t / ncclDataType_t are ints,
 // ncclComm_t an opaque pointer; ncclUint64 = 5, ncclInt32 = 2)
 typedef void *comm_t;
+struct UniqueId { // ncclUniqueId: passed BY VALUE to ncclCommInitRank
+    char internal[NEEDLE_UNIQUE_ID_BYTES];
+};
 struct Rccl {
     void *h = nullptr;
     int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(comm_t *, int, UniqueId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(comm_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -56,6 +62,9 @@ struct Rccl {
         return false;                                                          \
     }
         NEEDLE_SYM(CommInitAll, "ncclCommInitAll")
+        NEEDLE_SYM(GetUniqueId, "ncclGetUniqueId")
+        NEEDLE_SYM(CommInitRank, "ncclCommInitRank")
+        NEEDLE_SYM(AllGather, "ncclAllGather")
         NEEDLE_SYM(CommDestroy, "ncclCommDestroy")
         NEEDLE_SYM(GroupStart, "ncclGroupStart")
         NEEDLE_SYM(GroupEnd, "ncclGroupEnd")
@@ -86,6 +95,7 @@ struct needle_multi {
     std::vector<hipEvent_t> done;
     std::vector<comm_t> comm; // per rank, when RCCL carries the gather
     bool rccl = false, loopback = false;
+    int rank = -1, world = 0; // >= 0: one process per device (needle_multi_create_rank): comm[0] is this rank's communicator
     struct Buf {
         uint8_t *p = nullptr;
         size_t cap = 0;
@@ -158,6 +168,82 @@ void needle_multi_destroy(needle_multi *m) {
     delete m;
 }
 
+// ---- one process per device: the communicator is built from an id that rank 0 creates and hands to every rank over any
+// side channel (bench.py: a torch.distributed broadcast); the gathers run on a stream of the caller's choice.
+int needle_multi_unique_id(void *id_out) {
+    if (!id_out) return fail(NEEDLE_ERR_INVALID, "id_out is NULL");
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    std::string err;
+    if (!g_rccl.load(err)) return fail(NEEDLE_ERR_DEVICE, err);
+    UniqueId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return fail(NEEDLE_ERR_DEVICE, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(rc));
+    memcpy(id_out, &id, sizeof(id));
+    return NEEDLE_OK;
+}
+
+int needle_multi_create_rank(const void *unique_id, int rank, int world, int device, needle_multi **out) {
+    if (!out) return fail(NEEDLE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(NEEDLE_ERR_INVALID, "unique_id / rank / world");
+    {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        std::string err;
+        if (!g_rccl.load(err)) return fail(NEEDLE_ERR_DEVICE, err);
+    }
+    DeviceGuard guard;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(NEEDLE_ERR_INVALID, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    needle_multi *m = new needle_multi();
+    m->dev.assign(1, device);
+    m->stream.assign(1, nullptr);
+    m->done.assign(1, nullptr);
+    m->local.resize(1);
+    m->rank = rank;
+    m->world = world;
+    e = hipStreamCreateWithFlags(&m->stream[0], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->done[0], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        needle_multi_destroy(m);
+        return fail(NEEDLE_ERR_DEVICE, std::string("stream/event creation: ") + hipGetErrorString(e));
+    }
+    UniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    m->comm.assign(1, nullptr);
+    const int rc = g_rccl.CommInitRank(&m->comm[0], world, id, rank);
+    if (rc != 0) {
+        m->comm.clear();
+        needle_multi_destroy(m);
+        return fail(NEEDLE_ERR_DEVICE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc));
+    }
+    m->rccl = true;
+    *out = m;
+    return NEEDLE_OK;
+}
+
+// The bitmap words of every rank to every rank (d_recv: world * count words, in rank order), on `stream`.
+int needle_multi_all_gather_u64(needle_multi *m, const uint64_t *d_send, uint64_t count, uint64_t *d_recv, void *stream) {
+    if (!m || m->rank < 0 || !d_send || !d_recv) return fail(NEEDLE_ERR_INVALID, "needs a handle from needle_multi_create_rank and buffers");
+    const int rc = g_rccl.AllGather(d_send, d_recv, (size_t)count, kNcclUint64, m->comm[0], (hipStream_t)stream);
+    if (rc != 0) return fail(NEEDLE_ERR_DEVICE, std::string("ncclAllGather: ") + g_rccl.GetErrorString(rc));
+    return NEEDLE_OK;
+}
+
+// `count` int32 of every rank to rank 0 (d_recv_root: world * count, in rank order; ignored on the other ranks), on
+// `stream`: one group of send / receive pairs, every peer over its own link to the root.
+int needle_multi_gather_i32(needle_multi *m, const int32_t *d_send, uint64_t count, int32_t *d_recv_root, void *stream) {
+    if (!m || m->rank < 0 || !d_send || (m->rank == 0 && !d_recv_root)) return fail(NEEDLE_ERR_INVALID, "needs a handle from needle_multi_create_rank and buffers");
+    int rc = g_rccl.GroupStart();
+    if (rc == 0) rc = g_rccl.Send(d_send, (size_t)count, kNcclInt32, 0, m->comm[0], (hipStream_t)stream);
+    if (m->rank == 0)
+        for (int r = 0; r < m->world && rc == 0; ++r)
+            rc = g_rccl.Recv(d_recv_root + (size_t)r * count, (size_t)count, kNcclInt32, r, m->comm[0], (hipStream_t)stream);
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc == 0) rc = rc2;
+    if (rc != 0) return fail(NEEDLE_ERR_DEVICE, std::string("RCCL gather: ") + g_rccl.GetErrorString(rc));
+    return NEEDLE_OK;
+}
+
 int needle_multi_device_count(const needle_multi *m) { return m ? (int)m->dev.size() : 0; }
 void *needle_multi_stream(const needle_multi *m, int i) { return (m && i >= 0 && i < (int)m->stream.size()) ? (void *)m->stream[i] : nullptr; }
 
@@ -177,6 +263,7 @@ int needle_multi_sync(needle_multi *m) {
 int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const needle_batch_view *shards, uint64_t *d_bitmap,
                       int32_t *d_start, int32_t *d_end) {
     if (!m || !p || !shards) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    if (m->rank >= 0) return fail(NEEDLE_ERR_INVALID, "a per-rank handle gathers with needle_multi_all_gather_u64 / needle_multi_gather_i32");
     if (op < 0 || op > 2) return fail(NEEDLE_ERR_INVALID, "op: 0 matches, 1 containedIn, 2 find");
     const int n = (int)m->dev.size();
     const bool find = op == 2;

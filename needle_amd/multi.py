@@ -72,3 +72,41 @@ class MultiDevice:
         _check(_lib.lib().needle_scan_host_multi(self._h, pattern._h, OPS[op], ctypes.byref(v), words.ctypes.data,
                                                  st.ctypes.data if st is not None else None, en.ctypes.data if en is not None else None))
         return words, st, en
+
+
+class RankComm:
+    """One process per device: this rank's RCCL communicator inside the library (needle_multi_create_rank) and its two
+    gathers.  The id rank 0 creates travels over torch.distributed (any backend); after that a step's communication is
+    ONE C call on a stream of the caller's choice -- no per-step Python collective machinery."""
+
+    def __init__(self, unique_id, rank, world, device_index):
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(unique_id)
+        _check(_lib.lib().needle_multi_create_rank(buf, int(rank), int(world), int(device_index), ctypes.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and _lib._lib is not None:
+            _lib._lib.needle_multi_destroy(h)
+
+    @classmethod
+    def from_torch_distributed(cls, device):
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        on_gpu = dist.get_backend() == "nccl"
+        idt = torch.zeros(128, dtype=torch.uint8, device=device if on_gpu else "cpu")
+        if rank == 0:
+            raw = (ctypes.c_ubyte * 128)()
+            _check(_lib.lib().needle_multi_unique_id(raw))
+            idt.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        return cls(bytes(idt.cpu().numpy().tobytes()), rank, world, torch.device(device).index)
+
+    def all_gather_u64(self, send, recv, stream):
+        _check(_lib.lib().needle_multi_all_gather_u64(self._h, send.data_ptr(), send.numel(), recv.data_ptr(), stream))
+
+    def gather_i32(self, send, recv_root, stream):
+        _check(_lib.lib().needle_multi_gather_i32(self._h, send.data_ptr(), send.numel(),
+                                                  recv_root.data_ptr() if recv_root is not None else None, stream))

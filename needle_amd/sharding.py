@@ -49,6 +49,18 @@ class _Pending:
         return out[:self.n]
 
 
+class _EventPending:
+    """The same for a gather issued on a side stream: wait() orders the current stream behind it."""
+
+    def __init__(self, event, out, n):
+        self.event, self.out, self.n = event, out, n
+
+    def wait(self):
+        if self.event is not None:  # (None: the gather was issued on the current stream itself)
+            torch.cuda.current_stream().wait_event(self.event)
+        return None if self.out is None else self.out[:self.n]
+
+
 def gather_bitmap_async(words, total_rows, world, rank, out=None):
     """Start the all-gather of the per-shard bitmap words; returns a handle whose wait() yields the full bitmap on
     every rank.  The caller may launch further work on its stream before waiting.  `words` may already be the padded
@@ -120,26 +132,44 @@ class ShardedScan:
 
     scan(bitmap, start, end): writes this shard's verdicts into the given buffers (int64 bitmap words; int32 start /
     end, both None unless `is_find`); the buffers are the padded per-shard send buffers themselves, so a step moves
-    no byte more than the collectives do.  `n_buffers` result sets rotate so that step k + 1 may scan while the
-    gathers of step k are still in flight."""
+    no byte more than the collectives do.  matches / containedIn: ONE all-gather of the bitmap words (every rank ends
+    up with the whole bitmap).  find: start, end and the bitmap words sit back to back in ONE send buffer per rank and
+    go to rank 0 in ONE fan-in gather -- one collective call per step either way (on a 1.25M-row shard the scan takes
+    ~0.1 ms; three separately issued collectives cost the host more than that).  `n_buffers` result sets rotate so that
+    step k + 1 may scan while the gather of step k is still in flight."""
 
-    def __init__(self, scan, total_rows, world, rank, is_find, device, n_buffers=2):
+    def __init__(self, scan, total_rows, world, rank, is_find, device, n_buffers=2, comm=None, overlap=None):
+        """comm: a needle_amd.multi.RankComm -- the gather is then ONE call into the library's own RCCL communicator (GPU
+        runs); without it the gather goes through torch.distributed (any backend: the gloo tests).
+        overlap (with comm): issue the gather on a side stream so that the next scan runs beside it.  That costs two
+        cross-stream event handshakes per step -- ~25 us of queue latency, measured on 1.25M-row shards: c2 88 us per step
+        against 63 us with the gather simply queued behind the kernel on the scan's own stream (kernel 55 us), find 120
+        against 101 us -- so the default is the scan's own stream."""
         self.scan, self.total_rows, self.world, self.rank, self.is_find = scan, total_rows, world, rank, is_find
+        self.comm, self.side = comm, None
+        self.overlap = bool(overlap)
+        if comm is not None and self.overlap:
+            self.side = torch.cuda.Stream(device=device)
         self.row0, self.n_rows = shard_range(total_rows, world, rank)
-        self.per_words = _words_per_shard(total_rows, world) if world > 1 or _dist_on() else (total_rows + 63) // 64
-        per_rows = self.per_words * 64
+        self.dist = _dist_on() or comm is not None
+        self.per_words = _words_per_shard(total_rows, world) if world > 1 or self.dist else (total_rows + 63) // 64
+        self.per_rows = per_rows = self.per_words * 64
         self.sets, self.k = [], 0
         for _ in range(n_buffers):
-            s = {"bitmap": torch.zeros(self.per_words, dtype=torch.int64, device=device), "pending": None}
+            s = {"pending": None}
             if is_find:
-                s["start"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
-                s["end"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
-            if _dist_on():  # receive buffers are part of the set: no allocation inside a step
-                cuda = torch.device(device).type == "cuda"
-                s["bitmap_all"] = torch.empty(self.per_words * world, dtype=torch.int64, device=device) if cuda else None
-                if is_find and rank == 0:
-                    s["start_all"] = torch.empty(per_rows * world, dtype=torch.int32, device=device)
-                    s["end_all"] = torch.empty(per_rows * world, dtype=torch.int32, device=device)
+                # [start: per_rows int32 | end: per_rows int32 | bitmap: per_words int64 viewed as int32 pairs]
+                buf = torch.full((2 * per_rows + 2 * self.per_words,), -1, dtype=torch.int32, device=device)
+                buf[2 * per_rows:] = 0
+                s["buf"] = buf
+                s["start"], s["end"] = buf[:per_rows], buf[per_rows:2 * per_rows]
+                s["bitmap"] = buf[2 * per_rows:].view(torch.int64)
+                if (self.dist or comm is not None) and rank == 0:  # the receive buffer is part of the set: no allocation inside a step
+                    s["all"] = torch.empty((world, buf.numel()), dtype=torch.int32, device=device)
+            else:
+                s["bitmap"] = torch.zeros(self.per_words, dtype=torch.int64, device=device)
+                if (self.dist or comm is not None) and torch.device(device).type == "cuda":
+                    s["bitmap_all"] = torch.empty(self.per_words * world, dtype=torch.int64, device=device)
             self.sets.append(s)
 
     def scan_only(self):
@@ -150,35 +180,64 @@ class ShardedScan:
         return s
 
     def step(self, events=None):
-        """Scan + start the gathers; returns the buffer set, whose "pending" handles wait() completes.  events: an
-        optional pair of stream events recorded right before and right after the scan (the gathers run on the
-        collective library's own stream and are not between them)."""
+        """Scan + start the gather; returns the buffer set, whose "pending" handle wait() completes.  events: an
+        optional pair of stream events recorded right before and right after the scan (the gather runs on the
+        collective library's own stream and is not between them)."""
         s = self.sets[self.k % len(self.sets)]
-        if s["pending"] is not None:  # this set's previous gathers must have left before the scan overwrites it
-            for h in s["pending"]:
-                h.wait()
+        if s["pending"] is not None:  # this set's previous gather must have left before the scan overwrites it
+            s["pending"].wait()
         if events is not None:
             events[0].record()
         self.scan_only()
         if events is not None:
             events[1].record()
         self.k += 1
-        pend = [gather_bitmap_async(s["bitmap"], self.total_rows, self.world, self.rank, out=s.get("bitmap_all"))]
-        if self.is_find:
-            pend.append(gather_rows_to_root_async(s["start"], self.total_rows, self.world, self.rank, out=s.get("start_all")))
-            pend.append(gather_rows_to_root_async(s["end"], self.total_rows, self.world, self.rank, out=s.get("end_all")))
-        s["pending"] = pend
+        if not self.dist:
+            s["pending"] = _Pending(None, None, 0, None)
+        elif self.comm is not None:
+            # the library's communicator: right behind the scan on its stream, or on a side stream ordered after it
+            cur = torch.cuda.current_stream()
+            if self.side is not None:
+                self.side.wait_stream(cur)
+            st = (self.side if self.side is not None else cur).cuda_stream
+            if self.is_find:
+                self.comm.gather_i32(s["buf"], s.get("all"), st)
+            else:
+                self.comm.all_gather_u64(s["bitmap"], s["bitmap_all"], st)
+            ev = None
+            if self.side is not None:
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            s["pending"] = _EventPending(ev, None if self.is_find else s["bitmap_all"], (self.total_rows + 63) // 64)
+        elif self.is_find:
+            parts = list(s["all"].unbind(0)) if self.rank == 0 else None
+            s["pending"] = _Pending(dist.gather(s["buf"], gather_list=parts, dst=0, async_op=True), None, 0, parts)
+        else:
+            s["pending"] = gather_bitmap_async(s["bitmap"], self.total_rows, self.world, self.rank, out=s.get("bitmap_all"))
         return s
 
-    @staticmethod
-    def wait(s):
-        """-> (full bitmap words, start, end): the bitmap on every rank, start / end on rank 0 only (None elsewhere,
-        and None for matches / containedIn)."""
-        res = [h.wait() for h in s["pending"]]
-        s["pending"] = None
-        return res[0], (res[1] if len(res) > 1 else None), (res[2] if len(res) > 2 else None)
+    def wait(self, s):
+        """-> (full bitmap words, start, end).  matches / containedIn: the bitmap on every rank.  find: all three on
+        rank 0 (views into the gathered buffer, rows in shard order), None elsewhere."""
+        h, s["pending"] = s["pending"], None
+        n_words = (self.total_rows + 63) // 64
+        if not self.dist:
+            if h is not None:
+                h.wait()
+            return s["bitmap"][:n_words], (s["start"][:self.total_rows] if self.is_find else None), (s["end"][:self.total_rows] if self.is_find else None)
+        if not self.is_find:
+            return h.wait(), None, None
+        h.wait()
+        if self.rank != 0:
+            return None, None, None
+        g, pr = s["all"], self.per_rows
+        start = g[:, :pr].reshape(-1)[:self.total_rows]
+        end = g[:, pr:2 * pr].reshape(-1)[:self.total_rows]
+        bitmap = g[:, 2 * pr:].contiguous().view(torch.int64).reshape(-1)[:n_words]
+        return bitmap, start, end
 
     def drain(self):
         for s in self.sets:
             if s["pending"] is not None:
-                self.wait(s)
+                s["pending"].wait()
+                s["pending"] = None

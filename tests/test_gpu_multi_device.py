@@ -81,3 +81,56 @@ def test_multi_argument_errors():
     a = torch.zeros((65, 32), dtype=torch.uint8, device="cuda")  # not a multiple of 64 rows in a non-last shard
     with pytest.raises(ValueError):
         md.scan(p, "matches", [a, a])
+
+
+@pytest.mark.gpu
+def test_per_rank_handle_gathers_on_a_one_rank_communicator():
+    """needle_multi_create_rank + the two gather calls (what bench.py --gpus N issues per step), world size 1: the id,
+    ncclCommInitRank, ncclAllGather and the grouped send / receive run for real, on a side stream."""
+    import ctypes
+    import torch
+    from needle_amd import _lib
+    from needle_amd.multi import RankComm
+    raw = (ctypes.c_ubyte * 128)()
+    assert _lib.lib().needle_multi_unique_id(raw) == 0
+    comm = RankComm(bytes(raw), 0, 1, 0)
+    side = torch.cuda.Stream()
+    a = torch.arange(1000, dtype=torch.int64, device="cuda") * 7
+    out = torch.zeros(1000, dtype=torch.int64, device="cuda")
+    b = torch.arange(5000, dtype=torch.int32, device="cuda") - 17
+    outb = torch.zeros((1, 5000), dtype=torch.int32, device="cuda")
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_gather_u64(a, out, side.cuda_stream)
+    comm.gather_i32(b, outb, side.cuda_stream)
+    side.synchronize()
+    assert bool((out == a).all()) and bool((outb[0] == b).all())
+
+
+@pytest.mark.gpu
+def test_sharded_scan_step_through_the_library_communicator():
+    """ShardedScan (the bench step) with comm=RankComm at world size 1: find's one-buffer fan-in and the bitmap
+    all-gather, two steps in flight, against the oracle."""
+    import ctypes
+    import torch
+    from needle_amd import _lib
+    from needle_amd.multi import RankComm
+    from needle_amd.pattern import unpack_bitmap
+    from needle_amd.sharding import ShardedScan
+    p, o = compiled("[0-9]+")
+    total = 64 * 300 + 9
+    host = _batch(total, width=256, seed=21)
+    rows = torch.from_numpy(host).cuda()
+    raw = (ctypes.c_ubyte * 128)()
+    assert _lib.lib().needle_multi_unique_id(raw) == 0
+    comm = RankComm(bytes(raw), 0, 1, 0)
+    m, s, e = o.batch_find(host, threads=4)
+    sh = ShardedScan(lambda bm, st, en: p.find_batch(rows, out=(bm, st, en)), total, 1, 0, True, torch.device("cuda", 0), comm=comm)
+    s1, s2 = sh.step(), sh.step()
+    for st_ in (s1, s2):
+        bm, st, en = sh.wait(st_)
+        torch.cuda.synchronize()
+        assert (unpack_bitmap(bm, total) == m).all() and (st.cpu().numpy() == s).all() and (en.cpu().numpy() == e).all()
+    shc = ShardedScan(lambda bm, st, en: p.contained_in_batch(rows, out=bm), total, 1, 0, False, torch.device("cuda", 0), comm=comm)
+    bm, _, _ = shc.wait(shc.step())
+    torch.cuda.synchronize()
+    assert (unpack_bitmap(bm, total) == o.batch_contained_in(host, threads=4)).all()

@@ -54,11 +54,11 @@ def _worker(rank, world, port, total_rows, q):
         s2 = sh.step()
         full, st, en = sh.wait(s1)
         full2, st2, en2 = sh.wait(s2)
-        assert full.shape[0] == (total_rows + 63) // 64 and (full == full2).all()
-        if rank == 0:
+        if rank == 0:  # find: start | end | bitmap fan in to rank 0 in one gather
+            assert full.shape[0] == (total_rows + 63) // 64 and (full == full2).all()
             assert st.shape[0] == total_rows and (st == st2).all() and (en == en2).all()
         else:
-            assert st is None and en is None
+            assert full is None and st is None and en is None
         # the contained_in step (bitmap only) and the plain helpers
         bits = o.batch_contained_in(rows) if n else np.zeros(0, dtype=bool)
 
