@@ -302,23 +302,27 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             uint32_t bs = a.bhdr.start * bscale;
             int32_t lastb = a.bhdr.root_accepting ? cursor : INT_MAX; // :543-547 (LENGTH var = FROM)
             bool active = res;
+            // The text the walk reads: the 32-byte window [snapB | snapA] goes to the lane's own row of the LDS tile
+            // (walked and free by now), so that char p is ONE ds_read at a per-lane address instead of a select chain
+            // over eight registers per char.
+            if (res) {
+                *(lds_u32x4 *)(uintptr_t)(tile.row_addr) = snapB;
+                *(lds_u32x4 *)(uintptr_t)(tile.row_addr + 16u) = snapA;
+            }
+            const int32_t win0 = (snap_pi - 1) * 16;                 // byte offset (in the row) of the window's start
+            const int32_t win_lo = snapB_ok ? 0 : 16;                // first valid byte of the window
             while (__ballot(active) != 0ull) {
                 uint32_t cs[8];
+                const int32_t wb0 = idx_b * CW - win0;               // window offset of char idx_b (< 32)
+                const uint32_t rd = tile.row_addr + (uint32_t)(wb0 - 7 * CW); // chars idx_b - 7 .. idx_b at rd + 0 .. 7 * CW
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int32_t p = idx_b - k;
+                    const uint32_t held = (CW == 1) ? lds_u8(rd + (uint32_t)(7 - k)) : lds_u16(rd + (uint32_t)(7 - k) * 2u);
                     cs[k] = 0;
                     if (active && p >= cursor) {
-                        const uint32_t bp = (uint32_t)p * CW;                 // byte offset of the char in its row
-                        const int32_t rel = snap_pi - (int32_t)(bp >> 4);     // 0: in snapA, 1: in snapB, more: not held
-                        if (rel == 0 || (rel == 1 && snapB_ok)) {
-                            const u32x4 sp = rel == 0 ? snapA : snapB;
-                            const uint32_t d = (bp >> 2) & 3u;
-                            const uint32_t word = d == 0 ? sp[0] : d == 1 ? sp[1] : d == 2 ? sp[2] : sp[3];
-                            cs[k] = (word >> ((bp & 3u) * 8u)) & (CW == 1 ? 0xFFu : 0xFFFFu);
-                        } else {
-                            cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p]; // a match longer than the snapshot
-                        }
+                        if ((uint32_t)(wb0 - k * CW - win_lo) < (uint32_t)(32 - win_lo)) cs[k] = held; // inside the held window
+                        else cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p]; // beyond the snapshot: from memory
                     }
                 }
                 if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton -- 8 independent char -> F lookups, then bfe
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         last = p_last;
         cursor = 0;
         dead = false;
-        snap_pi = INT_MAX / 2; // nothing of the row's earlier text is held: indexBackwards reads it from memory
+        snap_pi = 1 << 24; // (beyond any real piece) nothing of the row's earlier text is held: indexBackwards reads it from memory
         snapB_ok = false;
         carry_ok = false;
         const uint32_t unit = p_ck / NT;
