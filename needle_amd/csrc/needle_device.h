@@ -53,6 +53,11 @@ struct ProgHeader {
     // rest; the backward table itself is walked out of HBM/L2)
     uint32_t off_bcmap, off_bptab, off_bpages;
     uint32_t off_btable; // != 0: the backward uint16 table is small and staged in LDS too (else read bprog from HBM/L2)
+    // MODE_PACK: bit offset of every device state's field (pack_off[0] = 0: the sink), the offsets of the start state
+    // and of the first accepting state (32 = none), the identity function; the same for a packed backward automaton
+    uint8_t pack_off[8];
+    uint32_t start_off, accept_off, ident_fn;
+    uint32_t bpack_start_off, bpack_accept_off;
     uint32_t hot_bytes;  // MODE_HYBRID: bytes of the table prefix (whole rows) that is in LDS at off_table
     uint32_t off_gtable; // MODE_HYBRID: the whole table inside the blob in HBM (after lds_bytes)
     uint32_t off_bpack;  // != 0: the backward automaton has <= 6 states and rides along as packed functions: 8-bit rows

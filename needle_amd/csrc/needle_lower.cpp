@@ -179,7 +179,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         else ++n_full;
     }
     const size_t pack2_bytes = kLdsPagesF2 + n_full * 1024 + (size_t)n_cols * 4;
-    if (n_dev <= 6 && (char_width == 1 || (pack2_bytes <= kMaxPackPagesBytes && pack2_bytes <= lds_table_budget))) mode = MODE_PACK;
+    if (n_dev <= 5 && (char_width == 1 || (pack2_bytes <= kMaxPackPagesBytes && pack2_bytes <= lds_table_budget))) mode = MODE_PACK;
     else if (n_dev <= 256) mode = MODE_TABLE8;
     else mode = MODE_TABLE16;
 
@@ -207,6 +207,8 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         // then 8 independent char -> F lookups and a chain of v_bfe_u32, not 8 x (2-3 dependent lookups)
         const Program pk = lower(t, W_BACKWARDS, char_width, 64u << 10, false, false);
         if (pk.hdr.mode == MODE_PACK && (char_width == 1 || pk.hdr.lds_bytes <= (24u << 10))) {
+            p.hdr.bpack_start_off = pk.hdr.start_off;
+            p.hdr.bpack_accept_off = pk.hdr.accept_off;
             if (char_width == 1) { // the forward layout replicates F per lane (64 KiB): one copy is plenty here
                 std::vector<uint32_t> f(256);
                 for (int c = 0; c < 256; ++c) memcpy(&f[c], &pk.blob[kLdsF1 + 256 * (size_t)c], 4);
@@ -230,9 +232,17 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
 
     if (mode == MODE_PACK) {
         // F: 5-bit field per state at bit 5*s holding 5*next(s): a transition is v_bfe_u32(F, state_field_offset, 5)
+        // field offsets (needle_device.h): non-accepting states (device ids 0 .. accept_lo - 1) at 0, 6, 12, ...;
+        // accepting ones at the odd offsets behind them, 6 apart: n_dev <= 5 keeps the last field inside 32 bits
+        uint32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < n_dev; ++s) off[s] = s < accept_lo ? 6u * s : 6u * accept_lo - 1u + 6u * (s - accept_lo);
+        for (int s = 0; s < 8; ++s) p.hdr.pack_off[s] = (uint8_t)off[s];
+        p.hdr.start_off = off[dev[0]];
+        p.hdr.accept_off = accept_lo < n_dev ? off[accept_lo] : 32u;
+        for (int s = 0; s < n_dev; ++s) p.hdr.ident_fn |= off[s] << off[s];
         auto pack = [&](int col) {
             uint32_t F = 0;
-            for (int s = 0; s < n_dev; ++s) F |= (uint32_t)(5 * next[(size_t)s * n_cols + col]) << (5 * s);
+            for (int s = 0; s < n_dev; ++s) F |= off[next[(size_t)s * n_cols + col]] << off[s];
             return F;
         };
         p.hdr.pad_f = pack(PAD);

@@ -71,10 +71,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     wk.table_off = a.hdr.off_table;
     wk.lane4 = (uint32_t)(lane & 31) * 4u; // lanes l and l+32 are served in different LDS passes: 32 copies suffice
     wk.gtable = (const uint16_t *)(a.prog + (MODE == MODE_HYBRID ? a.hdr.off_gtable : a.hdr.off_table));
-    wk.hot_bytes = a.hdr.hot_bytes;
-    constexpr uint32_t SCALE = (MODE == MODE_PACK) ? 5u : 1u; // state representation scale
-    const uint32_t accept_lo = a.hdr.accept_lo * SCALE;
-    const uint32_t start_state = a.hdr.start * SCALE;
+    wk.hot_last = a.hdr.hot_bytes - 2u;
+    // packed mode: a state is the bit offset of its field in F (needle_device.h)
+    const uint32_t accept_lo = MODE == MODE_PACK ? a.hdr.accept_off : a.hdr.accept_lo;
+    const uint32_t start_state = MODE == MODE_PACK ? a.hdr.start_off : a.hdr.start;
 
     // ---- this wave's LDS tile
     Tile tile;
@@ -239,12 +239,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                 walk_piece<OP, CW, MODE, true>(wk, w, n_in * CPP, rem, skip, accept_lo, st, last_rel);
             }
         } else {
+        constexpr bool HIST = OP == OP_FIND && MODE == MODE_PACK && !GUARD; // accept flags logged, not selected (walk_piece)
+        uint32_t acc_hist = 0;
 #pragma unroll kUnroll
         for (int kk = 0; kk < G::kPieces; ++kk) {
             const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
             if (kk + 1 < G::kPieces) v = tile_piece<CHB>(tile, lane, kk + 1); // next piece: its latency hides below
             const uint32_t p0 = kk * CPP;
-            walk_piece<OP, CW, MODE, GUARD>(wk, w, p0, rem, skip, accept_lo, st, last_rel);
+            walk_piece<OP, CW, MODE, GUARD, HIST>(wk, w, p0, rem, skip, accept_lo, st, last_rel, &acc_hist);
+            if (HIST && ((kk + 1) * CPP) % 32 == 0) {
+                // 32 chars logged: char i of them at bit i.  The last accepting one, if any, is the highest set bit.
+                const int32_t top = 31 - (int32_t)__builtin_clz(acc_hist | 1u);
+                last_rel = acc_hist ? (int32_t)((kk + 1) * CPP - 32) + top + 1 : last_rel;
+                acc_hist = 0;
+            }
         }
         }
         if (OP == OP_FIND) {
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         } else if (res) {
             atomicOr((unsigned long long *)&a.bitmap[my_row >> 6], 1ull << (my_row & 63));
         }
-        if (a.end_state && row_ok) a.end_state[my_row] = st / SCALE; // (speculative stripes: the state at the stripe's end)
+        if (a.end_state && row_ok) a.end_state[my_row] = st; // (speculative stripes, table modes only: the state at the stripe's end)
         if (OP != OP_FIND) return;
         int32_t s = -1;
         const int32_t e = res ? last : -1;
@@ -295,11 +303,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
             const uint16_t *bt = a.hdr.off_btable ? (const uint16_t *)(smem + a.hdr.off_btable)
                                                    : (const uint16_t *)(a.bprog + a.bhdr.off_table);
-            const uint32_t bscale = a.hdr.off_bpack ? 5u : 1u; // packed: a state is the bit offset of its field in F
-            const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo * bscale;
+            // (packed backward automaton: states are field offsets)
+            const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
             const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
             int32_t idx_b = last - 1;
-            uint32_t bs = a.bhdr.start * bscale;
+            uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
             int32_t lastb = a.bhdr.root_accepting ? cursor : INT_MAX; // :543-547 (LENGTH var = FROM)
             bool active = res;
             // The text the walk reads: the 32-byte window [snapB | snapA] goes to the lane's own row of the LDS tile

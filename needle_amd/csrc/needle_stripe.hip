@@ -82,17 +82,32 @@ hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_r
 //           accepting positions: atomicMax per row
 //   start   backward_row_kernel: indexBackwards from lastMatch - 1, one lane per row
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kIdentFn = (0u << 0) | (5u << 5) | (10u << 10) | (15u << 15) | (20u << 20) | (25u << 25);
+// Field offsets of the packed functions (ProgHeader::pack_off): the sink at 0, the other states' fields wherever the
+// lowering put them.  Only the first n_states fields exist.
+struct Fields {
+    uint32_t off[5];
+    uint32_t ident; // the identity function: field i holds off[i]
+    int n;
+};
+__device__ __forceinline__ Fields fields_of(const ProgHeader &h) {
+    Fields f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) f.off[i] = h.pack_off[i];
+    f.ident = h.ident_fn;
+    f.n = (int)h.n_states;
+    return f;
+}
 
 // B after A: field i of the result = B[A[i]]
-__device__ __forceinline__ uint32_t compose_fn(uint32_t a, uint32_t b) {
+__device__ __forceinline__ uint32_t compose_fn(const Fields &fl, uint32_t a, uint32_t b) {
     uint32_t r = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) r |= __builtin_amdgcn_ubfe(b, __builtin_amdgcn_ubfe(a, 5u * i, 5), 5) << (5u * i);
+    for (int i = 0; i < 5; ++i)
+        if (i < fl.n) r |= __builtin_amdgcn_ubfe(b, __builtin_amdgcn_ubfe(a, fl.off[i], 5), 5) << fl.off[i];
     return r;
 }
 
-// NS = device states incl. the sink (2..6).  The sink maps to itself under every char, so only states 1 .. NS-1 are
+// NS = device states incl. the sink (2..5).  The sink maps to itself under every char, so only states 1 .. NS-1 are
 // tracked: NS - 1 v_bfe_u32 per char.
 template <int CW, bool FIND, int NS>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const StripeArgs a) {
@@ -106,7 +121,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
     wk.ncols_e = 0, wk.pad_e = a.hdr.pad_f, wk.pre_e = a.hdr.pre_f, wk.table_off = 0, wk.gtable = nullptr;
     wk.lane4 = (uint32_t)(lane & 31) * 4u;
     constexpr int CPL = 64 / CW; // chars per lane and stripe
-    const uint32_t accept_lo = a.hdr.accept_lo * 5u;
+    const uint32_t accept_lo = a.hdr.accept_off;
+    const Fields fl = fields_of(a.hdr);
+    const uint32_t kIdentFn = fl.ident;
     const uint64_t total = a.n_rows * a.spr;
     for (uint64_t v = (uint64_t)blockIdx.x * kWavesPerBlock + wave; v < total; v += (uint64_t)gridDim.x * kWavesPerBlock) {
         const uint64_t row = v / a.spr;
@@ -129,9 +146,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
                 if (off + 16u * j < a.stride_bytes) d[j] = *(const u32x4 *)(p + 16 * j);
         }
         // the per-char functions of this lane's chars (kept for the second walk of FIND)
-        uint32_t g[6];
+        uint32_t g[NS];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) g[i] = 5u * i; // fields NS .. 5 stay identity (never a real state)
+        for (int i = 0; i < NS; ++i) g[i] = fl.off[i];
         const bool full = __ballot(n_valid != (uint32_t)CPL) == 0ull;
         auto walk_all = [&](auto per_char) __attribute__((always_inline)) {
 #pragma unroll
@@ -168,13 +185,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
         }
         uint32_t fn = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) fn |= g[i] << (5u * i);
+        for (int i = 0; i < NS; ++i) fn |= g[i] << fl.off[i];
         // ordered inclusive scan over the lanes: after step d lane l holds the function of lanes l-2d+1 .. l
         uint32_t incl = fn;
 #pragma unroll
         for (int dlt = 1; dlt < 64; dlt <<= 1) {
             const uint32_t left = (uint32_t)__shfl_up((int)incl, dlt);
-            if (lane >= dlt) incl = compose_fn(left, incl);
+            if (lane >= dlt) incl = compose_fn(fl, left, incl);
         }
         if (!FIND) {
             if (lane == 63) a.fn[v] = incl;
@@ -211,7 +228,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
 // row walking 262144 stripes of a 1 GiB row one dependent load at a time took 25 ms.)
 __global__ __launch_bounds__(1024) void stripe_prefix_kernel(const StripeArgs a) {
     __shared__ uint32_t wave_total[16];
-    const uint32_t accept_lo = a.hdr.accept_lo * 5u;
+    const uint32_t accept_lo = a.hdr.accept_off;
+    const Fields fl = fields_of(a.hdr);
+    const uint32_t kIdentFn = fl.ident;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = (blockDim.x + 63) >> 6;
     const uint32_t per = (a.spr + blockDim.x - 1) / blockDim.x; // stripes per thread
     for (uint64_t row = blockIdx.x; row < a.n_rows; row += gridDim.x) {
@@ -219,21 +238,21 @@ __global__ __launch_bounds__(1024) void stripe_prefix_kernel(const StripeArgs a)
         const uint32_t s0 = (uint32_t)tid * per < a.spr ? (uint32_t)tid * per : a.spr;
         const uint32_t s1 = s0 + per < a.spr ? s0 + per : a.spr;
         uint32_t mine = kIdentFn;
-        for (uint32_t s = s0; s < s1; ++s) mine = compose_fn(mine, fn[s]);
+        for (uint32_t s = s0; s < s1; ++s) mine = compose_fn(fl, mine, fn[s]);
         uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t left = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl = compose_fn(left, incl);
+            if (lane >= d) incl = compose_fn(fl, left, incl);
         }
         if (lane == 63) wave_total[wave] = incl;
         __syncthreads();
         uint32_t before = kIdentFn; // everything in the waves before this one
-        for (int w = 0; w < wave; ++w) before = compose_fn(before, wave_total[w]);
+        for (int w = 0; w < wave; ++w) before = compose_fn(fl, before, wave_total[w]);
         uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
         if (lane == 0) excl = kIdentFn;
-        excl = compose_fn(before, excl);
-        uint32_t q = __builtin_amdgcn_ubfe(excl, a.hdr.start * 5u, 5);
+        excl = compose_fn(fl, before, excl);
+        uint32_t q = __builtin_amdgcn_ubfe(excl, a.hdr.start_off, 5);
         for (uint32_t s = s0; s < s1; ++s) {
             const uint32_t f = fn[s];
             fn[s] = q;
@@ -306,8 +325,7 @@ static hipError_t launch_stripe_n(const StripeArgs &a, dim3 grid, size_t lds, hi
     case 0: case 1: case 2: return launch_stripe<CW, FIND, 2>(a, grid, lds, stream);
     case 3: return launch_stripe<CW, FIND, 3>(a, grid, lds, stream);
     case 4: return launch_stripe<CW, FIND, 4>(a, grid, lds, stream);
-    case 5: return launch_stripe<CW, FIND, 5>(a, grid, lds, stream);
-    default: return launch_stripe<CW, FIND, 6>(a, grid, lds, stream);
+    default: return launch_stripe<CW, FIND, 5>(a, grid, lds, stream); // packed mode has at most 5 states
     }
 }
 
@@ -593,8 +611,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
     wk.table_off = a.hdr.off_table;
     wk.lane4 = (uint32_t)(lane & 31) * 4u;
     wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
-    constexpr uint32_t SCALE = (MODE == MODE_PACK) ? 5u : 1u;
-    const uint32_t accept_lo = a.hdr.accept_lo * SCALE, start_state = a.hdr.start * SCALE;
+    const uint32_t accept_lo = MODE == MODE_PACK ? a.hdr.accept_off : a.hdr.accept_lo;
+    const uint32_t start_state = MODE == MODE_PACK ? a.hdr.start_off : a.hdr.start;
     constexpr int CPP = 16 / CW;
     const uint32_t n_pieces = (uint32_t)(a.stride_bytes >> 4); // 1..4, wave-uniform
     const uint64_t n_groups = (a.n_rows + 63) >> 6;

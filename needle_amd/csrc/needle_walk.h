@@ -127,7 +127,7 @@ struct Walk {
     uint32_t table_off; // char_width 2 table modes: LDS byte offset of the table
     uint32_t lane4;     // lane * 4 (byte 0 of the packed-mode F address)
     const uint16_t *gtable; // MODE_GLOBAL / MODE_HYBRID: the whole table in HBM
-    uint32_t hot_bytes;     // MODE_HYBRID: bytes of the table prefix held in LDS
+    uint32_t hot_last;      // MODE_HYBRID: byte offset of the last table entry held in LDS (hot_bytes - 2)
 };
 
 template <int CW>
@@ -172,9 +172,10 @@ __device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t 
         // numbering); rows of the hot states come from LDS, colder ones through the scalar cache: a per-lane HBM load
         // would have to be waited for with vmcnt, behind the tile prefetch that is in flight.
         const uint32_t i = __umul24(st & 0x7FFFu, wk.ncols_e) + col; // byte offset into the table
-        const bool hot = i < wk.hot_bytes;
-        uint32_t v = lds_u16((hot ? i : 0u) + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off));
-        uint64_t cold = __ballot(!hot);
+        // every lane reads LDS (cold lanes a clamped, harmless address: v_min instead of compare + select + add) ...
+        const uint32_t ih = i < wk.hot_last ? i : wk.hot_last;
+        uint32_t v = lds_u16(ih + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off));
+        uint64_t cold = __ballot(i > wk.hot_last);                  // ... and the cold ones are patched below
         while (cold != 0ull) { // rare: one scalar load per cold lane
             const int l = __builtin_ctzll(cold);
             cold &= cold - 1ull;
@@ -195,9 +196,13 @@ __device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t 
 // One 16-byte piece of one row: w = its four dwords, p0 = index of its first char inside the tile (or row), rem /
 // skip = GUARD: chars of the row from the tile start on / chars before the find() cursor, st = the automaton state
 // (5 * id in packed mode), last_rel = OP_FIND: index + 1 of the last accepting char seen (same origin as p0).
-template <int OP, int CW, int MODE, bool GUARD>
+// HIST (packed mode, find() on full rows): instead of "last_rel = accepted ? position : last_rel" -- two VALU ops per
+// char in a walk that is VALU-issue bound -- every char's accept flag, which is bit 0 of the packed state (accepting
+// states sit at odd field offsets), is shifted into acc_hist with ONE v_alignbit_b32; the caller turns the log into a
+// position every 32 chars (char i of the 32 at bit i).
+template <int OP, int CW, int MODE, bool GUARD, bool HIST = false>
 __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4], uint32_t p0, uint32_t rem, uint32_t skip,
-                                           uint32_t accept_lo, uint32_t &st, int32_t &last_rel) {
+                                           uint32_t accept_lo, uint32_t &st, int32_t &last_rel, uint32_t *acc_hist = nullptr) {
     constexpr int CPP = 16 / CW; // chars per 16-byte piece
     // Table modes are bound by LDS cycles, not by issue: a lane whose verdict is already final (sink, or
     // accepted for containedIn) is masked out of the piece's lookups, so its LDS passes and the bank
@@ -301,6 +306,15 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
                 lr = acc ? pos : lr;
             }
         }
+    } else if (HIST) {
+        uint32_t h = *acc_hist;
+#pragma unroll
+        for (int i = 0; i < CPP; ++i) {
+            st = apply<MODE, CW>(wk, st, col[i]);
+            h = __builtin_amdgcn_alignbit(st, h, 1); // ({st, h} >> 1): the accept flag enters at bit 31
+        }
+        *acc_hist = h;
+        return;
     } else
 #pragma unroll
     for (int i = 0; i < CPP; ++i) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses a scripts/profile_c2.sh output directory (gpurun_out/prof_<w>) into profiles/r<NN>_<w>.json + .md:
+"""Condenses a scripts/profile.sh output directory (gpurun_out/prof_<w>) into profiles/r<NN>_<w>.json + .md:
 kernel-trace stats of needle::scan_kernel and the HBM traffic counters, corrected as MI355X_MICROARCH.md
 prescribes (FETCH_SIZE is in KiB and reports exactly 1/2 of a wide coalesced stream on gfx950 -> x2; WRITE_SIZE
 in KiB, uncalibrated)."""
@@ -64,6 +64,8 @@ out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / alg
 out["achieved_GBs_from_trace_avg"] = alg / out["avg_ns"]
 os.makedirs("profiles", exist_ok=True)
 base = os.path.join("profiles", "r%s_%s" % (rnd, w))
+import shutil
+shutil.copyfile(os.path.join(src, "trace", "t_kernel_stats.csv"), base + "_kernel_stats.csv")  # rocprofv3's own table, verbatim
 json.dump(out, open(base + ".json", "w"), indent=1)
 with open(base + ".md", "w") as f:
     f.write("# rocprofv3 summary, round %s, workload %s\n\n" % (rnd, w))
