@@ -60,7 +60,12 @@ struct ProgHeader {
     uint32_t bpack_start_off, bpack_accept_off;
     uint32_t hot_bytes;  // MODE_HYBRID: bytes of the table prefix (whole rows) that is in LDS at off_table
     uint32_t off_gtable; // MODE_HYBRID: the whole table inside the blob in HBM (after lds_bytes)
-    uint32_t off_bpack;  // != 0: the backward automaton has <= 6 states and rides along as packed functions: 8-bit rows
+    uint32_t off_bsp_bm; // != 0: a backward automaton too big for a dense table in LDS but SPARSE (a reversed keyword trie:
+                         // 1704 live transitions in 720 x 31 cells) rides along popcount-compressed: uint32 bitmap[state]
+                         // of the columns with a live target here, uint16 base[state] at off_bsp_base, and the live targets
+                         // back to back at off_bsp_edges: next = bit(col) ? edges[base + popcount(bitmap below col)] : sink
+    uint32_t off_bsp_base, off_bsp_edges;
+    uint32_t off_bpack;  // != 0: the backward automaton has <= 5 states and rides along as packed functions: 8-bit rows
                          // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)
                          // followed by its F area.  The backward walk then needs no state-dependent lookup.
 };

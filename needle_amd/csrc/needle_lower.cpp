@@ -203,6 +203,30 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         const Program bp = lower(t, W_BACKWARDS, char_width, lds_table_budget, true, false);
         const size_t tbytes = bp.blob.size() - bp.hdr.off_table;
         if (tbytes <= 2048) p.hdr.off_btable = append(p.blob, bp.blob.data() + bp.hdr.off_table, tbytes);
+        else if (bp.hdr.n_cols <= 32 && mode != MODE_GLOBAL && mode != MODE_HYBRID) {
+            // (when the FORWARD table itself overflows the LDS, every byte goes to its hot rows instead)
+            // a big but sparse backward table (most cells lead to the sink): popcount-compressed rows, if they still fit
+            // beside the forward program and 16 waves of 64-byte tiles (else the dense table is walked out of HBM / L2:
+            // a chain of L2 round trips per matched row)
+            const uint16_t *bt = (const uint16_t *)(bp.blob.data() + bp.hdr.off_table);
+            const uint32_t bn = bp.hdr.n_states, bc = bp.hdr.n_cols;
+            std::vector<uint32_t> bm(bn, 0);
+            std::vector<uint16_t> base(bn, 0), edges;
+            for (uint32_t st = 0; st < bn; ++st) {
+                base[st] = (uint16_t)edges.size();
+                for (uint32_t c = 0; c < bc; ++c)
+                    if (bt[(size_t)st * bc + c] != 0) {
+                        bm[st] |= 1u << c;
+                        edges.push_back(bt[(size_t)st * bc + c]);
+                    }
+            }
+            const size_t sparse_bytes = bm.size() * 4 + base.size() * 2 + edges.size() * 2 + 64;
+            if (edges.size() < 65536 && p.blob.size() + sparse_bytes <= (96u << 10) && p.blob.size() + sparse_bytes <= lds_table_budget) {
+                p.hdr.off_bsp_bm = append(p.blob, bm.data(), bm.size() * 4);
+                p.hdr.off_bsp_base = append(p.blob, base.data(), base.size() * 2);
+                p.hdr.off_bsp_edges = append(p.blob, edges.data(), edges.size() * 2);
+            }
+        }
         // ... and a backward automaton of <= 6 states as packed functions (same device numbering as `bp`): its walk is
         // then 8 independent char -> F lookups and a chain of v_bfe_u32, not 8 x (2-3 dependent lookups)
         const Program pk = lower(t, W_BACKWARDS, char_width, 64u << 10, false, false);

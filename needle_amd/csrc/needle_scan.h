@@ -362,7 +362,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                             active = false;
                         } else {
                             const uint32_t col = column_of<CW>(bcmap, bptab, bpages, cs[k]);
-                            bs = bt[bs * bcols + col];
+                            if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
+                                const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
+                                const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col) - 1u));
+                                const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
+                                bs = ((bm >> col) & 1u) ? tgt : 0u;
+                            } else {
+                                bs = bt[bs * bcols + col];
+                            }
                             if (bs == 0) {
                                 active = false;
                             } else {
