@@ -8,6 +8,15 @@ mkdir -p $OUT
 i=0
 for grp in "$@"; do
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p -- python bench.py --workload $W $NEEDLE_BENCH_EXTRA --steps 3 --warmup 1 --also none --no-cpu-baseline --no-extras > $OUT/p$i.json 2> $OUT/p$i.log
+  # only the scan kernel's counter rows are kept: gpurun copies back at most 64 MiB
+  python - "$OUT/p$i/p_counter_collection.csv" <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "scan_kernel" in r["Kernel_Name"]]
+if rows:
+    w = csv.DictWriter(open(sys.argv[1], "w", newline=""), fieldnames=list(rows[0].keys()))
+    w.writeheader(); w.writerows(rows)
+PY
+  rm -f $OUT/p$i/p_kernel_trace.csv $OUT/p$i/p_agent_info.csv
   i=$((i+1))
 done
 python - <<PY

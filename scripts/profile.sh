@@ -13,5 +13,16 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python bench.py --workload $W --steps 5 --warmup 1 --also none --no-cpu-baseline --no-extras > $OUT/bench_write.json 2> $OUT/write.log
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $OUT/ea -o e -- python bench.py --workload $W --steps 5 --warmup 1 --also none --no-cpu-baseline --no-extras > $OUT/bench_ea.json 2> $OUT/ea.log
 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/eaw -o e -- python bench.py --workload $W --steps 5 --warmup 1 --also none --no-cpu-baseline --no-extras > $OUT/bench_eaw.json 2> $OUT/eaw.log
-find $OUT -name "*.csv" | head -20
-ls -la $OUT/*/* | head -30
+# keep what summarize_profile.py reads (gpurun copies back at most 64 MiB): the stats table and the scan kernel's counter rows
+python - $OUT <<'PY'
+import csv, glob, os, sys
+for f in glob.glob(os.path.join(sys.argv[1], "*", "*_counter_collection.csv")):
+    rows = [r for r in csv.DictReader(open(f)) if "scan_kernel" in r["Kernel_Name"]]
+    if rows:
+        w = csv.DictWriter(open(f, "w", newline=""), fieldnames=list(rows[0].keys()))
+        w.writeheader(); w.writerows(rows)
+for pat in ("*_kernel_trace.csv", "*_agent_info.csv", "*_domain_stats.csv"):
+    for f in glob.glob(os.path.join(sys.argv[1], "*", pat)):
+        os.remove(f)
+PY
+du -sh $OUT

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc_<workload>_<tag>/ (scripts/pmc.sh) -> profiles/r02_pmc.md; gpurun_out/prof_aux (scripts/profile_aux.sh)
+-> profiles/r02_aux_kernels.md + the kernel-stats tables."""
+import collections
+import csv
+import glob
+import os
+import shutil
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def summ(d):
+    agg, dur = collections.defaultdict(list), []
+    for f in sorted(glob.glob(os.path.join(root, "gpurun_out", d, "p*", "p_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            if "scan_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {k: sum(v) / len(v) for k, v in agg.items()}
+    out["kernel_us"] = sum(dur) / len(dur) / 1e3 if dur else None
+    return out
+
+
+sets = [("c3 find, round-1 kernel (before)", "pmc_c3_r2before"),
+        ("c3 find, round 2: survivor pool, LDS-window + popcount-compressed backward walk", "pmc_c3_r2after"),
+        ("c3s find (sparse-match variant): hot rows in LDS + HBM table", "pmc_c3s_r2after"),
+        ("c5 find, first step of round 2 (F in the pages, u32 page table)", "pmc_c5_r2a"),
+        ("c5 find, round 2: ptab64 + constant pages, accept-flag log, packed backward", "pmc_c5_r2after")]
+keys = ["kernel_us", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+        "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
+rows = [(n, summ(d)) for n, d in sets]
+rows = [(n, r) for n, r in rows if r.get("kernel_us")]
+
+
+def cu(r):
+    return r["GRBM_GUI_ACTIVE"] / 8 * 256 if r.get("GRBM_GUI_ACTIVE") else None
+
+
+def cell(r, f):
+    try:
+        return f(r)
+    except (KeyError, TypeError, ZeroDivisionError):
+        return "—"
+
+
+with open(os.path.join(root, "profiles", "r02_pmc.md"), "w") as f:
+    f.write("# PMC summaries, round 2 (`rocprofv3 --kernel-trace --pmc ...`, one counter group per pass: `scripts/pmc.sh`; this table: `scripts/summarize_pmc.py`)\n\n")
+    f.write("Per launch of `needle::scan_kernel` on the 10M x 256 batch, mean over the launches of a 3-step bench run.  `GRBM_GUI_ACTIVE` is summed "
+            "over the 8 XCDs (÷ 8 = kernel cycles); SQ wave / wait counters are in quad-cycles; `SQ_LDS_IDX_ACTIVE` / `SQ_LDS_BANK_CONFLICT` in LDS "
+            "cycles summed over all CUs.  Runs under the profiler are 3-8 % slower than the bench line.\n\n")
+    f.write("| counter | " + " | ".join(n for n, _ in rows) + " |\n|---|" + "---|" * len(rows) + "\n")
+    for k in keys:
+        f.write("| `%s` | " % k + " | ".join(("%.4g" % r[k]) if r.get(k) is not None else "—" for _, r in rows) + " |\n")
+    f.write("\nDerived (CU-cycles = GRBM_GUI_ACTIVE / 8 x 256 CUs):\n\n| | " + " | ".join(n for n, _ in rows) + " |\n|---|" + "---|" * len(rows) + "\n")
+    f.write("| LDS array busy | " + " | ".join(cell(r, lambda r: "%.0f %%" % (100 * r["SQ_LDS_IDX_ACTIVE"] / cu(r))) for _, r in rows) + " |\n")
+    f.write("| bank-conflict share of LDS cycles | " + " | ".join(cell(r, lambda r: "%.0f %%" % (100 * r["SQ_LDS_BANK_CONFLICT"] / r["SQ_LDS_IDX_ACTIVE"])) for _, r in rows) + " |\n")
+    f.write("| VALU busy (4 cycles per wave64 op, 4 SIMDs per CU) | " + " | ".join(cell(r, lambda r: "%.0f %%" % (100 * r["SQ_INSTS_VALU"] / cu(r))) for _, r in rows) + " |\n")
+    f.write("| waves parked in s_waitcnt | " + " | ".join(cell(r, lambda r: "%.0f %%" % (100 * r["SQ_WAIT_ANY"] / r["SQ_WAVE_CYCLES"])) for _, r in rows) + " |\n")
+    f.write("| VALU instructions per char-wave (4e7 char-waves per launch) | " + " | ".join(cell(r, lambda r: "%.2f" % (r["SQ_INSTS_VALU"] / 4e7)) for _, r in rows) + " |\n")
+    f.write("| LDS instructions per char-wave | " + " | ".join(cell(r, lambda r: "%.2f" % (r["SQ_INSTS_LDS"] / 4e7)) for _, r in rows) + " |\n")
+    f.write("| scalar-cache loads per char-wave (cold table entries) | " + " | ".join(cell(r, lambda r: "%.2f" % (r["SQ_INSTS_SMEM"] / 4e7)) for _, r in rows) + " |\n")
+
+aux = os.path.join(root, "gpurun_out", "prof_aux")
+if os.path.isdir(aux):
+    for d, name in (("short16", "short_rows_16B"), ("short64", "short_rows_64B"), ("long", "long_rows_1000x1MiB")):
+        shutil.copyfile(os.path.join(aux, d, "t_kernel_stats.csv"), os.path.join(root, "profiles", "r02_%s_kernel_stats.csv" % name))
+    with open(os.path.join(root, "profiles", "r02_aux_kernels.md"), "w") as f:
+        f.write("# Short-row and stripe kernels, round 2\n\n`scripts/profile_aux.sh`: `rocprofv3 --kernel-trace --stats -- python scripts/short_rows_rate.py 16|64` and "
+                "`... scripts/long_rows_rate.py 1000 1` ('[0-9]+'; 2.56 GB of rows of 16 / 64 bytes; 1000 rows of 1 MiB).  Rates printed by the scripts under the profiler:\n\n```\n")
+        for d in ("short16", "short64", "long"):
+            f.write("".join(line for line in open(os.path.join(aux, d + ".log")) if "amdgpu.ids" not in line))
+        f.write("```\n\nKernel tables (rocprofv3's `*_kernel_stats.csv`, verbatim): `r02_short_rows_16B_kernel_stats.csv`, `r02_short_rows_64B_kernel_stats.csv` "
+                "(`needle::short_kernel<OP, CW, MODE>`), `r02_long_rows_1000x1MiB_kernel_stats.csv` (`needle::stripe_kernel<CW, FIND, NS>`, `stripe_prefix_kernel`).\n")
+print(open(os.path.join(root, "profiles", "r02_pmc.md")).read())
