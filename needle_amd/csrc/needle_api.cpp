@@ -960,14 +960,8 @@ int needle_find_all_dev(const needle_pattern *p, const needle_batch_view *v, uin
     }
     return done(NEEDLE_OK);
 }
-int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
-                         int32_t *end, int *more) {
-    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
-    int rc = check_view(v, false);
-    if (rc) return rc;
-    if (more) *more = 0;
-    if (v->n_rows == 0) return NEEDLE_OK;
-    if (!counts || (slots && (!start || !end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+static int find_all_host_one(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
+                             int32_t *end, int *more) {
     const size_t cw = v->char_width, n = (size_t)v->n_rows;
     const size_t src_stride = (size_t)v->row_stride * cw;
     size_t dst_stride = (src_stride + 15) & ~(size_t)15;
@@ -995,13 +989,39 @@ int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, ui
     dv.rows = d;
     dv.lengths = v->lengths ? (const uint32_t *)(d + o_len) : nullptr;
     dv.row_stride = dst_stride / cw;
-    rc = needle_find_all_dev(p, &dv, slots, (uint32_t *)(d + o_cnt), (int32_t *)(d + o_s), (int32_t *)(d + o_e), more, nullptr);
+    int rc = needle_find_all_dev(p, &dv, slots, (uint32_t *)(d + o_cnt), (int32_t *)(d + o_s), (int32_t *)(d + o_e), more, nullptr);
     if (rc) return done(rc);
     e = hipMemcpy(counts, d + o_cnt, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && slots) e = hipMemcpy(start, d + o_s, n * slots * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && slots) e = hipMemcpy(end, d + o_e, n * slots * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return done(hip_fail(e, "find_all_host download"));
     return done(NEEDLE_OK);
+}
+
+// (like the other host entry points: at most ~2 GiB of rows + results resident on the device at a time)
+int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
+                         int32_t *end, int *more) {
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, false);
+    if (rc) return rc;
+    if ((rc = check_host_lengths(v))) return rc;
+    if (more) *more = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!counts || (slots && (!start || !end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    static const uint64_t kHostChunkBytes = getenv("NEEDLE_HOST_CHUNK_BYTES") ? (uint64_t)atoll(getenv("NEEDLE_HOST_CHUNK_BYTES")) : (2ull << 30);
+    const uint64_t row_bytes = std::max<uint64_t>(16, (v->row_stride * v->char_width + 15) & ~(uint64_t)15) + 8 + 8ull * slots;
+    const uint64_t per = std::max<uint64_t>(64, (kHostChunkBytes / row_bytes) & ~(uint64_t)63);
+    for (uint64_t r0 = 0; r0 < v->n_rows; r0 += per) {
+        needle_batch_view c = *v;
+        c.n_rows = std::min<uint64_t>(per, v->n_rows - r0);
+        c.rows = (const uint8_t *)v->rows + r0 * v->row_stride * v->char_width;
+        c.lengths = v->lengths ? v->lengths + r0 : nullptr;
+        int m = 0;
+        rc = find_all_host_one(p, &c, slots, counts + r0, start ? start + r0 * slots : nullptr, end ? end + r0 * slots : nullptr, &m);
+        if (rc) return rc;
+        if (m && more) *more = 1;
+    }
+    return NEEDLE_OK;
 }
 int needle_matches_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm) {
     return run_host(p, OP_MATCHES, v, bm, nullptr, nullptr);

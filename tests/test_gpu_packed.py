@@ -130,7 +130,9 @@ lens = (np.arange(30011) * 2654435761 % 257).astype(np.uint32)
 c = p.contained_in_batch(rows, lens)
 m = p.matches_batch(rows)
 fw, fs, fe = p.find_batch(rows, lens)
-np.save(sys.argv[1], np.concatenate([c.view(np.int64), m.view(np.int64), fw.view(np.int64), fs.astype(np.int64), fe.astype(np.int64)]))
+cnt, als, ale, more = p.find_all_dense(rows, 3, lens)  # needle_find_all_host, chunked the same way
+np.save(sys.argv[1], np.concatenate([c.view(np.int64), m.view(np.int64), fw.view(np.int64), fs.astype(np.int64), fe.astype(np.int64),
+                                     cnt.astype(np.int64), als.astype(np.int64).ravel(), ale.astype(np.int64).ravel(), np.array([int(more)])]))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
