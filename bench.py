@@ -411,7 +411,7 @@ def main():
     torch.cuda.set_device(local)
     ctx.dev = dev = torch.device("cuda", local)
     ctx.use_dist = use_dist = world > 1 or "RANK" in os.environ  # also under `torch.distributed.run --nproc-per-node 1`
-    if use_dist:
+    if use_dist and args.overlap == "on":
         # the scan kernel is one persistent workgroup per CU that owns the CU's whole LDS; leave a few CUs free so
         # that the RCCL kernels gathering the PREVIOUS step's results can run next to it instead of behind it
         os.environ.setdefault("NEEDLE_RESERVE_CUS", "4")
@@ -425,7 +425,15 @@ def main():
         # the gathers go through the library's own RCCL communicator (one C call per step); torch.distributed only
         # carries the communicator id, the barrier and the max-over-ranks reduction of the clock
         from needle_amd.multi import RankComm
-        ctx.comm = RankComm.from_torch_distributed(dev)
+        try:
+            ctx.comm = RankComm.from_torch_distributed(dev)
+        except Exception as e:  # noqa: BLE001 -- e.g. no loadable RCCL outside torch's: the torch.distributed path is equivalent
+            sys.stderr.write("library RCCL communicator unavailable (%s): gathers through torch.distributed\n" % e)
+            ctx.comm = None
+        ok = torch.tensor([1 if ctx.comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must take the same path
+        if int(ok.item()) == 0:
+            ctx.comm = None
     if args.also is None:
         also = ["c3", "c3s", "c5"] if world == 1 else ["c3"]
         if args.regex or args.op or args.rows != 10_000_000:
