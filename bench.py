@@ -393,6 +393,8 @@ def main():
     ap.add_argument("--graph", default="off", choices=["off", "scan"], help="launch the scan as a HIP graph (experiment; plain launches are faster)")
     ap.add_argument("--buffers", type=int, default=2, help="result buffer sets rotating through the steps (N > 1: gathers in flight)")
     ap.add_argument("--overlap", default="off", choices=["on", "off"], help="N > 1: gather on a side stream beside the next scan (costs ~25 us of event handshakes per step)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo + --all-on-device 0: a functional N > 1 run on ONE GPU; tests)")
+    ap.add_argument("--all-on-device", type=int, default=None, help="tests: every rank uses this device instead of LOCAL_RANK")
     ap.add_argument("--collectives", default="rccl", choices=["rccl", "torch"], help="N > 1: gathers through the library's RCCL communicator (default) or torch.distributed")
     ap.add_argument("--regex", default=None, help="tuning runs: another regex over the chosen workload's rows")
     ap.add_argument("--op", default=None, choices=["matches", "contained_in", "find"], help="tuning runs: another op")
@@ -408,6 +410,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
+    if args.all_on_device is not None:
+        local = args.all_on_device
     torch.cuda.set_device(local)
     ctx.dev = dev = torch.device("cuda", local)
     ctx.use_dist = use_dist = world > 1 or "RANK" in os.environ  # also under `torch.distributed.run --nproc-per-node 1`
@@ -418,7 +422,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            args.collectives = "torch"  # (the library's communicator is RCCL)
 
     ctx.comm = None
     if use_dist and args.collectives == "rccl":

@@ -134,3 +134,32 @@ def test_sharded_scan_step_through_the_library_communicator():
     bm, _, _ = shc.wait(shc.step())
     torch.cuda.synchronize()
     assert (unpack_bitmap(bm, total) == o.batch_contained_in(host, threads=4)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c2", "c3"])
+def test_bench_two_ranks_on_one_gpu(workload):
+    """bench.py's N = 2 path end to end on the single-GPU box: two ranks under torch.distributed.run, both on device 0,
+    gloo carrying the gathers (RCCL refuses two ranks on one device): the SAME batch sharded in two, ShardedScan steps,
+    the max-over-ranks clock, ONE JSON line from rank 0 with the C4 bookkeeping.  The sharded job must report the same
+    number of matches as the single-GPU job on the same rows."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    base = [sys.executable, "bench.py", "--workload", workload, "--rows", "200000", "--steps", "3", "--warmup", "1", "--also", "none",
+            "--no-cpu-baseline", "--no-extras"]
+    one = subprocess.run(base, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           "bench.py", "--gpus", "2", "--backend", "gloo", "--all-on-device", "0"] + base[2:]
+    two = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["config"]["rows_total"] == 200000 and d2["config"]["rows_per_gpu"] == 100032
+    assert abs(d2["matched_fraction"] - d1["matched_fraction"]) < 1e-12
+    assert d2["scan_ms"] > 0 and "gather_ms" in d2 and d2["gather"]["issued_by"] == "torch.distributed"
