@@ -18,6 +18,7 @@
 namespace needle {
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
 bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows);
+hipError_t launch_find_all(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream); // needle_find_all.hip
 hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, const int32_t *s, const int32_t *e, int32_t *cursor,
                                    uint32_t *counts, int32_t *starts, int32_t *ends, int32_t *any_hit, int n_cus, hipStream_t stream);
 hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipStream_t stream);
@@ -64,6 +65,7 @@ struct needle_pattern {
     // (device, which, char_width, variant) -> program resident in that device's HBM
     // variant: 0 plain, 1 global-walk layout (backward automaton of find), 2 forward + backward column maps,
     //          3 HBM-table layout forced (column maps + uint16 table in one blob: the speculative-stripe fix-up walks it)
+    //          4 / 5 as 0 / 2 without the pair table (the one-pass find-all kernel)
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
     ~needle_pattern() {
@@ -92,7 +94,7 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        dp.prog = lower(p->t, (Which)which, cw, variant == 3 ? 0 : max_prog_lds(), variant == 1, variant == 2);
+        dp.prog = lower(p->t, (Which)which, cw, variant == 3 ? 0 : max_prog_lds(), variant == 1, variant == 2 || variant == 5, variant >= 4);
         HIP_TRY(hipMalloc((void **)&dp.d_blob, dp.prog.blob.size()));
         if (hipError_t ce = hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice); ce != hipSuccess) {
             (void)hipFree(dp.d_blob);
@@ -919,15 +921,10 @@ int needle_find_next_dev(const needle_pattern *p, const needle_batch_view *v, co
     if (!cur) return fail(NEEDLE_ERR_INVALID, "cursor is NULL");
     return run_dev(p, OP_FIND, v, bm, st, en, s, cur);
 }
-int needle_find_all_dev(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
-                        int32_t *d_end, int *more, void *stream_) {
-    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
-    int rc = check_view(v, true);
-    if (rc) return rc;
-    if (more) *more = 0;
-    if (v->n_rows == 0) return NEEDLE_OK;
-    if (!d_counts || (slots && (!d_start || !d_end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
-    hipStream_t stream = (hipStream_t)stream_;
+// The round-per-match form: one needle_find_next pass over the batch per round, one stream synchronisation per round.
+// Rows of 64 MiB and more (stripe paths only) take it; NEEDLE_FIND_ALL_ROUNDS=1 forces it (tests cross-check the two).
+static int find_all_rounds(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
+                           int32_t *d_end, int *more, hipStream_t stream) {
     const size_t n = (size_t)v->n_rows, words = (n + 63) / 64;
     int dev = 0, cus = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -942,8 +939,8 @@ int needle_find_all_dev(const needle_pattern *p, const needle_batch_view *v, uin
     if (hipMemsetAsync(tmp + o_cur, 0, n * 4, stream) != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
     for (uint32_t k = 0;; ++k) {
         if (hipMemsetAsync(tmp + o_flag, 0, 4, stream) != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
-        rc = run_dev(p, OP_FIND, v, (uint64_t *)(tmp + o_bm), (int32_t *)(tmp + o_s), (int32_t *)(tmp + o_e), stream,
-                     (const int32_t *)(tmp + o_cur));
+        int rc = run_dev(p, OP_FIND, v, (uint64_t *)(tmp + o_bm), (int32_t *)(tmp + o_s), (int32_t *)(tmp + o_e), stream,
+                         (const int32_t *)(tmp + o_cur));
         if (rc) return done(rc);
         hipError_t e = launch_find_all_collect(n, slots, k, (const int32_t *)(tmp + o_s), (const int32_t *)(tmp + o_e),
                                                (int32_t *)(tmp + o_cur), d_counts, d_start, d_end, (int32_t *)(tmp + o_flag), cus, stream);
@@ -957,6 +954,72 @@ int needle_find_all_dev(const needle_pattern *p, const needle_batch_view *v, uin
             if (more) *more = 1;
             break;
         }
+    }
+    return done(NEEDLE_OK);
+}
+
+int needle_find_all_dev(const needle_pattern *cp, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
+                        int32_t *d_end, int *more, void *stream_) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, true);
+    if (rc) return rc;
+    if (more) *more = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_counts || (slots && (!d_start || !d_end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    static const bool rounds = getenv("NEEDLE_FIND_ALL_ROUNDS") && atoi(getenv("NEEDLE_FIND_ALL_ROUNDS")) != 0;
+    const uint64_t stride_bytes = v->row_stride * v->char_width;
+    if (rounds || stride_bytes >= (1ull << 26)) return find_all_rounds(p, v, slots, d_counts, d_start, d_end, more, stream);
+
+    // one pass: every row is fetched once, each lane restarts its search where its last match ended (needle_find_all.hip)
+    const DevProgram *fp = nullptr, *bp = nullptr;
+    int n_cus = 0;
+    const bool need_backward = p->t.fixed_len < 0;
+    rc = get_program(p, W_FORWARDS, (int)v->char_width, need_backward ? 5 : 4, &fp, &n_cus);
+    if (rc) return rc;
+    FindAllArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    ScanArgs &a = fa.s;
+    a.rows = (const uint8_t *)v->rows;
+    a.n_rows = v->n_rows;
+    a.stride_bytes = stride_bytes;
+    a.total_bytes = a.n_rows * a.stride_bytes;
+    a.row_len = v->row_len;
+    a.lengths = v->lengths;
+    a.prog = fp->d_blob;
+    a.hdr = fp->prog.hdr;
+    a.fixed_len = p->t.fixed_len;
+    if (need_backward) {
+        rc = get_program(p, W_BACKWARDS, (int)v->char_width, 1, &bp, nullptr);
+        if (rc) return rc;
+        a.bprog = bp->d_blob;
+        a.bhdr = bp->prog.hdr;
+    }
+    fa.slots = slots;
+    static const bool no_defer = getenv("NEEDLE_FIND_ALL_DEFER") && atoi(getenv("NEEDLE_FIND_ALL_DEFER")) == 0; // A/B, tests
+    fa.defer = (a.fixed_len < 0 && !a.hdr.root_accepting && v->row_stride <= 65535 && !no_defer) ? 1u : 0u;
+    static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr; // measurement aid: start = the search cursor
+    if (fa.defer && dbg_no_backward) fa.defer = 2;
+    fa.counts = d_counts;
+    fa.starts = d_start;
+    fa.ends = d_end;
+    int32_t *d_more = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&d_more, 16, stream));
+    auto done = [&](int code) {
+        (void)hipFreeAsync(d_more, stream);
+        return code;
+    };
+    if (hipMemsetAsync(d_more, 0, 4, stream) != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
+    fa.more = d_more;
+    hipError_t e = launch_find_all((int)v->char_width, fa, n_cus, stream);
+    if (e != hipSuccess) return done(hip_fail(e, "find_all"));
+    if (more) { // the only synchronisation: the caller asked whether its slots sufficed
+        int32_t m = 0;
+        e = hipMemcpyAsync(&m, d_more, 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return done(hip_fail(e, "find_all"));
+        *more = m != 0;
     }
     return done(NEEDLE_OK);
 }

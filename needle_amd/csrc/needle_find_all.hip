@@ -1,0 +1,451 @@
+// needle_find_all.hip -- every non-overlapping match of every row in ONE pass over the batch (the
+// reference's repeated Matcher.find(), DFAClassBuilder.java:616-659; DFACompilerTest.java:66-78,671-699).
+//
+// The round-per-match form (needle_find_next_dev fed its own `end` as the next cursor) reads the whole batch once per
+// round: a keyword dictionary over text finds a handful of matches per row and up to a few dozen in the worst row of
+// ten million, so the batch crosses the HBM bus dozens of times.  Here a row is fetched once.
+//
+// Same data movement as the scan kernel (needle_scan.h): one row per lane, 64-row groups, whole lines HBM -> VGPRs
+// -> XOR-swizzled LDS tile, the lowered automaton staged once per workgroup.  What differs is the walk.  After a match
+// [start, end) the reference restarts the search automaton AT `end` -- chars the walk already consumed while it
+// waited for the automaton to die -- so the rows of a wave stop being at the same char.  Every lane therefore keeps its
+// own PIECE index (16-byte piece of its row) and the wave iterates "each live lane walks its current piece": a
+// ds_read_b128 at a per-lane tile address, then walk_piece() with the per-char guards, which hide the chars before the
+// lane's cursor (the restart point, anywhere inside a piece) and past its row length.  A lane whose automaton died
+// files the match, moves its cursor to `end`, steps back to the piece holding `end` (from memory, in the rare case it is
+// in the previous tile) and starts again; lanes that reached the tile's end wait there for the others.
+//
+// Start indices (indexBackwards, :529-586).  A fixed-length pattern has start = end - L.  Otherwise the backward
+// automaton walks right to left from end - 1, bounded by the cursor the match was searched from.  Doing that at the
+// moment a lane resolves would run the backward walk's code for the one or two lanes resolving in any given
+// iteration; instead a lane pushes `end` on a small register stack (four VGPRs of 16-bit entries; the bound of a
+// match is the `end` of the one before it) and the wave walks backwards for ALL its lanes' pending matches at once,
+// at the end of the tile (whose text is still in LDS) or when a lane's stack is full.  Patterns that match the empty
+// string need every start at once -- an empty match ends its row (see needle_find_all_dev in needle_hip.h) -- and take
+// the immediate form, as do rows too long for 16-bit indices.
+#include "needle_walk.h"
+
+namespace needle {
+
+// One 16-byte piece of one row in the find-all walk.  Chars before the lane's cursor (the first skip_rel of the piece)
+// go through the PRE column (identity); chars past the row's end are walked like any others -- the search ends with
+// that piece whatever its state is, and the caller masks their accept flags.  Accept flags are LOGGED, one shift per
+// char (walk_piece selects a position per char: three VALU ops in a walk that is issue-bound under its guards):
+// returns the flags of the piece's chars, char i at bit i.
+template <int CW, int MODE>
+__device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t (&w)[4], uint32_t skip_rel, uint32_t accept_lo,
+                                                  uint32_t &st) {
+    constexpr int CPP = 16 / CW;
+    uint32_t col[CPP];
+    piece_lookups<MODE, CW, false>(wk, w, 0, 0, 0, col);
+    if (MODE == MODE_PACK) lds_fence();
+#pragma unroll
+    for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < skip_rel) ? wk.pre_e : col[i];
+    uint32_t h = 0;
+    const uint32_t acc_m1 = accept_lo - 1u;
+#pragma unroll
+    for (int i = 0; i < CPP; ++i) {
+        st = apply<MODE, CW>(wk, st, col[i]);
+        if (MODE == MODE_PACK) h = __builtin_amdgcn_alignbit(st, h, 1);                 // accepting states: odd field offsets
+        else if (MODE == MODE_HYBRID) h = __builtin_amdgcn_alignbit(h, st << 16, 31);   // accepting: bit 15 of the entry
+        else h = __builtin_amdgcn_alignbit(h, acc_m1 - st, 31);                          // accepting: st >= accept_lo
+    }
+    // packed: char i at bit 32 - CPP + i; the others: char i at bit CPP - 1 - i
+    if (MODE != MODE_PACK) h = __builtin_bitreverse32(h);
+    return h >> (32 - CPP);
+}
+
+template <int CW, int MODE, int CHB>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const FindAllArgs fa) {
+    using G = Geom<CHB>;
+    const ScanArgs &a = fa.s;
+    constexpr int CPP = 16 / CW; // chars per 16-byte piece
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = blockDim.x >> 6;
+
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u)
+        *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
+    __syncthreads();
+
+    Walk wk;
+    constexpr uint32_t ELEM = (MODE == MODE_TABLE16 || MODE == MODE_HYBRID) ? 2u : 1u;
+    wk.ncols_e = a.hdr.n_cols * ELEM;
+    wk.pad_e = (MODE == MODE_PACK) ? a.hdr.pad_f : a.hdr.pad_col * ELEM;
+    wk.pre_e = (MODE == MODE_PACK) ? a.hdr.pre_f : (a.hdr.pad_col + 1u) * ELEM;
+    wk.pad_b = wk.pre_b = 0;
+    wk.table_off = a.hdr.off_table;
+    wk.lane4 = (uint32_t)lane * 4u; // packed mode on 8-bit rows: all 64 lane copies of F are there (no tiles in the F rows)
+    wk.gtable = (const uint16_t *)(a.prog + (MODE == MODE_HYBRID ? a.hdr.off_gtable : a.hdr.off_table));
+    wk.hot_last = a.hdr.hot_bytes - 2u;
+    const uint32_t accept_lo = MODE == MODE_PACK ? a.hdr.accept_off : a.hdr.accept_lo;
+    const uint32_t start_state = MODE == MODE_PACK ? a.hdr.start_off : a.hdr.start;
+
+    Tile tile;
+    {
+        const uint32_t base = ((a.hdr.lds_bytes + 15u) & ~15u) + (uint32_t)wave * G::kTileBytes;
+        tile.store_addr = base + (uint32_t)(lane / G::kPieces) * CHB + (uint32_t)(lane % G::kPieces) * 16u;
+        tile.store_step = G::kRowsPerInstr * CHB;
+        tile.row_addr = base + (uint32_t)lane * CHB;
+    }
+    const uint32_t swz16 = (uint32_t)G::swz(lane) << 4; // byte b of this lane's tile row is at row_addr + (b ^ swz16)
+
+    const uint64_t n_groups = (a.n_rows + 63) >> 6;
+    const uint64_t wave_cnt = (uint64_t)gridDim.x * n_waves;
+    uint64_t g = (uint64_t)blockIdx.x * n_waves + wave;
+    if (g >= n_groups) return;
+
+    // tile fetch: as in scan_kernel (needle_scan.h) -- a fetch unit is one 128-byte line per row: one tile of 128-byte
+    // pieces or the two 64-byte tiles of the same lines, requested back to back
+    const uint32_t q = (uint32_t)lane >> 4;
+    const uint32_t p_in_row = (uint32_t)(lane % G::kPieces);
+    const uint32_t row_in_instr = (uint32_t)(lane / G::kPieces);
+    const uint32_t o_even = row_in_instr * (uint32_t)a.stride_bytes + 16u * (p_in_row ^ q);
+    const uint32_t o_odd = CHB == 128 ? (row_in_instr * (uint32_t)a.stride_bytes + 16u * (p_in_row ^ q ^ 4u)) : o_even;
+    const uint64_t load_step = (uint64_t)G::kRowsPerInstr * a.stride_bytes;
+    constexpr int NT = (CHB == 64) ? 2 : 1;
+    u32x4 R[NT][G::kInstrs];
+    auto fetch = [&](uint64_t grp, uint32_t unit) __attribute__((always_inline)) {
+        const uint8_t *base = a.rows + (grp << 6) * a.stride_bytes + unit * (NT * CHB);
+#pragma unroll
+        for (int j = 0; j < G::kInstrs; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) R[t][j] = load_row16<NT == 1>(base + t * CHB + j * load_step + ((j & 1) ? o_odd : o_even));
+    };
+    auto fetch_clamped = [&](uint64_t grp, uint32_t chunk) __attribute__((always_inline)) {
+        const uint32_t last_r = (uint32_t)(a.n_rows - 1 - (grp << 6));
+        const uint32_t stride = (uint32_t)a.stride_bytes;
+        const uint8_t *gbase = a.rows + (grp << 6) * a.stride_bytes;
+#pragma unroll
+        for (int j = 0; j < G::kInstrs; ++j) {
+            uint32_t r = (uint32_t)(j * G::kRowsPerInstr) + row_in_instr;
+            const uint32_t kk = p_in_row ^ (uint32_t)G::swz((int)r);
+            r = r < last_r ? r : last_r;
+            uint32_t pb = chunk * CHB + kk * 16u;
+            if (pb + 16u > stride) pb = stride - 16u;
+            R[0][j] = load_row16<false>(gbase + (r * stride + pb));
+        }
+    };
+
+    // ---- per-group (per-row) state
+    uint64_t my_row = 0;
+    bool row_ok = false, done = true;
+    uint32_t len = 0, n_chunks = 1, st = 0, pi = 0, count = 0;
+    int32_t last = -1, cursor = 0;
+    const uint8_t *rowp = a.rows;
+    // pending matches whose start is still to be found: their ends, newest in the low half of pend[0]
+    uint32_t pend[4] = {0, 0, 0, 0};
+    uint32_t n_pend = 0;
+    int32_t pend_bound = 0; // the cursor the OLDEST pending match was searched from
+
+    // indexBackwards(en - 1, bound), :536-583, for the lanes of `act`; the tile in LDS holds the row bytes
+    // [tile_b0, tile_b0 + CHB), anything else is read from memory.
+    auto backward = [&](bool act, int32_t en, int32_t bound, uint32_t tile_b0) __attribute__((always_inline)) -> int32_t {
+        const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
+        const uint16_t *bt = a.hdr.off_btable ? (const uint16_t *)(smem + a.hdr.off_btable)
+                                               : (const uint16_t *)(a.bprog + a.bhdr.off_table);
+        const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
+        int32_t idx_b = en - 1;
+        uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
+        int32_t lastb = a.bhdr.root_accepting ? bound : INT_MAX; // :543-547
+        bool active = act;
+        while (__ballot(active) != 0ull) {
+            uint32_t cs[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int32_t p = idx_b - k;
+                const uint32_t rel = (uint32_t)(p * CW) - tile_b0;     // byte offset inside the tile, if it is there
+                const bool in_tile = rel < (uint32_t)CHB;
+                const uint32_t ad = tile.row_addr + ((in_tile ? rel : 0u) ^ swz16);
+                const uint32_t held = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
+                cs[k] = 0;
+                if (active && p >= bound) cs[k] = in_tile ? held : ((CW == 1) ? (uint32_t)rowp[p] : (uint32_t)((const uint16_t *)rowp)[p]);
+            }
+            if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton
+                uint32_t fb[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (CW == 1) {
+                        fb[k] = lds_u32(a.hdr.off_bpack + (cs[k] << 2));
+                    } else {
+                        const u32x2 pg = lds_u32x2(a.hdr.off_bpack + ((cs[k] >> 8) << 3));
+                        fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool in_range = active && idx_b >= bound; // loop bound `index >= FROM`, :549
+                    const uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
+                    const bool alive = in_range && nb != 0u;
+                    lastb = (alive && nb >= bacc) ? idx_b : lastb;
+                    bs = alive ? nb : bs;
+                    idx_b = alive ? idx_b - 1 : idx_b;
+                    active = alive;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (active) {
+                        if (idx_b < bound) {
+                            active = false;
+                        } else {
+                            const uint32_t col = column_of<CW>(bcmap, bptab, bpages, cs[k]);
+                            if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
+                                const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
+                                const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col) - 1u));
+                                const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
+                                bs = ((bm >> col) & 1u) ? tgt : 0u;
+                            } else {
+                                bs = bt[bs * bcols + col];
+                            }
+                            if (bs == 0) {
+                                active = false;
+                            } else {
+                                if (bs >= bacc) lastb = idx_b;
+                                --idx_b;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        return lastb;
+    };
+
+    // starts of every lane's pending matches (the deferred form): the pending entries are the matches
+    // count - n_pend .. count - 1 of the row, newest on top; the bound of each is the end of the one before it
+    auto flush_pending = [&](uint32_t tile_b0) __attribute__((always_inline)) {
+        const uint32_t first = count - n_pend; // matches of this row whose start is filed already
+        while (__ballot(n_pend != 0u) != 0ull) {
+            const bool act = n_pend != 0u;
+            const int32_t en = (int32_t)(pend[0] & 0xFFFFu);
+            pend[0] = __builtin_amdgcn_alignbit(pend[1], pend[0], 16); // pop
+            pend[1] = __builtin_amdgcn_alignbit(pend[2], pend[1], 16);
+            pend[2] = __builtin_amdgcn_alignbit(pend[3], pend[2], 16);
+            pend[3] >>= 16;
+            if (act) --n_pend;
+            const int32_t bound = n_pend ? (int32_t)(pend[0] & 0xFFFFu) : pend_bound;
+            const int32_t s = fa.defer == 2u ? bound : backward(act, en, bound, tile_b0); // (2: measurement aid)
+            if (act) fa.starts[my_row * fa.slots + first + n_pend] = s;
+        }
+    };
+
+    auto begin_group = [&](uint64_t grp) __attribute__((always_inline)) {
+        my_row = (grp << 6) + lane;
+        row_ok = my_row < a.n_rows;
+        len = 0;
+        if (row_ok) len = a.lengths ? a.lengths[my_row] : a.row_len;
+        const uint32_t max_len = a.lengths ? wave_max(len) : a.row_len;
+        n_chunks = (max_len * CW + CHB - 1) / CHB;
+        if (n_chunks == 0) n_chunks = 1;
+        rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
+        done = !row_ok;
+        cursor = 0;
+        st = start_state;
+        last = a.hdr.root_accepting ? 0 : -1; // :356 literal 0 (cursor 0: the same whether 0 < length or not)
+        pi = 0;
+        count = 0;
+        n_pend = 0;
+        pend_bound = 0;
+    };
+
+    // Walk the tile in LDS (chunk ck of the group's rows) until every live lane is past it.
+    auto walk_tile = [&](uint32_t ck) __attribute__((always_inline)) {
+        const uint32_t tile_p0 = ck * G::kPieces, tile_p1 = tile_p0 + G::kPieces, tile_b0 = ck * CHB;
+        for (;;) {
+            const uint32_t p0 = pi * CPP;
+            const bool beyond = p0 >= len; // nothing of the row there (a walk over PAD: the search ends)
+            const bool active = !done && (pi < tile_p1 || beyond);
+            if (__ballot(active) == 0ull) break;
+            bool ended = false;
+            if (active) {
+                u32x4 v = {0, 0, 0, 0};
+                if (!beyond) {
+                    if (pi >= tile_p0) v = *(const lds_u32x4 *)(uintptr_t)(tile.row_addr + (((pi - tile_p0) << 4) ^ swz16));
+                    else v = *(const u32x4 *)(rowp + (uint64_t)pi * 16u); // a restart in the previous tile
+                }
+                const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
+                const uint32_t skip_rel = (uint32_t)cursor > p0 ? (uint32_t)cursor - p0 : 0u; // < CPP: the cursor's piece, or none
+                uint32_t acc = walk_piece_fa<CW, MODE>(wk, w, skip_rel, accept_lo, st);
+                const uint32_t in_row = len > p0 ? len - p0 : 0u; // chars of the piece inside the row (all, if >= CPP)
+                acc &= ~((1u << skip_rel) - 1u);                   // an accepting start state does not count before the cursor
+                if (in_row < (uint32_t)CPP) acc &= (1u << in_row) - 1u;
+                last = acc ? (int32_t)(p0 + 32u - (uint32_t)__builtin_clz(acc)) : last;
+                ended = st == 0u || p0 + CPP >= len;
+                if (!ended) ++pi;
+            }
+            if (__ballot(ended) == 0ull) continue;
+            // ---- find() returns for the lanes of `ended` (:629-657)
+            const bool hit = ended && last >= 0;
+            const int32_t en = last;
+            if (ended && !hit) done = true; // no further match in this row
+            if (fa.defer) {
+                // not nullable, start by indexBackwards: the match is not empty and ends beyond its cursor -- the row goes on
+                if (hit) {
+                    if (count < fa.slots) {
+                        fa.ends[my_row * fa.slots + count] = en;
+                        ++count;
+                        if (n_pend == 0u) pend_bound = cursor;
+                        pend[3] = __builtin_amdgcn_alignbit(pend[3], pend[2], 16); // push
+                        pend[2] = __builtin_amdgcn_alignbit(pend[2], pend[1], 16);
+                        pend[1] = __builtin_amdgcn_alignbit(pend[1], pend[0], 16);
+                        pend[0] = (pend[0] << 16) | (uint32_t)en;
+                        ++n_pend;
+                        cursor = en;
+                        st = start_state;
+                        last = -1;
+                        pi = ((uint32_t)en * CW) >> 4;
+                    } else {
+                        *fa.more = 1;
+                        done = true;
+                    }
+                }
+                if (__ballot(n_pend == 8u) != 0ull) flush_pending(tile_b0);
+            } else {
+                int32_t s = en - a.fixed_len;
+                if (a.fixed_len < 0) s = backward(hit, en, cursor, tile_b0);
+                // en < s: the wrapped pseudo-match of a nullable pattern searched from cursor == length; dropped, ends the row
+                const bool valid = hit && en >= s;
+                if (hit && !valid) done = true;
+                if (valid) {
+                    if (count < fa.slots) {
+                        fa.starts[my_row * fa.slots + count] = s;
+                        fa.ends[my_row * fa.slots + count] = en;
+                        ++count;
+                        // the row goes on only while the cursor advances (needle_hip.h)
+                        if (en == s || en <= cursor) {
+                            done = true;
+                        } else {
+                            cursor = en;
+                            st = start_state;
+                            last = a.hdr.root_accepting ? (((uint32_t)cursor < len) ? cursor : 0) : -1;
+                            pi = ((uint32_t)en * CW) >> 4;
+                        }
+                    } else {
+                        *fa.more = 1;
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (fa.defer) flush_pending(tile_b0);
+    };
+    auto end_group = [&]() __attribute__((always_inline)) {
+        if (row_ok) fa.counts[my_row] = count;
+    };
+    auto stage = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int T = decltype(tc)::value;
+#pragma unroll
+        for (int j = 0; j < G::kInstrs; ++j) store_piece(tile, j, R[T][j]);
+    };
+
+    uint64_t last_group = n_groups - 1; // first group handled by the clamped tail below (as in scan_kernel)
+    {
+        const uint64_t group_bytes = 64 * a.stride_bytes;
+        const uint64_t safe = a.total_bytes >= (uint64_t)(NT * CHB) ? (a.total_bytes - NT * CHB) / group_bytes : 0;
+        if (safe < last_group) last_group = safe;
+    }
+    if (g < last_group) {
+        fetch(g, 0);
+        for (;;) {
+            begin_group(g);
+            uint32_t ck = 0;
+            bool have_next = false; // R holds (or will hold) unit 0 of this wave's next group
+            // the registers of a unit are free once its last tile is staged: the next unit -- of this group, or the
+            // first one of the wave's next group -- is requested then and arrives while the tile is walked
+            auto prefetch = [&]() __attribute__((always_inline)) {
+                if (ck + 1 < n_chunks) fetch(g, (ck + 1) / NT);
+                else if (g + wave_cnt < last_group) fetch(g + wave_cnt, 0), have_next = true;
+            };
+            for (;;) {
+                stage(std::integral_constant<int, 0>{});
+                asm volatile("" ::: "memory");
+                if (NT == 1) prefetch();
+                asm volatile("" ::: "memory");
+                walk_tile(ck);
+                ++ck;
+                if (ck >= n_chunks || __ballot(!done) == 0ull) break;
+                if (NT == 2) {
+                    stage(std::integral_constant<int, NT - 1>{});
+                    asm volatile("" ::: "memory");
+                    prefetch();
+                    asm volatile("" ::: "memory");
+                    walk_tile(ck);
+                    ++ck;
+                    if (ck >= n_chunks || __ballot(!done) == 0ull) break;
+                }
+            }
+            end_group();
+            g += wave_cnt;
+            if (g >= last_group) break;
+            if (!have_next) fetch(g, 0);
+        }
+    }
+    for (; g < n_groups; g += wave_cnt) {
+        begin_group(g);
+        for (uint32_t ck = 0; ck < n_chunks; ++ck) {
+            fetch_clamped(g, ck);
+            stage(std::integral_constant<int, 0>{});
+            walk_tile(ck);
+            if (__ballot(!done) == 0ull) break;
+        }
+        end_group();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher
+// ------------------------------------------------------------------------------------------------
+template <int CW, int MODE, int CHB>
+static hipError_t launch_fa(const FindAllArgs &fa, int grid, int waves, size_t lds, hipStream_t stream) {
+    auto k = find_all_kernel<CW, MODE, CHB>;
+    static thread_local uint64_t configured = 0;
+    if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(waves * 64), lds, stream, fa);
+    return hipGetLastError();
+}
+template <int CW, int MODE>
+static hipError_t launch_fa_h(const FindAllArgs &fa, int chb, int grid, int waves, size_t lds, hipStream_t s) {
+    return chb == 128 ? launch_fa<CW, MODE, 128>(fa, grid, waves, lds, s) : launch_fa<CW, MODE, 64>(fa, grid, waves, lds, s);
+}
+template <int CW>
+static hipError_t launch_fa_m(const FindAllArgs &fa, int chb, int grid, int waves, size_t lds, hipStream_t s) {
+    switch (fa.s.hdr.mode) {
+    case MODE_PACK: return launch_fa_h<CW, MODE_PACK>(fa, chb, grid, waves, lds, s);
+    case MODE_TABLE8: return launch_fa_h<CW, MODE_TABLE8>(fa, chb, grid, waves, lds, s);
+    case MODE_TABLE16: return launch_fa_h<CW, MODE_TABLE16>(fa, chb, grid, waves, lds, s);
+    case MODE_HYBRID: return launch_fa_h<CW, MODE_HYBRID>(fa, chb, grid, waves, lds, s);
+    case MODE_GLOBAL: return launch_fa_h<CW, MODE_GLOBAL>(fa, chb, grid, waves, lds, s);
+    default: return hipErrorInvalidValue; // (pair mode: the caller lowers the automaton without it)
+    }
+}
+
+// One persistent workgroup per CU; the shape (waves x tile bytes) follows the automaton's LDS footprint.
+hipError_t launch_find_all(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream) {
+    if (fa.s.n_rows == 0) return hipSuccess;
+    const size_t p = (fa.s.hdr.lds_bytes + 15u) & ~15u, cap = 160u * 1024u;
+    static const int cand[6][2] = {{16, 128}, {12, 128}, {16, 64}, {12, 64}, {8, 64}, {4, 64}};
+    int waves = 0, chb = 0;
+    static const char *force = getenv("NEEDLE_FIND_ALL_SHAPE"); // e.g. "8x128" (tuning experiments only)
+    if (force) {
+        int w = 0, c = 0;
+        if (sscanf(force, "%dx%d", &w, &c) == 2 && (c == 64 || c == 128) && w >= 1 && w <= 16 && p + (size_t)w * 64 * c <= cap) waves = w, chb = c;
+    }
+    if (!waves)
+    for (const auto &c : cand)
+        if (p + (size_t)c[0] * 64 * c[1] <= cap) {
+            waves = c[0];
+            chb = c[1];
+            break;
+        }
+    if (!waves) return hipErrorInvalidValue;
+    const uint64_t n_groups = (fa.s.n_rows + 63) >> 6;
+    uint64_t blocks = (n_groups + waves - 1) / waves;
+    if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
+    const size_t lds = p + (size_t)waves * 64 * chb;
+    return char_width == 1 ? launch_fa_m<1>(fa, chb, (int)blocks, waves, lds, stream) : launch_fa_m<2>(fa, chb, (int)blocks, waves, lds, stream);
+}
+
+} // namespace needle

@@ -108,7 +108,7 @@ static ColumnMaps column_maps(const RefTables &t, const RefDfa &d, int char_widt
 }
 
 Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
-              bool with_backward_maps) {
+              bool with_backward_maps, bool no_pair) {
     const RefDfa &d = t.dfa[which];
     const int N = t.stride;
     const int n_ref = d.n_states;
@@ -187,7 +187,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     // when [state][col][col] fits, one lookup advances TWO chars.  NEEDLE_PAIR_MAX_BYTES=0 turns it off (A/B, tests).
     static const size_t pair_budget = getenv("NEEDLE_PAIR_MAX_BYTES") ? (size_t)atol(getenv("NEEDLE_PAIR_MAX_BYTES")) : (size_t)(96u << 10);
     const size_t pair_bytes = (size_t)n_dev * n_cols * n_cols * 2;
-    if (mode == MODE_TABLE8 && char_width == 1 && pair_bytes <= pair_budget && pair_bytes + 4096 <= lds_table_budget) mode = MODE_PAIR;
+    if (!no_pair && mode == MODE_TABLE8 && char_width == 1 && pair_bytes <= pair_budget && pair_bytes + 4096 <= lds_table_budget) mode = MODE_PAIR;
 
     ColumnMaps bm;
     if (with_backward_maps) bm = column_maps(t, t.dfa[W_BACKWARDS], char_width);
@@ -200,7 +200,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             p.hdr.off_bpages = append(p.blob, bm.pages.data(), bm.pages.size());
         }
         // a small backward table rides along in LDS (same layout as the global-walk program: uint16 [n_dev][n_cols])
-        const Program bp = lower(t, W_BACKWARDS, char_width, lds_table_budget, true, false);
+        const Program bp = lower(t, W_BACKWARDS, char_width, lds_table_budget, true, false, false);
         const size_t tbytes = bp.blob.size() - bp.hdr.off_table;
         if (tbytes <= 2048) p.hdr.off_btable = append(p.blob, bp.blob.data() + bp.hdr.off_table, tbytes);
         else if (bp.hdr.n_cols <= 32 && mode != MODE_GLOBAL && mode != MODE_HYBRID) {
@@ -229,7 +229,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         }
         // ... and a backward automaton of <= 6 states as packed functions (same device numbering as `bp`): its walk is
         // then 8 independent char -> F lookups and a chain of v_bfe_u32, not 8 x (2-3 dependent lookups)
-        const Program pk = lower(t, W_BACKWARDS, char_width, 64u << 10, false, false);
+        const Program pk = lower(t, W_BACKWARDS, char_width, 64u << 10, false, false, false);
         if (pk.hdr.mode == MODE_PACK && (char_width == 1 || pk.hdr.lds_bytes <= (24u << 10))) {
             p.hdr.bpack_start_off = pk.hdr.start_off;
             p.hdr.bpack_accept_off = pk.hdr.accept_off;

@@ -42,7 +42,8 @@ bool validate_tables(const RefTables &t, std::string &err);
 // take (tables above it are walked out of HBM: MODE_GLOBAL).  `global_walk`: build the plain uint16 layout
 // read from global memory (used for the backward automaton of find()).
 // `with_backward_maps` (W_FORWARDS only): append the backward automaton's char -> column maps to the blob.
+// `no_pair`: never the two-chars-per-lookup table (the find-all kernel walks from per-lane char positions).
 Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
-              bool with_backward_maps = false);
+              bool with_backward_maps = false, bool no_pair = false);
 
 } // namespace needle

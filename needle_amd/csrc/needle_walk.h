@@ -193,26 +193,13 @@ __device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t 
     return MODE == MODE_TABLE8 ? lds_u8(addr) : lds_u16(addr);
 }
 
-// One 16-byte piece of one row: w = its four dwords, p0 = index of its first char inside the tile (or row), rem /
-// skip = GUARD: chars of the row from the tile start on / chars before the find() cursor, st = the automaton state
-// (5 * id in packed mode), last_rel = OP_FIND: index + 1 of the last accepting char seen (same origin as p0).
-// HIST (packed mode, find() on full rows): instead of "last_rel = accepted ? position : last_rel" -- two VALU ops per
-// char in a walk that is VALU-issue bound -- every char's accept flag, which is bit 0 of the packed state (accepting
-// states sit at odd field offsets), is shifted into acc_hist with ONE v_alignbit_b32; the caller turns the log into a
-// position every 32 chars (char i of the 32 at bit i).
-template <int OP, int CW, int MODE, bool GUARD, bool HIST = false>
-__device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4], uint32_t p0, uint32_t rem, uint32_t skip,
-                                           uint32_t accept_lo, uint32_t &st, int32_t &last_rel, uint32_t *acc_hist = nullptr) {
-    constexpr int CPP = 16 / CW; // chars per 16-byte piece
-    // Table modes are bound by LDS cycles, not by issue: a lane whose verdict is already final (sink, or
-    // accepted for containedIn) is masked out of the piece's lookups, so its LDS passes and the bank
-    // conflicts it would cause disappear.  (Packed mode is conflict-free by construction: no masking.)
-    bool lane_live = true;
-    if (MODE != MODE_PACK && NEEDLE_MASK_DONE_LANES)
-        lane_live = (OP == OP_CONTAINED_IN) ? (st - 1u < accept_lo - 1u) : (st != 0u);
-    if (lane_live) {
+// Everything of a 16-byte piece's walk that does not depend on the automaton state: per char its F (packed mode) or
+// its column * element size (table modes).  GUARD: chars at p0 + i >= rem take the PAD column, chars at p0 + i < skip PRE.
+template <int MODE, int CW, bool GUARD>
+__device__ __forceinline__ void piece_lookups(const Walk &wk, const uint32_t (&w)[4], uint32_t p0, uint32_t rem, uint32_t skip,
+                                              uint32_t (&col)[16 / CW]) {
+    constexpr int CPP = 16 / CW;
     // all state-independent lookups of the piece first (they pipeline in the LDS) ...
-    uint32_t col[CPP];
     if (CW == 2) {
         // UTF-16: two dependent lookups per char before the state chain -- packed mode: page table -> F; table modes:
         // page table -> page -> column (the table lookup follows on the state chain).  Issued as batches of 8 with ONE
@@ -279,6 +266,29 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
         }
 #undef NEEDLE_LOOKUP
     }
+}
+
+// One 16-byte piece of one row: w = its four dwords, p0 = index of its first char inside the tile (or row), rem /
+// skip = GUARD: chars of the row from the tile start on / chars before the find() cursor, st = the automaton state
+// (5 * id in packed mode), last_rel = OP_FIND: index + 1 of the last accepting char seen (same origin as p0).
+// HIST (packed mode, find() on full rows): instead of "last_rel = accepted ? position : last_rel" -- two VALU ops per
+// char in a walk that is VALU-issue bound -- every char's accept flag, which is bit 0 of the packed state (accepting
+// states sit at odd field offsets), is shifted into acc_hist with ONE v_alignbit_b32; the caller turns the log into a
+// position every 32 chars (char i of the 32 at bit i).
+template <int OP, int CW, int MODE, bool GUARD, bool HIST = false>
+__device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4], uint32_t p0, uint32_t rem, uint32_t skip,
+                                           uint32_t accept_lo, uint32_t &st, int32_t &last_rel, uint32_t *acc_hist = nullptr) {
+    constexpr int CPP = 16 / CW; // chars per 16-byte piece
+    // Table modes are bound by LDS cycles, not by issue: a lane whose verdict is already final (sink, or
+    // accepted for containedIn) is masked out of the piece's lookups, so its LDS passes and the bank
+    // conflicts it would cause disappear.  (Packed mode is conflict-free by construction: no masking.)
+    bool lane_live = true;
+    if (MODE != MODE_PACK && NEEDLE_MASK_DONE_LANES)
+        lane_live = (OP == OP_CONTAINED_IN) ? (st - 1u < accept_lo - 1u) : (st != 0u);
+    if (lane_live) {
+    // all state-independent lookups of the piece first (they pipeline in the LDS) ...
+    uint32_t col[CPP];
+    piece_lookups<MODE, CW, GUARD>(wk, w, p0, rem, skip, col);
     // ... then ONE wait for all of them instead of one s_waitcnt per char (the walk is issue-bound), ...
     // (packed mode only: in the table and pair modes the same fence costs 5-8 %, their lookups are better left
     // interleaved with the dependent chain)

@@ -276,9 +276,10 @@ class Pattern:
                                           en.data_ptr(), s))
         return words, st, en
 
-    def find_all_dense(self, rows, max_per_row, lengths=None, stream=None):
+    def find_all_dense(self, rows, max_per_row, lengths=None, stream=None, out=None):
         """needle_find_all_dev: every non-overlapping match of every row in dense per-row slots.
-        -> (counts int32[n], start int32[n, max_per_row], end int32[n, max_per_row], more: bool)"""
+        -> (counts int32[n], start int32[n, max_per_row], end int32[n, max_per_row], more: bool)
+        out: optional caller-owned (counts, start, end) device tensors (slots beyond a row's count are left as they are)."""
         L = _lib.lib()
         if isinstance(rows, np.ndarray):  # host buffers: needle_find_all_host
             rows = np.ascontiguousarray(rows)
@@ -308,9 +309,14 @@ class Pattern:
             v.lengths = lengths.data_ptr()
         with torch.cuda.device(rows.device):
             s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
-            counts = torch.zeros(n, dtype=torch.int32, device=rows.device)
-            st = torch.full((n, max_per_row), -1, dtype=torch.int32, device=rows.device)
-            en = torch.full((n, max_per_row), -1, dtype=torch.int32, device=rows.device)
+            if out is not None:
+                counts, st, en = out
+                assert counts.shape == (n,) and st.shape == (n, max_per_row) and en.shape == (n, max_per_row)
+                assert all(t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() for t in out)
+            else:
+                counts = torch.zeros(n, dtype=torch.int32, device=rows.device)
+                st = torch.full((n, max_per_row), -1, dtype=torch.int32, device=rows.device)
+                en = torch.full((n, max_per_row), -1, dtype=torch.int32, device=rows.device)
             more = ctypes.c_int(0)
             _check(L.needle_find_all_dev(self._h, ctypes.byref(v), int(max_per_row), counts.data_ptr(), st.data_ptr(),
                                          en.data_ptr(), ctypes.byref(more), s))

@@ -1,0 +1,154 @@
+"""SURVEY.md s8f-1 at batch scale: needle_find_all_dev's ONE-PASS kernel (needle_find_all.hip) -- every non-overlapping
+match of every row, each lane restarting its search where its last match ended -- against the oracle's repeated find()
+(oracle/walker.py find_all: Matcher.find() with the nextStart cursor, DFAClassBuilder.java:616-659), and against the
+round-per-match form built on the scan kernel's per-row cursors.  Bit-exact: counts, starts, ends, the `more` flag."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DICTIONARY = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from needle_amd import workload as W
+from needle_amd.pattern import DFACompiler
+from test_compile_matches_txt import oracle_for
+words = W.keywords(300)
+rx = "|".join(words)
+p = DFACompiler.compile(rx, "t", 0)
+want_mode = int(sys.argv[1])
+if want_mode >= 0:
+    assert p.info()["kernel_mode"]["forwards"] == want_mode, p.info()
+o, _ = oracle_for(rx, 0)
+n = 3000
+rows = W.keyword_batch(torch, words, 11, n, 256, device="cuda")
+host = rows.cpu().numpy()
+want = [o.find_all(host[i]) for i in range(n)]
+most = max(len(w) for w in want)
+assert most >= 6 and sum(len(w) for w in want) > n
+for slots in (most, 3):
+    counts, st, en, more = p.find_all_dense(rows, slots)
+    counts, st, en = counts.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+    assert more == (slots < most)
+    for i in range(n):
+        k = min(len(want[i]), slots)
+        assert counts[i] == k, (i, counts[i], want[i])
+        assert list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == want[i][:k], (i, want[i])
+        assert (st[i, k:] == -1).all() and (en[i, k:] == -1).all()  # slots beyond the count are untouched
+# the round-per-match loop over the scan kernel's per-row cursors (find_next): an independent GPU path
+offsets, s2, e2 = p.find_all_batch(rows, max_rounds=most + 2)
+offsets, s2, e2 = offsets.cpu().numpy(), s2.cpu().numpy(), e2.cpu().numpy()
+for i in range(0, n, 7):
+    assert list(zip(s2[offsets[i]:offsets[i + 1]].tolist(), e2[offsets[i]:offsets[i + 1]].tolist())) == want[i]
+# UTF-16 rows of the same text
+rows16 = rows.to(torch.int16)
+counts16, st16, en16, more16 = p.find_all_dense(rows16, most)
+assert not more16 and (counts16.cpu().numpy() == [len(w) for w in want]).all()
+st16, en16 = st16.cpu().numpy(), en16.cpu().numpy()
+for i in range(0, n, 5):
+    assert list(zip(st16[i, :len(want[i])].tolist(), en16[i, :len(want[i])].tolist())) == want[i]
+print("FIND-ALL-OK")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,mode", [({}, 2), ({"NEEDLE_FIND_ALL_DEFER": "0"}, 2), ({"NEEDLE_FIND_ALL_ROUNDS": "1"}, 2),
+                                      ({"NEEDLE_MAX_PROG_LDS": "4096", "NEEDLE_HYBRID": "0"}, 3),
+                                      ({"NEEDLE_MAX_PROG_LDS": "4096"}, 5), ({"NEEDLE_MAX_PROG_LDS": "20000"}, 5)],
+                         ids=["one-pass", "starts-at-once", "rounds", "hbm-table", "hot-rows-4k", "hot-rows-20k"])
+def test_keyword_dictionary_every_match(env, mode):
+    """A 300-keyword union (779 states, uint16 table) over 3000 rows of 256 chars: one to two matches per row, up to 8.
+    Children: the one-pass kernel with starts found tile by tile (default) or match by match, the round-per-match form,
+    and the automaton forced out of the LDS (whole table in HBM; hot rows in LDS + HBM table)."""
+    r = subprocess.run([sys.executable, "-c", DICTIONARY, str(mode)], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert "FIND-ALL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def _oracle(regex, flags=0):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_compile_matches_txt import oracle_for
+    from needle_amd.pattern import DFACompiler
+    return DFACompiler.compile(regex, "t", flags), oracle_for(regex, flags)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regex", ["[0-9]+", "(ab|a|bcdef|g)+", "a.c", "ab|a|bcdef|g", "[a-c]*", "abc|abcd1|d1"])
+@pytest.mark.parametrize("stride", [16, 48, 64, 80, 192, 320, 1040])
+def test_every_match_across_tile_boundaries(regex, stride):
+    """Rows whose stride is not a multiple of the LDS tile (64 / 128 bytes), ragged lengths (empty rows included), text
+    dense in matches: restarts, matches and backward walks straddle pieces, tiles and 128-byte lines.  `[a-c]*` matches
+    the empty string (starts found match by match; an empty match ends its row); `abc|abcd1|d1` dies two chars after
+    a match's end, so a restart steps back."""
+    import torch
+    p, o = _oracle(regex)
+    rng = np.random.default_rng(stride)
+    n = 700
+    rows = rng.choice(np.frombuffer(b"abcdefg019 abca", dtype=np.uint8), size=(n, stride))
+    lens = rng.integers(0, stride + 1, size=n).astype(np.uint32)
+    lens[:50] = stride
+    for ragged in (True, False):
+        ln = lens if ragged else None
+        want = [o.find_all(rows[i, :lens[i]] if ragged else rows[i]) for i in range(n)]
+        most = max(1, max(len(w) for w in want))
+        t = torch.from_numpy(rows).cuda()
+        tl = torch.from_numpy(lens.astype(np.int32)).cuda() if ragged else None
+        counts, st, en, more = p.find_all_dense(t, most, tl)
+        counts, st, en = counts.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+        assert not more
+        for i in range(n):
+            k = len(want[i])
+            assert counts[i] == k, (i, counts[i], want[i][:4])
+            assert list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == want[i], (i, want[i][:4])
+        if most > 1:
+            c2, _, _, more2 = p.find_all_dense(t, most - 1, tl)
+            assert more2 and (c2.cpu().numpy() == np.minimum(counts, most - 1)).all()
+
+
+@pytest.mark.gpu
+def test_every_match_utf16_script_runs():
+    """The C5 regex (runs of Greek / Cyrillic / Hebrew / CJK code units) over UTF-16 rows: packed functions behind the
+    two-level page map, one to a few runs per row."""
+    import torch
+    from needle_amd import workload as W
+    p, o = _oracle(W.script_regex())
+    n = 1500
+    rows = W.script_batch(torch, 3, n, 256, device="cuda")
+    host = rows.cpu().numpy().view(np.uint16)
+    want = [o.find_all(host[i]) for i in range(n)]
+    most = max(len(w) for w in want)
+    assert most >= 1
+    counts, st, en, more = p.find_all_dense(rows, most + 1)
+    counts, st, en = counts.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+    assert not more
+    for i in range(n):
+        k = len(want[i])
+        assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == want[i], (i, want[i])
+
+
+@pytest.mark.gpu
+def test_every_match_in_rows_beyond_16_bit_indices():
+    """Rows of 70 000 chars: match ends no longer fit the 16-bit pending stack, starts are found match by match; and a
+    row with more matches than slots says so."""
+    import torch
+    p, o = _oracle("[0-9]+x")
+    rng = np.random.default_rng(9)
+    L = 70000
+    rows = rng.choice(np.frombuffer(b"abcdefghijklmnopqrstuvwxyz      01x", dtype=np.uint8), size=(6, L))
+    rows[:, 66000:66004] = np.frombuffer(b"123x", dtype=np.uint8)
+    want = [o.find_all(rows[i]) for i in range(6)]
+    most = max(len(w) for w in want)
+    assert most > 20 and any(e > 65536 for w in want for _, e in w)
+    t = torch.from_numpy(rows).cuda()
+    counts, st, en, more = p.find_all_dense(t, most)
+    counts, st, en = counts.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+    assert not more
+    for i in range(6):
+        k = len(want[i])
+        assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == want[i]
+    c2, s2, e2, more2 = p.find_all_dense(t, 5)
+    assert more2 and (c2.cpu().numpy() == 5).all() and (s2.cpu().numpy() == st[:, :5]).all() and (e2.cpu().numpy() == en[:, :5]).all()
