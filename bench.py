@@ -373,6 +373,28 @@ def measure(workload, args, ctx, headline):
         dt = (time.perf_counter() - t) / k2
         out["host_landed"] = {"ms_per_step": dt * 1e3, "GB/s": bytes_job / dt / 1e9, "d2h_bytes_per_step": sh.per_words * 8 + (8 * n_rows if is_find else 0),
                               "note": "scan + D2H of the results into pinned host memory, every step"}
+    if rank == 0 and world == 1 and not args.no_extras and workload == "c3" and is_find:
+        # EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
+        # the batch (needle_find_all.hip): counts + dense per-row slots.  Its own figure, never the `value`.
+        slots = 32
+        fc = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        fs = torch.full((n_rows, slots), -1, dtype=torch.int32, device=dev)
+        fe = torch.full((n_rows, slots), -1, dtype=torch.int32, device=dev)
+        more = pattern.find_all_dense(rows, slots, out=(fc, fs, fe))[3]
+        torch.cuda.synchronize()
+        k2 = max(3, args.steps // 4)
+        t = time.perf_counter()
+        for _ in range(k2):
+            pattern.find_all_dense(rows, slots, out=(fc, fs, fe))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / k2
+        n_matches = int(fc.sum().item())
+        fa_bytes = n_rows * (256 * cw + 4) + 8 * n_matches
+        out["find_all"] = {"ms_per_step": dt * 1e3, "matches": n_matches, "matches_per_s": n_matches / dt, "max_per_row": int(fc.max().item()),
+                           "slots": slots, "more": bool(more), "GB/s": fa_bytes / dt / 1e9, "algorithmic_bytes": fa_bytes,
+                           "kernel": "needle::find_all_kernel",
+                           "note": "every non-overlapping match per row (repeated Matcher.find()), one pass; bytes = rows + 4 B count per row + 8 B per match"}
+        del fc, fs, fe
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(workload, pattern, rows, op_name, 10.0 if headline else 4.0)
     del rows, sh, graphs

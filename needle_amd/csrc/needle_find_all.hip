@@ -143,9 +143,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
     // indexBackwards(en - 1, bound), :536-583, for the lanes of `act`; the tile in LDS holds the row bytes
     // [tile_b0, tile_b0 + CHB), anything else is read from memory.
     auto backward = [&](bool act, int32_t en, int32_t bound, uint32_t tile_b0) __attribute__((always_inline)) -> int32_t {
-        const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
-        const uint16_t *bt = a.hdr.off_btable ? (const uint16_t *)(smem + a.hdr.off_btable)
-                                               : (const uint16_t *)(a.bprog + a.bhdr.off_table);
+        const uint16_t *gbt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
         const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
         int32_t idx_b = en - 1;
         uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
@@ -160,8 +158,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 const bool in_tile = rel < (uint32_t)CHB;
                 const uint32_t ad = tile.row_addr + ((in_tile ? rel : 0u) ^ swz16);
                 const uint32_t held = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
-                cs[k] = 0;
-                if (active && p >= bound) cs[k] = in_tile ? held : ((CW == 1) ? (uint32_t)rowp[p] : (uint32_t)((const uint16_t *)rowp)[p]);
+                uint32_t c = 0;
+                if (active && p >= bound) {
+                    c = held;
+                    if (!in_tile) { // text of an earlier tile (rare): waited for inside the branch, as in walk_tile
+                        c = (CW == 1) ? (uint32_t)rowp[p] : (uint32_t)((const uint16_t *)rowp)[p];
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c));
+                    }
+                }
+                cs[k] = c;
             }
             if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton
                 uint32_t fb[8];
@@ -191,14 +196,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                         if (idx_b < bound) {
                             active = false;
                         } else {
-                            const uint32_t col = column_of<CW>(bcmap, bptab, bpages, cs[k]);
+                            uint32_t col; // the backward automaton's char -> column maps, at absolute LDS addresses
+                            if (CW == 1) col = lds_u8(a.hdr.off_bcmap + cs[k]);
+                            else col = lds_u8(a.hdr.off_bpages + ((lds_u8(a.hdr.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
                             if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
                                 const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
                                 const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col) - 1u));
                                 const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
                                 bs = ((bm >> col) & 1u) ? tgt : 0u;
-                            } else {
-                                bs = bt[bs * bcols + col];
+                            } else if (a.hdr.off_btable) { // wave-uniform: small dense table in LDS
+                                bs = lds_u16(a.hdr.off_btable + (bs * bcols + col) * 2u);
+                            } else { // dense table in HBM / L2 (waited for here: no vmcnt wait on the other paths)
+                                bs = gbt[bs * bcols + col];
+                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(bs));
                             }
                             if (bs == 0) {
                                 active = false;
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
         row_ok = my_row < a.n_rows;
         len = 0;
         if (row_ok) len = a.lengths ? a.lengths[my_row] : a.row_len;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(len)); // (the tile it is about to stage was requested earlier still)
         const uint32_t max_len = a.lengths ? wave_max(len) : a.row_len;
         n_chunks = (max_len * CW + CHB - 1) / CHB;
         if (n_chunks == 0) n_chunks = 1;
@@ -264,7 +275,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 u32x4 v = {0, 0, 0, 0};
                 if (!beyond) {
                     if (pi >= tile_p0) v = *(const lds_u32x4 *)(uintptr_t)(tile.row_addr + (((pi - tile_p0) << 4) ^ swz16));
-                    else v = *(const u32x4 *)(rowp + (uint64_t)pi * 16u); // a restart in the previous tile
+                    else { // a restart in the previous tile (rare): waited for HERE, so that the common path carries no
+                           // vmcnt wait -- it would also wait for the tile prefetch and for every match store in flight
+                        v = *(const u32x4 *)(rowp + (uint64_t)pi * 16u);
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
+                    }
                 }
                 const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
                 const uint32_t skip_rel = (uint32_t)cursor > p0 ? (uint32_t)cursor - p0 : 0u; // < CPP: the cursor's piece, or none
