@@ -270,53 +270,58 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             const bool beyond = p0 >= len; // nothing of the row there (a walk over PAD: the search ends)
             const bool active = !done && (pi < tile_p1 || beyond);
             if (__ballot(active) == 0ull) break;
-            bool ended = false;
-            if (active) {
-                u32x4 v = {0, 0, 0, 0};
-                if (!beyond) {
-                    if (pi >= tile_p0) v = *(const lds_u32x4 *)(uintptr_t)(tile.row_addr + (((pi - tile_p0) << 4) ^ swz16));
-                    else { // a restart in the previous tile (rare): waited for HERE, so that the common path carries no
-                           // vmcnt wait -- it would also wait for the tile prefetch and for every match store in flight
-                        v = *(const u32x4 *)(rowp + (uint64_t)pi * 16u);
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
-                    }
+            // The iteration is straight-line code for all 64 lanes -- idle lanes walk a piece too and their results are
+            // dropped by selects: every divergent region here costs the compiler a copy of the loop-carried lane state per
+            // path, and with it more VALU ops than the walk itself.
+            const bool in_lds = active && !beyond && pi >= tile_p0;
+            u32x4 v = *(const lds_u32x4 *)(uintptr_t)(tile.row_addr + (((in_lds ? pi - tile_p0 : 0u) << 4) ^ swz16));
+            const bool in_mem = active && !beyond && pi < tile_p0;
+            if (__ballot(in_mem) != 0ull) { // a restart in the previous tile (rare): waited for HERE, so that the common path
+                                            // carries no vmcnt wait (tile prefetch and match stores are in flight)
+                if (in_mem) {
+                    v = *(const u32x4 *)(rowp + (uint64_t)pi * 16u);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
                 }
-                const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
-                const uint32_t skip_rel = (uint32_t)cursor > p0 ? (uint32_t)cursor - p0 : 0u; // < CPP: the cursor's piece, or none
-                uint32_t acc = walk_piece_fa<CW, MODE>(wk, w, skip_rel, accept_lo, st);
-                const uint32_t in_row = len > p0 ? len - p0 : 0u; // chars of the piece inside the row (all, if >= CPP)
-                acc &= ~((1u << skip_rel) - 1u);                   // an accepting start state does not count before the cursor
-                if (in_row < (uint32_t)CPP) acc &= (1u << in_row) - 1u;
-                last = acc ? (int32_t)(p0 + 32u - (uint32_t)__builtin_clz(acc)) : last;
-                ended = st == 0u || p0 + CPP >= len;
-                if (!ended) ++pi;
             }
+            const uint32_t w[4] = {v[0], v[1], v[2], v[3]}; // (a piece beyond the row: whatever is there -- its flags are masked)
+            const uint32_t skip_rel = (uint32_t)cursor > p0 ? (uint32_t)cursor - p0 : 0u; // < CPP: the cursor's piece, or none
+            uint32_t st_new = st;
+            uint32_t acc = walk_piece_fa<CW, MODE>(wk, w, skip_rel, accept_lo, st_new);
+            const uint32_t in_row = len > p0 ? len - p0 : 0u; // chars of the piece inside the row (all, if >= CPP)
+            acc &= ~((1u << skip_rel) - 1u);                   // an accepting start state does not count before the cursor
+            acc &= in_row < (uint32_t)CPP ? (1u << in_row) - 1u : 0xFFFFFFFFu;
+            acc = active ? acc : 0u;
+            last = acc ? (int32_t)(p0 + 32u - (uint32_t)__builtin_clz(acc)) : last;
+            st = active ? st_new : st;
+            const bool ended = active && (st_new == 0u || p0 + CPP >= len);
+            pi += (active && !ended) ? 1u : 0u;
             if (__ballot(ended) == 0ull) continue;
             // ---- find() returns for the lanes of `ended` (:629-657)
             const bool hit = ended && last >= 0;
             const int32_t en = last;
             if (ended && !hit) done = true; // no further match in this row
             if (fa.defer) {
-                // not nullable, start by indexBackwards: the match is not empty and ends beyond its cursor -- the row goes on
-                if (hit) {
-                    if (count < fa.slots) {
-                        fa.ends[my_row * fa.slots + count] = en;
-                        ++count;
-                        if (n_pend == 0u) pend_bound = cursor;
-                        pend[3] = __builtin_amdgcn_alignbit(pend[3], pend[2], 16); // push
-                        pend[2] = __builtin_amdgcn_alignbit(pend[2], pend[1], 16);
-                        pend[1] = __builtin_amdgcn_alignbit(pend[1], pend[0], 16);
-                        pend[0] = (pend[0] << 16) | (uint32_t)en;
-                        ++n_pend;
-                        cursor = en;
-                        st = start_state;
-                        last = -1;
-                        pi = ((uint32_t)en * CW) >> 4;
-                    } else {
-                        *fa.more = 1;
-                        done = true;
-                    }
-                }
+                // not nullable, start by indexBackwards: the match is not empty and ends beyond its cursor -- the row goes on.
+                // Written as selects, not branches: this block runs in most iterations (some lane of 64 has just resolved)
+                // and every divergent branch costs a copy of the loop-carried lane state per path.
+                const bool file = hit && count < fa.slots;
+                if (hit && !file) *fa.more = 1;
+                done = done || (hit && !file);
+                if (file) fa.ends[my_row * fa.slots + count] = en;
+                pend_bound = (file && n_pend == 0u) ? cursor : pend_bound;
+                // push: a lane that files nothing shifts by nothing (v_perm selectors chosen per lane)
+                const uint32_t sel_hi = file ? 0x05040302u : 0x07060504u; // {hi.lo16, lo.hi16} | hi unchanged: v_perm_b32(hi, lo, sel), bytes 4-7 = hi
+                pend[3] = __builtin_amdgcn_perm(pend[3], pend[2], sel_hi);
+                pend[2] = __builtin_amdgcn_perm(pend[2], pend[1], sel_hi);
+                pend[1] = __builtin_amdgcn_perm(pend[1], pend[0], sel_hi);
+                pend[0] = __builtin_amdgcn_perm(pend[0], (uint32_t)en, file ? 0x05040100u : 0x07060504u);
+                const uint32_t one = file ? 1u : 0u;
+                count += one;
+                n_pend += one;
+                cursor = file ? en : cursor;
+                st = file ? start_state : st;
+                last = file ? -1 : last;
+                pi = file ? (((uint32_t)en * CW) >> 4) : pi;
                 if (__ballot(n_pend == 8u) != 0ull) flush_pending(tile_b0);
             } else {
                 int32_t s = en - a.fixed_len;
