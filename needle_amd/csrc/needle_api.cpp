@@ -958,25 +958,16 @@ static int find_all_rounds(const needle_pattern *p, const needle_batch_view *v, 
     return done(NEEDLE_OK);
 }
 
-int needle_find_all_dev(const needle_pattern *cp, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
-                        int32_t *d_end, int *more, void *stream_) {
-    needle_pattern *p = const_cast<needle_pattern *>(cp);
-    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
-    int rc = check_view(v, true);
-    if (rc) return rc;
-    if (more) *more = 0;
-    if (v->n_rows == 0) return NEEDLE_OK;
-    if (!d_counts || (slots && (!d_start || !d_end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
-    hipStream_t stream = (hipStream_t)stream_;
-    static const bool rounds = getenv("NEEDLE_FIND_ALL_ROUNDS") && atoi(getenv("NEEDLE_FIND_ALL_ROUNDS")) != 0;
+// One pass over the batch: every row is fetched once, each lane restarts its search where its last match ended
+// (needle_find_all.hip).  Dense slots (offsets == nullptr), compact filing at caller-computed offsets, or counting only.
+static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
+                             int32_t *d_end, const uint64_t *d_offsets, bool count_only, int *more, hipStream_t stream) {
     const uint64_t stride_bytes = v->row_stride * v->char_width;
-    if (rounds || stride_bytes >= (1ull << 26)) return find_all_rounds(p, v, slots, d_counts, d_start, d_end, more, stream);
-
-    // one pass: every row is fetched once, each lane restarts its search where its last match ended (needle_find_all.hip)
+    if (stride_bytes >= (1ull << 26)) return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more: only needle_find_all_dev (round per match) takes them");
     const DevProgram *fp = nullptr, *bp = nullptr;
     int n_cus = 0;
     const bool need_backward = p->t.fixed_len < 0;
-    rc = get_program(p, W_FORWARDS, (int)v->char_width, need_backward ? 5 : 4, &fp, &n_cus);
+    int rc = get_program(p, W_FORWARDS, (int)v->char_width, need_backward ? 5 : 4, &fp, &n_cus);
     if (rc) return rc;
     FindAllArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -997,6 +988,8 @@ int needle_find_all_dev(const needle_pattern *cp, const needle_batch_view *v, ui
         a.bhdr = bp->prog.hdr;
     }
     fa.slots = slots;
+    fa.offsets = d_offsets;
+    fa.count_only = count_only ? 1u : 0u;
     static const bool no_defer = getenv("NEEDLE_FIND_ALL_DEFER") && atoi(getenv("NEEDLE_FIND_ALL_DEFER")) == 0; // A/B, tests
     fa.defer = (a.fixed_len < 0 && !a.hdr.root_accepting && v->row_stride <= 65535 && !no_defer) ? 1u : 0u;
     static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr; // measurement aid: start = the search cursor
@@ -1023,6 +1016,44 @@ int needle_find_all_dev(const needle_pattern *cp, const needle_batch_view *v, ui
     }
     return done(NEEDLE_OK);
 }
+
+int needle_find_all_dev(const needle_pattern *cp, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
+                        int32_t *d_end, int *more, void *stream_) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, true);
+    if (rc) return rc;
+    if (more) *more = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_counts || (slots && (!d_start || !d_end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    static const bool rounds = getenv("NEEDLE_FIND_ALL_ROUNDS") && atoi(getenv("NEEDLE_FIND_ALL_ROUNDS")) != 0;
+    if (rounds || v->row_stride * v->char_width >= (1ull << 26)) return find_all_rounds(p, v, slots, d_counts, d_start, d_end, more, stream);
+    return find_all_one_pass(p, v, slots, d_counts, d_start, d_end, nullptr, false, more, stream);
+}
+
+int needle_count_matches_dev(const needle_pattern *cp, const needle_batch_view *v, uint32_t *d_counts, void *stream_) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, true);
+    if (rc) return rc;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_counts) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    return find_all_one_pass(p, v, 0, d_counts, nullptr, nullptr, nullptr, true, nullptr, (hipStream_t)stream_);
+}
+
+int needle_find_all_csr_dev(const needle_pattern *cp, const needle_batch_view *v, const uint64_t *d_offsets, int32_t *d_start, int32_t *d_end,
+                            int *more, void *stream_) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, true);
+    if (rc) return rc;
+    if (more) *more = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_offsets || !d_start || !d_end) return fail(NEEDLE_ERR_INVALID, "offsets / output buffer is NULL");
+    return find_all_one_pass(p, v, 0, nullptr, d_start, d_end, d_offsets, false, more, (hipStream_t)stream_);
+}
+
 static int find_all_host_one(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
                              int32_t *end, int *more) {
     const size_t cw = v->char_width, n = (size_t)v->n_rows;

@@ -102,6 +102,9 @@ struct FindAllArgs {
     int32_t *starts;   // [n_rows][slots]
     int32_t *ends;     // [n_rows][slots]
     int32_t *more;     // set to 1 when some row has a match beyond its last slot
+    const uint64_t *offsets; // != nullptr: compact (CSR) filing -- match k of row r at offsets[r] + k, room for
+                             // offsets[r + 1] - offsets[r] matches; slots is not used
+    uint32_t count_only;     // 1: nothing is filed (starts / ends may be null), every match is counted
 };
 
 // Long rows of table-mode automata (needle_stripe.hip, "speculative stripes"): every stripe is first scanned as a row of

@@ -139,6 +139,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
     uint32_t pend[4] = {0, 0, 0, 0};
     uint32_t n_pend = 0;
     int32_t pend_bound = 0; // the cursor the OLDEST pending match was searched from
+    uint64_t out0 = 0;      // index of this row's first result slot (dense: row * slots; compact: offsets[row])
+    uint32_t cap = 0;       // matches this row may file
 
     // indexBackwards(en - 1, bound), :536-583, for the lanes of `act`; the tile in LDS holds the row bytes
     // [tile_b0, tile_b0 + CHB), anything else is read from memory.
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             if (act) --n_pend;
             const int32_t bound = n_pend ? (int32_t)(pend[0] & 0xFFFFu) : pend_bound;
             const int32_t s = fa.defer == 2u ? bound : backward(act, en, bound, tile_b0); // (2: measurement aid)
-            if (act) fa.starts[my_row * fa.slots + first + n_pend] = s;
+            if (act) fa.starts[out0 + first + n_pend] = s;
         }
     };
 
@@ -260,6 +262,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
         count = 0;
         n_pend = 0;
         pend_bound = 0;
+        out0 = my_row * fa.slots;
+        cap = fa.count_only ? 0xFFFFFFFFu : fa.slots;
+        if (fa.offsets) {
+            out0 = row_ok ? fa.offsets[my_row] : 0;
+            cap = row_ok ? (uint32_t)(fa.offsets[my_row + 1] - out0) : 0u;
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cap)); // (as for len above: no vmcnt wait inside the walk)
+        }
     };
 
     // Walk the tile in LDS (chunk ck of the group's rows) until every live lane is past it.
@@ -304,20 +313,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 // not nullable, start by indexBackwards: the match is not empty and ends beyond its cursor -- the row goes on.
                 // Written as selects, not branches: this block runs in most iterations (some lane of 64 has just resolved)
                 // and every divergent branch costs a copy of the loop-carried lane state per path.
-                const bool file = hit && count < fa.slots;
+                const bool file = hit && count < cap;
                 if (hit && !file) *fa.more = 1;
                 done = done || (hit && !file);
-                if (file) fa.ends[my_row * fa.slots + count] = en;
-                pend_bound = (file && n_pend == 0u) ? cursor : pend_bound;
+                const bool push = file && !fa.count_only; // (counting: no starts wanted, nothing pends)
+                if (push) fa.ends[out0 + count] = en;
+                pend_bound = (push && n_pend == 0u) ? cursor : pend_bound;
                 // push: a lane that files nothing shifts by nothing (v_perm selectors chosen per lane)
-                const uint32_t sel_hi = file ? 0x05040302u : 0x07060504u; // {hi.lo16, lo.hi16} | hi unchanged: v_perm_b32(hi, lo, sel), bytes 4-7 = hi
+                const uint32_t sel_hi = push ? 0x05040302u : 0x07060504u; // {hi.lo16, lo.hi16} | hi unchanged: v_perm_b32(hi, lo, sel), bytes 4-7 = hi
                 pend[3] = __builtin_amdgcn_perm(pend[3], pend[2], sel_hi);
                 pend[2] = __builtin_amdgcn_perm(pend[2], pend[1], sel_hi);
                 pend[1] = __builtin_amdgcn_perm(pend[1], pend[0], sel_hi);
-                pend[0] = __builtin_amdgcn_perm(pend[0], (uint32_t)en, file ? 0x05040100u : 0x07060504u);
-                const uint32_t one = file ? 1u : 0u;
-                count += one;
-                n_pend += one;
+                pend[0] = __builtin_amdgcn_perm(pend[0], (uint32_t)en, push ? 0x05040100u : 0x07060504u);
+                count += file ? 1u : 0u;
+                n_pend += push ? 1u : 0u;
                 cursor = file ? en : cursor;
                 st = file ? start_state : st;
                 last = file ? -1 : last;
@@ -330,9 +339,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 const bool valid = hit && en >= s;
                 if (hit && !valid) done = true;
                 if (valid) {
-                    if (count < fa.slots) {
-                        fa.starts[my_row * fa.slots + count] = s;
-                        fa.ends[my_row * fa.slots + count] = en;
+                    if (count < cap) {
+                        if (!fa.count_only) {
+                            fa.starts[out0 + count] = s;
+                            fa.ends[out0 + count] = en;
+                        }
                         ++count;
                         // the row goes on only while the cursor advances (needle_hip.h)
                         if (en == s || en <= cursor) {
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
         if (fa.defer) flush_pending(tile_b0);
     };
     auto end_group = [&]() __attribute__((always_inline)) {
-        if (row_ok) fa.counts[my_row] = count;
+        if (row_ok && fa.counts) fa.counts[my_row] = count;
     };
     auto stage = [&](auto tc) __attribute__((always_inline)) {
         constexpr int T = decltype(tc)::value;

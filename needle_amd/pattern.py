@@ -322,26 +322,62 @@ class Pattern:
                                          en.data_ptr(), ctypes.byref(more), s))
         return counts, st, en, bool(more.value)
 
+    def _dev_view(self, rows, lengths):
+        import torch
+        assert isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dim() == 2 and rows.is_contiguous()
+        v = BatchView()
+        n, stride = rows.shape
+        v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.data_ptr(), rows.element_size(), n, stride, stride
+        if lengths is not None:
+            assert lengths.is_cuda and lengths.dtype == torch.int32 and lengths.shape == (n,)
+            v.lengths = lengths.data_ptr()
+        return v
+
+    def count_matches_batch(self, rows, lengths=None, stream=None):
+        """needle_count_matches_dev: int32[n_rows], the number of non-overlapping matches of every row."""
+        import torch
+        L = _lib.lib()
+        v = self._dev_view(rows, lengths)
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            counts = torch.empty(rows.shape[0], dtype=torch.int32, device=rows.device)
+            _check(L.needle_count_matches_dev(self._h, ctypes.byref(v), counts.data_ptr(), s))
+        return counts
+
+    def find_all_csr(self, rows, lengths=None, stream=None):
+        """Every non-overlapping match of every row in compact form, two passes over the batch: count
+        (needle_count_matches_dev), exclusive prefix sum, fill (needle_find_all_csr_dev).
+        -> (offsets int64[n_rows + 1], start int32[m], end int32[m])"""
+        import torch
+        L = _lib.lib()
+        v = self._dev_view(rows, lengths)
+        n = rows.shape[0]
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            counts = self.count_matches_batch(rows, lengths, stream)
+            offsets = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)
+            torch.cumsum(counts, 0, out=offsets[1:])
+            total = int(offsets[-1].item())
+            st = torch.empty(total, dtype=torch.int32, device=rows.device)
+            en = torch.empty(total, dtype=torch.int32, device=rows.device)
+            more = ctypes.c_int(0)
+            _check(L.needle_find_all_csr_dev(self._h, ctypes.byref(v), offsets.data_ptr(), st.data_ptr(), en.data_ptr(), ctypes.byref(more), s))
+            assert not more.value, "count pass and fill pass disagree"
+        return offsets, st, en
+
     def find_all_batch(self, rows, lengths=None, max_rounds=None):
         """Every non-overlapping match of every row, as the reference's repeated find() would report them
-        (DFACompilerTest.java:66-78,671-699): one launch per round over the rows that still have a cursor, results
-        compacted on the device.  -> (offsets int64[n_rows + 1], start int32[m], end int32[m]) in CSR form.
+        (DFACompilerTest.java:66-78,671-699) -> (offsets int64[n_rows + 1], start int32[m], end int32[m]) in CSR form:
+        find_all_csr (count pass, prefix sum, fill pass); with max_rounds, or for rows of 64 MiB and more, one
+        find_next launch per round over the rows that still have a cursor.
         A row ends where the reference's cursor stops advancing: an EMPTY match (or any match that does not end beyond
         the cursor it was searched from) is reported once and ends its row; a nullable pattern's wrapped pseudo-match
         at cursor == length (start = length, end = 0), on which the reference would cycle for ever, is dropped."""
         import torch
         n = rows.shape[0]
         dev = rows.device
-        if max_rounds is None:  # the library's own rounds, dense slots -> CSR; rows with very many matches: loop below
-            for slots in (4, 16, 64):
-                if n * slots > (1 << 31):
-                    break
-                counts, st, en, more = self.find_all_dense(rows, slots, lengths)
-                if not more:
-                    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-                    offsets[1:] = torch.cumsum(counts, 0)
-                    keep = torch.arange(slots, device=dev, dtype=torch.int32)[None, :] < counts[:, None]
-                    return offsets, st[keep], en[keep]
+        if max_rounds is None and rows.shape[1] * rows.element_size() < (1 << 26):  # count, prefix sum, fill: two passes
+            return self.find_all_csr(rows, lengths)
         cursor = torch.zeros(n, dtype=torch.int32, device=dev)
         ids = torch.arange(n, dtype=torch.int64, device=dev)
         counts = torch.zeros(n, dtype=torch.int64, device=dev)

@@ -39,6 +39,14 @@ for slots in (most, 3):
         assert counts[i] == k, (i, counts[i], want[i])
         assert list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == want[i][:k], (i, want[i])
         assert (st[i, k:] == -1).all() and (en[i, k:] == -1).all()  # slots beyond the count are untouched
+# compact form: count pass, prefix sum, fill pass (needle_count_matches_dev / needle_find_all_csr_dev)
+cnt = p.count_matches_batch(rows).cpu().numpy()
+assert (cnt == [len(w) for w in want]).all()
+offsets, s1, e1 = p.find_all_csr(rows)
+offsets, s1, e1 = offsets.cpu().numpy(), s1.cpu().numpy(), e1.cpu().numpy()
+assert offsets[-1] == sum(len(w) for w in want) == len(s1) == len(e1)
+for i in range(n):
+    assert list(zip(s1[offsets[i]:offsets[i + 1]].tolist(), e1[offsets[i]:offsets[i + 1]].tolist())) == want[i], i
 # the round-per-match loop over the scan kernel's per-row cursors (find_next): an independent GPU path
 offsets, s2, e2 = p.find_all_batch(rows, max_rounds=most + 2)
 offsets, s2, e2 = offsets.cpu().numpy(), s2.cpu().numpy(), e2.cpu().numpy()
@@ -107,6 +115,13 @@ def test_every_match_across_tile_boundaries(regex, stride):
         if most > 1:
             c2, _, _, more2 = p.find_all_dense(t, most - 1, tl)
             assert more2 and (c2.cpu().numpy() == np.minimum(counts, most - 1)).all()
+        # compact form (count, prefix sum, fill) and the CSR wrapper built on it
+        assert (p.count_matches_batch(t, tl).cpu().numpy() == [len(w) for w in want]).all()
+        offsets, s1, e1 = p.find_all_batch(t, tl)
+        offsets, s1, e1 = offsets.cpu().numpy(), s1.cpu().numpy(), e1.cpu().numpy()
+        assert offsets[-1] == sum(len(w) for w in want)
+        for i in range(n):
+            assert list(zip(s1[offsets[i]:offsets[i + 1]].tolist(), e1[offsets[i]:offsets[i + 1]].tolist())) == want[i], i
 
 
 @pytest.mark.gpu
