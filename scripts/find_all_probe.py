@@ -36,19 +36,20 @@ out["more"] = bool(more)
 out["GB/s"] = round(n * 256 * cw / best / 1e9, 1)
 out["matches/s"] = round(total / best / 1e6, 1)
 # compact form: count pass + fill pass (find_all_csr also allocates and prefix-sums: timed apart)
-for rep in range(3):
+for rep in range(0 if os.environ.get("FIND_ALL_PROBE_DENSE_ONLY") else 3):
     t0 = time.perf_counter()
     cnt = pattern.count_matches_batch(rows)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out["count_ms"] = round(dt * 1e3, 3) if rep == 0 or dt * 1e3 < out["count_ms"] else out["count_ms"]
-for rep in range(3):
+for rep in range(0 if os.environ.get("FIND_ALL_PROBE_DENSE_ONLY") else 3):
     t0 = time.perf_counter()
     offs, cs, ce = pattern.find_all_csr(rows)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out["csr_ms"] = round(dt * 1e3, 3) if rep == 0 or dt * 1e3 < out["csr_ms"] else out["csr_ms"]
-assert int(offs[-1].item()) == total or more
+if not os.environ.get("FIND_ALL_PROBE_DENSE_ONLY"):
+    assert int(offs[-1].item()) == total or more
 if len(sys.argv) > 4 and sys.argv[4] == "check":
     import numpy as np
     from oracle.walker import Dfa, OraclePattern

@@ -7,7 +7,7 @@ OUT=gpurun_out/pmc_fa_${W}_${TAG}
 mkdir -p $OUT
 i=0
 for grp in "$@"; do
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p -- python scripts/find_all_probe.py $W 10000000 32 > $OUT/p$i.json 2> $OUT/p$i.log
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p -- env FIND_ALL_PROBE_DENSE_ONLY=1 python scripts/find_all_probe.py $W 10000000 32 > $OUT/p$i.json 2> $OUT/p$i.log
   python - "$OUT/p$i/p_counter_collection.csv" <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "find_all_kernel" in r["Kernel_Name"]]
