@@ -360,6 +360,8 @@ class Pattern:
             total = int(offsets[-1].item())
             st = torch.empty(total, dtype=torch.int32, device=rows.device)
             en = torch.empty(total, dtype=torch.int32, device=rows.device)
+            if total == 0:
+                return offsets, st, en
             more = ctypes.c_int(0)
             _check(L.needle_find_all_csr_dev(self._h, ctypes.byref(v), offsets.data_ptr(), st.data_ptr(), en.data_ptr(), ctypes.byref(more), s))
             assert not more.value, "count pass and fill pass disagree"

@@ -55,6 +55,18 @@ def test_random_regexes_on_random_haystacks(seed):
         of, os_, oe = o.batch_find(full, threads=4)
         assert (unpack_bitmap(fw, 1024) == of).all(), (regex, flags)
         assert (fs.cpu().numpy() == os_).all() and (fe.cpu().numpy() == oe).all(), (regex, flags)
+        # every non-overlapping match of every row (the one-pass find-all kernel, compact form), full and ragged UTF-16 rows
+        pad72 = np.zeros((n, 72), dtype=np.uint16)  # device batches: row stride a multiple of 16 bytes
+        pad72[:, :70] = pad
+        for rows_t, lens_t, host, host_lens in ((t, None, full, None),
+                                                (torch.from_numpy(pad72.view(np.int16)).cuda(), torch.from_numpy(L.astype(np.int32)).cuda(), pad72, L)):
+            sub = range(0, host.shape[0], 3)
+            offs, s_all, e_all = p.find_all_batch(rows_t, lens_t)
+            offs, s_all, e_all = offs.cpu().numpy(), s_all.cpu().numpy(), e_all.cpu().numpy()
+            for i in sub:
+                want = o.find_all(host[i] if host_lens is None else host[i, :host_lens[i]])
+                got = list(zip(s_all[offs[i]:offs[i + 1]].tolist(), e_all[offs[i]:offs[i + 1]].tolist()))
+                assert got == want, (regex, flags, "find-all", i, got[:4], want[:4])
         # short rows (stride <= 64 B: the register-resident kernel), ragged and full
         lens_s = nrng.integers(0, 25, n)
         rows_s = [nrng.choice(ALPHABET, int(l)).astype(np.uint16) for l in lens_s]
