@@ -12,6 +12,7 @@
 
 #include "../../include/needle_hip.h"
 #include "needle_device.h"
+#include "needle_find_all.h"
 #include "needle_lower.h"
 #include "needle_regex.h"
 

@@ -92,21 +92,6 @@ struct ScanArgs {
                              // a 128-byte line hands them to its wave's pool and ends; 0 = off
 };
 
-// Every non-overlapping match of every row in one pass (needle_find_all.hip).
-struct FindAllArgs {
-    ScanArgs s;        // rows, lengths, forward program (+ backward maps), backward program, fixed_len; no outputs
-    uint32_t slots;    // matches filed per row at most
-    uint32_t defer;    // 1: starts by indexBackwards, found tile by tile for all pending matches of a wave at once (pattern
-                       // not nullable, row indices fit 16 bits); 0: every start at the moment its match is found
-    uint32_t *counts;  // [n_rows]
-    int32_t *starts;   // [n_rows][slots]
-    int32_t *ends;     // [n_rows][slots]
-    int32_t *more;     // set to 1 when some row has a match beyond its last slot
-    const uint64_t *offsets; // != nullptr: compact (CSR) filing -- match k of row r at offsets[r] + k, room for
-                             // offsets[r + 1] - offsets[r] matches; slots is not used
-    uint32_t count_only;     // 1: nothing is filed (starts / ends may be null), every match is counted
-};
-
 // Long rows of table-mode automata (needle_stripe.hip, "speculative stripes"): every stripe is first scanned as a row of
 // its own from the START state (the tiled kernel, all stripes in parallel); then each stripe whose true entry state
 // differs is re-walked next to the speculative run until the two states meet.

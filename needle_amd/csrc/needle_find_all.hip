@@ -24,6 +24,7 @@
 // string need every start at once -- an empty match ends its row (see needle_find_all_dev in needle_hip.h) -- and take
 // the immediate form, as do rows too long for 16-bit indices.
 #include "needle_walk.h"
+#include "needle_find_all.h"
 
 namespace needle {
 
