@@ -1,5 +1,5 @@
 /* A C host of libneedle_hip.so: compile a regex, put a small fixed-stride batch in HBM, run the three ops and
- * find-all, print the results.
+ * find-all (dense slots, then the compact form), print the results.
  *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/scan_rows.c \
  *       -Lneedle_amd -lneedle_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/needle_amd -o scan_rows
  * (plain C: the HIP runtime is only used for hipMalloc / hipMemcpy). */
@@ -75,6 +75,32 @@ int main(void) {
         printf("\n");
     }
     printf("more=%d\n", more);
+
+    /* the same enumeration in compact form: count pass, prefix sum (here on the host: 5 rows), fill pass */
+    {
+        uint64_t offsets[ROWS + 1];
+        int32_t csr_s[ROWS * 4], csr_e[ROWS * 4];
+        void *d_off;
+        if (needle_count_matches_dev(p, &v, (uint32_t *)d_cnt, NULL) != NEEDLE_OK) {
+            printf("count failed: %s\n", needle_last_error());
+            return 1;
+        }
+        hipDeviceSynchronize();
+        hipMemcpy(counts, d_cnt, sizeof(counts), hipMemcpyDeviceToHost);
+        offsets[0] = 0;
+        for (r = 0; r < ROWS; ++r) offsets[r + 1] = offsets[r] + counts[r];
+        hipMalloc(&d_off, sizeof(offsets));
+        hipMemcpy(d_off, offsets, sizeof(offsets), hipMemcpyHostToDevice);
+        if (needle_find_all_csr_dev(p, &v, (const uint64_t *)d_off, (int32_t *)d_as, (int32_t *)d_ae, &more, NULL) != NEEDLE_OK) {
+            printf("csr failed: %s\n", needle_last_error());
+            return 1;
+        }
+        hipMemcpy(csr_s, d_as, sizeof(csr_s), hipMemcpyDeviceToHost);
+        hipMemcpy(csr_e, d_ae, sizeof(csr_e), hipMemcpyDeviceToHost);
+        printf("csr total=%d more=%d:", (int)offsets[ROWS], more);
+        for (k = 0; k < (int)offsets[ROWS]; ++k) printf(" (%d,%d)", csr_s[k], csr_e[k]);
+        printf("\n");
+    }
     needle_pattern_destroy(p);
     return 0;
 }

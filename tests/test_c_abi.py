@@ -49,3 +49,4 @@ def test_c_example_runs(tmp_path):
     assert 'row 3 "a1b22c333": found=1 first=(1,2) all=(1,2)(3,5)(6,9)' in out
     assert 'row 4 "2024-01-31": found=1 first=(0,4) all=(0,4)(5,7)(8,10)' in out
     assert "more=0" in out
+    assert "csr total=7 more=0: (6,8) (1,2) (3,5) (6,9) (0,4) (5,7) (8,10)" in out
