@@ -492,7 +492,10 @@ def main():
     if also:
         out["workloads"] = {}
         for w in also:
-            r, _ = measure(w, args, ctx, False)
+            try:
+                r, _ = measure(w, args, ctx, False)
+            except Exception as e:  # noqa: BLE001 -- a further workload must never cost the headline its line
+                r = {"error": "%s: %s" % (type(e).__name__, e)}
             out["workloads"][w] = r
     if rank == 0:
         print(json.dumps(out))
