@@ -10,10 +10,13 @@
 // [start, end) the reference restarts the search automaton AT `end` -- chars the walk already consumed while it
 // waited for the automaton to die -- so the rows of a wave stop being at the same char.  Every lane therefore keeps its
 // own PIECE index (16-byte piece of its row) and the wave iterates "each live lane walks its current piece": a
-// ds_read_b128 at a per-lane tile address, then walk_piece() with the per-char guards, which hide the chars before the
-// lane's cursor (the restart point, anywhere inside a piece) and past its row length.  A lane whose automaton died
-// files the match, moves its cursor to `end`, steps back to the piece holding `end` (from memory, in the rare case it is
-// in the previous tile) and starts again; lanes that reached the tile's end wait there for the others.
+// ds_read_b128 at a per-lane tile address, then walk_piece_fa() below, whose one per-char guard hides the chars before
+// the lane's cursor (the restart point, anywhere inside a piece).  A lane whose automaton died files the match, moves
+// its cursor to `end`, steps back to the piece holding `end` (from memory, in the rare case it is in the previous tile)
+// and starts again; lanes that reached the tile's end wait there for the others.
+//
+// Results: dense per-row slots (needle_find_all_dev), or compact filing at caller-computed offsets after a counting
+// pass of the same kernel that files nothing (needle_count_matches_dev / needle_find_all_csr_dev).
 //
 // Start indices (indexBackwards, :529-586).  A fixed-length pattern has start = end - L.  Otherwise the backward
 // automaton walks right to left from end - 1, bounded by the cursor the match was searched from.  Doing that at the
