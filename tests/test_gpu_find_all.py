@@ -125,6 +125,27 @@ def test_every_match_across_tile_boundaries(regex, stride):
 
 
 @pytest.mark.gpu
+def test_no_slots_and_no_matches():
+    """max_per_row = 0 files nothing and only says whether any row had a match; a batch without matches has an empty
+    compact form."""
+    import torch
+    p, o = _oracle("[0-9]+")
+    rows = torch.from_numpy(np.frombuffer(b"no digits in here, none at all!!" * 200, dtype=np.uint8).reshape(200, 32).copy()).cuda()
+    counts, st, en, more = p.find_all_dense(rows, 0)
+    assert not more and int(counts.sum()) == 0
+    offsets, s1, e1 = p.find_all_batch(rows)
+    assert int(offsets[-1]) == 0 and s1.numel() == 0 and e1.numel() == 0
+    assert int(p.count_matches_batch(rows).sum()) == 0
+    rows[17, 5] = ord("7")
+    counts, st, en, more = p.find_all_dense(rows, 0)
+    assert more and int(counts.sum()) == 0
+    cnt = p.count_matches_batch(rows).cpu().numpy()
+    assert cnt[17] == 1 and cnt.sum() == 1
+    offsets, s1, e1 = p.find_all_batch(rows)
+    assert offsets.cpu().numpy()[17:19].tolist() == [0, 1] and s1.tolist() == [5] and e1.tolist() == [6]
+
+
+@pytest.mark.gpu
 def test_every_match_utf16_script_runs():
     """The C5 regex (runs of Greek / Cyrillic / Hebrew / CJK code units) over UTF-16 rows: packed functions behind the
     two-level page map, one to a few runs per row."""
