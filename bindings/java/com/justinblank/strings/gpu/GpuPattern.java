@@ -111,6 +111,35 @@ public final class GpuPattern implements Pattern, AutoCloseable {
         return more[0] != 0;
     }
 
+    /** Result of {@link #findAllCompact}: row r's matches are start/end[offsets[r] .. offsets[r + 1]). */
+    public static final class Matches {
+        public final long[] offsets;
+        public final int[] start;
+        public final int[] end;
+
+        Matches(long[] offsets, int[] start, int[] end) {
+            this.offsets = offsets;
+            this.start = start;
+            this.end = end;
+        }
+    }
+
+    /**
+     * Every non-overlapping match of every row in compact form (no per-row limit): a counting pass sizes the result,
+     * a second call files it.
+     */
+    public Matches findAllCompact(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen, ByteBuffer lengths) {
+        long[] offsets = new long[(int) nRows + 1];
+        long[] total = new long[1];
+        check(Native.findAllCsrHost(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, offsets, null, null, total), null);
+        int[] start = new int[(int) total[0]];
+        int[] end = new int[(int) total[0]];
+        if (total[0] > 0) {
+            check(Native.findAllCsrHost(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, offsets, start, end, total), null);
+        }
+        return new Matches(offsets, start, end);
+    }
+
     /**
      * find() over an array of haystacks: the strings are flattened to one char buffer + offsets (no per-string
      * Matcher objects, SURVEY.md s8 a9) and cross the boundary once.  Returns the match bitmap.

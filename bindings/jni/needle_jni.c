@@ -143,6 +143,28 @@ NATIVE(jint, findAllHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw,
     return rc;
 }
 
+/* needle_find_all_csr_host: offsets long[nRows + 1]; start / end int[capacity] (may be null with capacity 0: count only);
+ * total long[1]. */
+NATIVE(jint, findAllCsrHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jlongArray offsets, jintArray start, jintArray end, jlongArray total) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    if (!offsets || !total || (*env)->GetArrayLength(env, offsets) < n + 1 || (*env)->GetArrayLength(env, total) < 1) return NEEDLE_ERR_INVALID;
+    jsize cap = start ? (*env)->GetArrayLength(env, start) : 0;
+    if (end && (*env)->GetArrayLength(env, end) < cap) cap = (*env)->GetArrayLength(env, end);
+    if (!end) cap = 0;
+    jlong *of = (*env)->GetLongArrayElements(env, offsets, NULL);
+    jint *st = cap ? (*env)->GetIntArrayElements(env, start, NULL) : NULL;
+    jint *en = cap ? (*env)->GetIntArrayElements(env, end, NULL) : NULL;
+    uint64_t t = 0;
+    int rc = needle_find_all_csr_host((const needle_pattern *)(intptr_t)h, &v, (uint64_t *)of, (int32_t *)st, (int32_t *)en, (uint64_t)cap, &t);
+    jlong jt = (jlong)t;
+    (*env)->SetLongArrayRegion(env, total, 0, 1, &jt);
+    (*env)->ReleaseLongArrayElements(env, offsets, of, 0);
+    if (st) (*env)->ReleaseIntArrayElements(env, start, st, 0);
+    if (en) (*env)->ReleaseIntArrayElements(env, end, en, 0);
+    return rc;
+}
+
 NATIVE(jint, packedHost)(JNIEnv *env, jclass c, jlong h, jint op, jcharArray data, jlongArray offsets, jlongArray bitmap, jintArray start, jintArray end) {
     needle_packed_view v;
     memset(&v, 0, sizeof(v));

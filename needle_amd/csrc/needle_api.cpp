@@ -1094,6 +1094,82 @@ static int find_all_host_one(const needle_pattern *p, const needle_batch_view *v
 }
 
 // (like the other host entry points: at most ~2 GiB of rows + results resident on the device at a time)
+// One chunk of needle_find_all_csr_host: upload, count pass, prefix sum on the host (the counts come back anyway), fill
+// pass while the rows are still resident, download.  offsets: n + 1 entries, offsets[0] given by the caller.
+static int find_all_csr_host_one(const needle_pattern *p, const needle_batch_view *v, uint64_t *offsets, int32_t *start, int32_t *end,
+                                 uint64_t capacity) {
+    const size_t cw = v->char_width, n = (size_t)v->n_rows;
+    const size_t src_stride = (size_t)v->row_stride * cw;
+    size_t dst_stride = (src_stride + 15) & ~(size_t)15;
+    if (dst_stride == 0) dst_stride = 16;
+    uint8_t *d = nullptr, *d_out = nullptr; // rows | lengths | counts | offsets;  start | end
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_len = up16(n * dst_stride), o_cnt = o_len + up16(n * 4), o_off = o_cnt + up16(n * 4), total = o_off + up16((n + 1) * 8);
+    HIP_TRY(hipMalloc((void **)&d, total));
+    auto done = [&](int code) {
+        (void)hipFree(d);
+        if (d_out) (void)hipFree(d_out);
+        return code;
+    };
+    hipError_t e = hipSuccess;
+    if (dst_stride == src_stride) {
+        e = hipMemcpy(d, v->rows, n * src_stride, hipMemcpyHostToDevice);
+    } else {
+        e = hipMemset(d, 0, n * dst_stride);
+        if (e == hipSuccess && src_stride) e = hipMemcpy2D(d, dst_stride, v->rows, src_stride, src_stride, n, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && v->lengths) e = hipMemcpy(d + o_len, v->lengths, n * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host upload"));
+    needle_batch_view dv = *v;
+    dv.rows = d;
+    dv.lengths = v->lengths ? (const uint32_t *)(d + o_len) : nullptr;
+    dv.row_stride = dst_stride / cw;
+    int rc = needle_count_matches_dev(p, &dv, (uint32_t *)(d + o_cnt), nullptr);
+    if (rc) return done(rc);
+    std::vector<uint32_t> counts(n);
+    e = hipMemcpy(counts.data(), d + o_cnt, n * 4, hipMemcpyDeviceToHost); // (synchronises with the count pass)
+    if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host counts"));
+    for (size_t r = 0; r < n; ++r) offsets[r + 1] = offsets[r] + counts[r];
+    const uint64_t m = offsets[n] - offsets[0];
+    if (m == 0 || offsets[n] > capacity) return done(NEEDLE_OK); // nothing to file, or the caller's buffers are too small
+    std::vector<uint64_t> local(n + 1);
+    for (size_t r = 0; r <= n; ++r) local[r] = offsets[r] - offsets[0];
+    e = hipMalloc((void **)&d_out, 2 * up16(m * 4));
+    if (e == hipSuccess) e = hipMemcpy(d + o_off, local.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host offsets"));
+    int more = 0;
+    rc = needle_find_all_csr_dev(p, &dv, (const uint64_t *)(d + o_off), (int32_t *)d_out, (int32_t *)(d_out + up16(m * 4)), &more, nullptr);
+    if (rc) return done(rc);
+    if (more) return done(fail(NEEDLE_ERR_DEVICE, "find_all_csr_host: count pass and fill pass disagree"));
+    e = hipMemcpy(start + offsets[0], d_out, m * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(end + offsets[0], d_out + up16(m * 4), m * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host download"));
+    return done(NEEDLE_OK);
+}
+int needle_find_all_csr_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *offsets, int32_t *start, int32_t *end,
+                             uint64_t capacity, uint64_t *total) {
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, false);
+    if (rc) return rc;
+    if ((rc = check_host_lengths(v))) return rc;
+    if (!offsets || !total || (capacity && (!start || !end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    offsets[0] = 0;
+    *total = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    static const uint64_t kHostChunkBytes = getenv("NEEDLE_HOST_CHUNK_BYTES") ? (uint64_t)atoll(getenv("NEEDLE_HOST_CHUNK_BYTES")) : (2ull << 30);
+    const uint64_t row_bytes = std::max<uint64_t>(16, (v->row_stride * v->char_width + 15) & ~(uint64_t)15) + 16;
+    const uint64_t per = std::max<uint64_t>(64, (kHostChunkBytes / row_bytes) & ~(uint64_t)63);
+    for (uint64_t r0 = 0; r0 < v->n_rows; r0 += per) {
+        needle_batch_view c = *v;
+        c.n_rows = std::min<uint64_t>(per, v->n_rows - r0);
+        c.rows = (const uint8_t *)v->rows + r0 * v->row_stride * v->char_width;
+        c.lengths = v->lengths ? v->lengths + r0 : nullptr;
+        rc = find_all_csr_host_one(p, &c, offsets + r0, start, end, capacity);
+        if (rc) return rc;
+    }
+    *total = offsets[v->n_rows];
+    return NEEDLE_OK;
+}
 int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
                          int32_t *end, int *more) {
     if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");

@@ -348,8 +348,30 @@ class Pattern:
         """Every non-overlapping match of every row in compact form, two passes over the batch: count
         (needle_count_matches_dev), exclusive prefix sum, fill (needle_find_all_csr_dev).
         -> (offsets int64[n_rows + 1], start int32[m], end int32[m])"""
-        import torch
         L = _lib.lib()
+        if isinstance(rows, np.ndarray):  # host buffers: needle_find_all_csr_host (first with a guessed capacity)
+            rows = np.ascontiguousarray(rows)
+            if rows.dtype == np.int16:
+                rows = rows.view(np.uint16)
+            assert rows.ndim == 2 and rows.dtype in (np.uint8, np.uint16)
+            n, stride = rows.shape
+            v = BatchView()
+            v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.ctypes.data, rows.dtype.itemsize, n, stride, stride
+            if lengths is not None:
+                lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+                v.lengths = lengths.ctypes.data
+            offsets = np.zeros(n + 1, dtype=np.uint64)
+            capacity = max(1024, 2 * n)
+            while True:
+                st = np.empty(capacity, dtype=np.int32)
+                en = np.empty(capacity, dtype=np.int32)
+                total = ctypes.c_uint64(0)
+                _check(L.needle_find_all_csr_host(self._h, ctypes.byref(v), offsets.ctypes.data, st.ctypes.data, en.ctypes.data, capacity,
+                                                  ctypes.byref(total)))
+                if total.value <= capacity:
+                    return offsets.astype(np.int64), st[:total.value], en[:total.value]
+                capacity = int(total.value)
+        import torch
         v = self._dev_view(rows, lengths)
         n = rows.shape[0]
         with torch.cuda.device(rows.device):

@@ -115,6 +115,12 @@ def test_every_match_across_tile_boundaries(regex, stride):
         if most > 1:
             c2, _, _, more2 = p.find_all_dense(t, most - 1, tl)
             assert more2 and (c2.cpu().numpy() == np.minimum(counts, most - 1)).all()
+        # the compact form on host buffers (needle_find_all_csr_host; 700 rows of up to ~30 matches: the guessed capacity of
+        # 1400 entries is too small for the dense strides, so the second call is exercised too)
+        ho, hs2, he2 = p.find_all_csr(rows, ln)
+        assert ho[-1] == sum(len(w) for w in want) == len(hs2)
+        for i in range(0, n, 3):
+            assert list(zip(hs2[ho[i]:ho[i + 1]].tolist(), he2[ho[i]:ho[i + 1]].tolist())) == want[i], i
         # compact form (count, prefix sum, fill) and the CSR wrapper built on it
         assert (p.count_matches_batch(t, tl).cpu().numpy() == [len(w) for w in want]).all()
         offsets, s1, e1 = p.find_all_batch(t, tl)
