@@ -97,11 +97,19 @@ class RankComm:
         rank, world = dist.get_rank(), dist.get_world_size()
         on_gpu = dist.get_backend() == "nccl"
         idt = torch.zeros(128, dtype=torch.uint8, device=device if on_gpu else "cpu")
+        err = None
         if rank == 0:
-            raw = (ctypes.c_ubyte * 128)()
-            _check(_lib.lib().needle_multi_unique_id(raw))
-            idt.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            try:
+                raw = (ctypes.c_ubyte * 128)()
+                _check(_lib.lib().needle_multi_unique_id(raw))
+                idt.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            except Exception as e:  # noqa: BLE001 -- the broadcast below must still happen: the other ranks are waiting in it
+                err = e
         dist.broadcast(idt, src=0)
+        if err is not None:
+            raise err
+        if not bool(idt.any()):
+            raise RuntimeError("rank 0 could not create an RCCL unique id")
         return cls(bytes(idt.cpu().numpy().tobytes()), rank, world, torch.device(device).index)
 
     def all_gather_u64(self, send, recv, stream):
