@@ -8,6 +8,9 @@ resident batch, plus the oracle itself on a seeded sample of rows spread over th
   C3  keywords    find.matched ==   containedIn bitmap; [start, end) spells one of the 1000 keywords; nothing matches
                   when the row is cut one char before `end` (lengths = end - 1): leftmost match really ends at `end`
   C5  BMP runs    find.matched ==   containedIn; [start, end) is a maximal run of in-range chars of length >= 3
+  C3  find-all    (every match of every row, 46.6 M of them) slot 0 == find(); every match spells a keyword; matches are
+                  ordered and disjoint; count pass == filed counts; compact form == dense form; rounds of find_next agree
+                  on the second match; the oracle's repeated find() on sampled rows
   all             partition invariance: the bitmap of the whole batch == the bitmaps of two unequal shards, joined
                   (what row sharding across GPUs relies on); a second launch gives identical bits"""
 import numpy as np
@@ -127,6 +130,73 @@ def test_c3_full_size_properties():
     assert bool(((cs == -1) | (cs >= fs) | ~matched).all())
     partition_invariant(p.find_batch, rows, fw)
     check_sample_against_oracle(p, rows, f_bits, fs.cpu().numpy(), fe.cpu().numpy(), c_bits)
+
+
+@pytest.mark.gpu
+def test_c3_full_size_find_all_properties():
+    """SURVEY.md s8f-1 at the full size: the one-pass find-all kernel over all 10^7 rows, tied to find() and to itself
+    through properties that need no CPU pass, plus the oracle on a sample."""
+    import torch
+    from needle_amd.pattern import unpack_bitmap
+    p, rows, words = make("c3")
+    n = rows.shape[0]
+    slots = 32
+    counts, st, en, more = p.find_all_dense(rows, slots)
+    assert not more
+    fw, fs, fe = p.find_batch(rows)
+    matched = torch.from_numpy(unpack_bitmap(fw, n)).cuda()
+    # the first match IS find()
+    assert bool(((counts > 0) == matched).all())
+    assert torch.equal(torch.where(matched, st[:, 0], torch.full_like(fs, -1)), fs)
+    assert torch.equal(torch.where(matched, en[:, 0], torch.full_like(fe, -1)), fe)
+    # slots: filled up to the count, untouched (-1) beyond; matches ordered, disjoint, 3..5 chars long
+    k = torch.arange(slots, device="cuda", dtype=torch.int32)[None, :]
+    used = k < counts[:, None]
+    assert bool(((st >= 0) == used).all()) and bool(((en >= 0) == used).all())
+    ln = en - st
+    assert bool((((ln >= 3) & (ln <= 5)) | ~used).all())
+    assert bool(((st[:, 1:] >= en[:, :-1]) | ~used[:, 1:]).all())
+    assert bool((en <= 256).all())
+    total = int(counts.sum().item())
+    assert total > 4 * n
+    # every match spells a keyword (base-32 code of its letters in the keyword code set), checked slot by slot
+    wcodes = []
+    for w in words:
+        v = 0
+        for ch in w:
+            v = v * 32 + (ord(ch) - 96)
+        wcodes.append(v)
+    wset = torch.tensor(sorted(wcodes), dtype=torch.int64, device="cuda")
+    for slot in range(int(counts.max().item())):
+        s_k, l_k, u_k = st[:, slot].long().clamp(min=0), ln[:, slot], used[:, slot]
+        code = torch.zeros(n, dtype=torch.int64, device="cuda")
+        for j in range(5):
+            ch = rows.gather(1, (s_k + j).clamp(max=255)[:, None])[:, 0].long() - 96
+            code = torch.where(l_k > j, code * 32 + ch, code)
+        assert bool((torch.isin(code, wset) | ~u_k).all()), slot
+    del code, ch
+    # the second match == find() searched from the first one's end (the round-per-match form's second round)
+    cursor = torch.where(matched, fe, torch.full_like(fe, -1))
+    _w2, s2, e2 = p.find_next_batch(rows, cursor)
+    has2 = counts > 1
+    assert torch.equal(torch.where(has2, st[:, 1], torch.full_like(s2, -1)), s2)
+    assert torch.equal(torch.where(has2, en[:, 1], torch.full_like(e2, -1)), e2)
+    # count pass and compact form
+    assert torch.equal(p.count_matches_batch(rows), counts)
+    offsets, cs, ce = p.find_all_csr(rows)
+    assert int(offsets[-1].item()) == total
+    assert torch.equal(cs, st[used]) and torch.equal(ce, en[used])
+    # run-to-run identity
+    c2, st2, en2, _ = p.find_all_dense(rows, slots)
+    assert torch.equal(c2, counts) and torch.equal(st2, st) and torch.equal(en2, en)
+    # the oracle's repeated find() on rows spread over the batch
+    o = oracle_of(p)
+    idx = sample_rows(n, k=3000)
+    host = rows[torch.from_numpy(idx).cuda()].cpu().numpy()
+    hc, hs, he = counts[idx].cpu().numpy(), st[idx].cpu().numpy(), en[idx].cpu().numpy()
+    for i in range(0, len(idx), 3):
+        want = o.find_all(host[i])
+        assert [(int(hs[i, j]), int(he[i, j])) for j in range(int(hc[i]))] == want, idx[i]
 
 
 @pytest.mark.gpu
