@@ -211,7 +211,9 @@ def measure(workload, args, ctx, headline):
     def scan(bitmap, start, end):
         op(rows, out=(bitmap, start, end) if is_find else bitmap)
 
-    sh = ShardedScan(scan, total_rows, world, rank, is_find, dev, n_buffers=args.buffers, comm=ctx.comm, overlap=args.overlap == "on")
+    # N > 1, find: start / end cross the links as one dword per row (rows are 256 chars: two 16-bit halves)
+    sh = ShardedScan(scan, total_rows, world, rank, is_find, dev, n_buffers=args.buffers, comm=ctx.comm, overlap=args.overlap == "on",
+                     pack16=use_dist and is_find)
     for _ in range(2):  # first launches: program upload, kernel attributes (never part of a captured graph)
         sh.scan_only()
     torch.cuda.synchronize()
@@ -296,7 +298,7 @@ def measure(workload, args, ctx, headline):
                        "" if world == 1 else (", row-sharded over %d GPUs (%d rows per GPU)" % (world, n_rows))),
                    "rows_total": total_rows, "rows_per_gpu": n_rows, "row_chars": 256, "char_bytes": cw,
                    "parallelism": "row-shard x%d" % world,
-                   "result": "bitmap" + ("+start/end int32" if is_find else ""),
+                   "result": "bitmap" + (("+start/end int32" + (" (on the links: one dword per row, two 16-bit halves)" if use_dist else "")) if is_find else ""),
                    "automaton": {"states": inf["n_states"][which], "classes": inf["stride"],
                                  "kernel_mode": mode_names.get(inf["kernel_mode"][which], str(inf["kernel_mode"][which]))},
                    "launch": "HIP graph replay" if graphs else "eager"},
@@ -337,7 +339,7 @@ def measure(workload, args, ctx, headline):
         out["scan_ms"] = blocking(lambda: sh.scan_only())
         out["gather_ms"] = blocking(lambda: sh.wait(sh.step())) - out["scan_ms"]
         out["step_ms"] = out["ms_per_step"]
-        out["gather"] = {"collective": ("ONE gather to rank 0 (RCCL send/recv fan-in) of start | end | bitmap: %d B per rank" % (sh.sets[0]["buf"].numel() * 4)) if is_find
+        out["gather"] = {"collective": ("ONE gather to rank 0 (RCCL send/recv fan-in) of start / end as 16-bit halves | bitmap: %d B per rank" % (sh.sets[0]["buf"].numel() * 4)) if is_find
                                        else ("ONE all-gather (RCCL) of the bitmap words: %d B per rank" % (sh.per_words * 8)),
                          "issued_by": "libneedle_hip.so (needle_multi_*)" if ctx.comm is not None else "torch.distributed",
                          "note": "gather_ms = blocking (scan + gathers) - blocking scan; inside the timed steps the gathers overlap the next scan"}

@@ -4,9 +4,11 @@ ROCm, "gloo" in the CPU tests).  Rows are independent units (a Matcher is per ha
 
   * the per-shard result BITMAP (156 KB per rank at 10M rows over 8 GPUs): one all-gather, every rank ends up with
     the whole bitmap;
-  * for find(), the per-row start / end (2 x int32 per row: 10 MB per rank at 10M rows over 8 GPUs): a FAN-IN to
-    rank 0 -- every peer sends over its own direct xGMI link to the root (7 links in parallel).  An all-gather would
-    push the same 70 MB through every link of a ring and serve no one: only the host side of rank 0 consumes them.
+  * for find(), the per-row start / end: a FAN-IN to rank 0 -- every peer sends over its own direct xGMI link to the
+    root (7 links in parallel).  An all-gather would push the same bytes through every link of a ring and serve no
+    one: only the host side of rank 0 consumes them.  Rows of up to 65 534 chars travel as ONE dword per row (two
+    16-bit halves, 0xFFFF = no match: 5 MB per rank at 10M rows over 8 GPUs instead of 10) and are unpacked on rank 0
+    when somebody asks for them.
 
 Both are issued asynchronously (RCCL's own stream, ordered after the scan kernel), so the next step's scan overlaps
 with them.  `ShardedScan` is the one implementation of a step: bench.py drives it with the HIP kernels, the gloo
@@ -138,7 +140,7 @@ class ShardedScan:
     ~0.1 ms; three separately issued collectives cost the host more than that).  `n_buffers` result sets rotate so that
     step k + 1 may scan while the gather of step k is still in flight."""
 
-    def __init__(self, scan, total_rows, world, rank, is_find, device, n_buffers=2, comm=None, overlap=None):
+    def __init__(self, scan, total_rows, world, rank, is_find, device, n_buffers=2, comm=None, overlap=None, pack16=False):
         """comm: a needle_amd.multi.RankComm -- the gather is then ONE call into the library's own RCCL communicator (GPU
         runs); without it the gather goes through torch.distributed (any backend: the gloo tests).
         overlap (with comm): issue the gather on a side stream so that the next scan runs beside it.  That costs two
@@ -147,6 +149,8 @@ class ShardedScan:
         against 101 us -- so the default is the scan's own stream."""
         self.scan, self.total_rows, self.world, self.rank, self.is_find = scan, total_rows, world, rank, is_find
         self.comm, self.side = comm, None
+        # pack16 (find, rows of at most 65 534 chars: the caller's promise): start / end cross the links as one dword per row
+        self.pack16 = bool(pack16) and is_find
         self.overlap = bool(overlap)
         if comm is not None and self.overlap:
             self.side = torch.cuda.Stream(device=device)
@@ -157,7 +161,19 @@ class ShardedScan:
         self.sets, self.k = [], 0
         for _ in range(n_buffers):
             s = {"pending": None}
-            if is_find:
+            if is_find and self.pack16:
+                # send buffer [start | end as 16-bit halves: per_rows int32 | bitmap: per_words int64 viewed as int32 pairs];
+                # the scan writes int32 start / end next to it, the pack kernel (or three torch ops on the CPU) fills it
+                buf = torch.full((per_rows + 2 * self.per_words,), -1, dtype=torch.int32, device=device)
+                buf[per_rows:] = 0
+                s["buf"] = buf
+                s["start"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
+                s["end"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
+                s["packed"] = buf[:per_rows]
+                s["bitmap"] = buf[per_rows:].view(torch.int64)
+                if (self.dist or comm is not None) and rank == 0:
+                    s["all"] = torch.empty((world, buf.numel()), dtype=torch.int32, device=device)
+            elif is_find:
                 # [start: per_rows int32 | end: per_rows int32 | bitmap: per_words int64 viewed as int32 pairs]
                 buf = torch.full((2 * per_rows + 2 * self.per_words,), -1, dtype=torch.int32, device=device)
                 buf[2 * per_rows:] = 0
@@ -192,6 +208,8 @@ class ShardedScan:
         if events is not None:
             events[1].record()
         self.k += 1
+        if self.pack16 and self.dist:
+            self._pack(s)
         if not self.dist:
             s["pending"] = _Pending(None, None, 0, None)
         elif self.comm is not None:
@@ -216,6 +234,29 @@ class ShardedScan:
             s["pending"] = gather_bitmap_async(s["bitmap"], self.total_rows, self.world, self.rank, out=s.get("bitmap_all"))
         return s
 
+    def _pack(self, s):
+        if s["packed"].is_cuda:
+            from . import _lib
+            from .pattern import _check
+            _check(_lib.lib().needle_pack_start_end16_dev(s["start"].data_ptr(), s["end"].data_ptr(), self.per_rows, s["packed"].data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream))
+        else:  # the gloo tests
+            torch.bitwise_or(s["start"] & 0xFFFF, s["end"] << 16, out=s["packed"])
+
+    @staticmethod
+    def _unpack(packed):
+        if packed.is_cuda:
+            from . import _lib
+            from .pattern import _check
+            packed = packed.contiguous()
+            start, end = torch.empty_like(packed), torch.empty_like(packed)
+            _check(_lib.lib().needle_unpack_start_end16_dev(packed.data_ptr(), packed.numel(), start.data_ptr(), end.data_ptr(),
+                                                            torch.cuda.current_stream().cuda_stream))
+            return start, end
+        lo, hi = packed & 0xFFFF, (packed >> 16) & 0xFFFF
+        minus1 = torch.full_like(lo, -1)
+        return torch.where(lo == 0xFFFF, minus1, lo), torch.where(hi == 0xFFFF, minus1, hi)
+
     def wait(self, s):
         """-> (full bitmap words, start, end).  matches / containedIn: the bitmap on every rank.  find: all three on
         rank 0 (views into the gathered buffer, rows in shard order), None elsewhere."""
@@ -231,6 +272,10 @@ class ShardedScan:
         if self.rank != 0:
             return None, None, None
         g, pr = s["all"], self.per_rows
+        if self.pack16:
+            start, end = self._unpack(g[:, :pr].reshape(-1)[:self.total_rows])
+            bitmap = g[:, pr:].contiguous().view(torch.int64).reshape(-1)[:n_words]
+            return bitmap, start, end
         start = g[:, :pr].reshape(-1)[:self.total_rows]
         end = g[:, pr:2 * pr].reshape(-1)[:self.total_rows]
         bitmap = g[:, 2 * pr:].contiguous().view(torch.int64).reshape(-1)[:n_words]

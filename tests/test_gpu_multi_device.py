@@ -130,6 +130,13 @@ def test_sharded_scan_step_through_the_library_communicator():
         bm, st, en = sh.wait(st_)
         torch.cuda.synchronize()
         assert (unpack_bitmap(bm, total) == m).all() and (st.cpu().numpy() == s).all() and (en.cpu().numpy() == e).all()
+    # start / end packed to one dword per row before the gather (the pack / unpack kernels of the library)
+    shp = ShardedScan(lambda bm, st, en: p.find_batch(rows, out=(bm, st, en)), total, 1, 0, True, torch.device("cuda", 0), comm=comm, pack16=True)
+    sp = shp.step()
+    assert sp["buf"].numel() == shp.per_rows + 2 * shp.per_words
+    bm, st, en = shp.wait(sp)
+    torch.cuda.synchronize()
+    assert (unpack_bitmap(bm, total) == m).all() and (st.cpu().numpy() == s).all() and (en.cpu().numpy() == e).all()
     shc = ShardedScan(lambda bm, st, en: p.contained_in_batch(rows, out=bm), total, 1, 0, False, torch.device("cuda", 0), comm=comm)
     bm, _, _ = shc.wait(shc.step())
     torch.cuda.synchronize()

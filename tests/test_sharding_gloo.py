@@ -59,6 +59,15 @@ def _worker(rank, world, port, total_rows, q):
             assert st.shape[0] == total_rows and (st == st2).all() and (en == en2).all()
         else:
             assert full is None and st is None and en is None
+        # the same step with start / end travelling as one dword per row (two 16-bit halves, 0xFFFF = -1)
+        shp = ShardedScan(scan, total_rows, world, rank, True, "cpu", n_buffers=2, pack16=True)
+        sp = shp.step()
+        assert sp["buf"].numel() == shp.per_rows + 2 * shp.per_words  # half the start / end bytes on the wire
+        fullp, stp, enp = shp.wait(sp)
+        if rank == 0:
+            assert (fullp == full).all() and (stp == st).all() and (enp == en).all()
+        else:
+            assert fullp is None and stp is None and enp is None
         # the contained_in step (bitmap only) and the plain helpers
         bits = o.batch_contained_in(rows) if n else np.zeros(0, dtype=bool)
 
