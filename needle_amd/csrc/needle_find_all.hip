@@ -59,6 +59,94 @@ __device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t
     return h >> (32 - CPP);
 }
 
+// indexBackwards(en - 1, bound), DFAClassBuilder.java:536-583, for the lanes of `act`.  The row bytes [win_b0, win_b0 +
+// win_bytes) are in LDS at win_addr (byte b at win_addr + ((b - win_b0) ^ swz16): the find-all tile is bank-swizzled, a
+// plain window is not); anything else is read from memory.  The backward automaton rides in the forward program's LDS part
+// (packed functions, popcount-compressed rows, a small dense table) or is walked out of HBM / L2.
+template <int CW>
+__device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, int32_t en, int32_t bound, uint32_t win_addr, uint32_t win_b0,
+                                                 uint32_t win_bytes, uint32_t swz16, const uint8_t *rowp) {
+    const uint16_t *gbt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
+    const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
+    int32_t idx_b = en - 1;
+    uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
+    int32_t lastb = a.bhdr.root_accepting ? bound : INT_MAX; // :543-547
+    bool active = act;
+    while (__ballot(active) != 0ull) {
+        uint32_t cs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int32_t p = idx_b - k;
+            const uint32_t rel = (uint32_t)(p * CW) - win_b0;      // byte offset inside the window, if it is there
+            const bool in_tile = rel < win_bytes;
+            const uint32_t ad = win_addr + ((in_tile ? rel : 0u) ^ swz16);
+            const uint32_t held = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
+            uint32_t c = 0;
+            if (active && p >= bound) {
+                c = held;
+                if (!in_tile) { // text outside the window (rare): waited for inside the branch, as in walk_tile
+                    c = (CW == 1) ? (uint32_t)rowp[p] : (uint32_t)((const uint16_t *)rowp)[p];
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(c));
+                }
+            }
+            cs[k] = c;
+        }
+        if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton
+            uint32_t fb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (CW == 1) {
+                    fb[k] = lds_u32(a.hdr.off_bpack + (cs[k] << 2));
+                } else {
+                    const u32x2 pg = lds_u32x2(a.hdr.off_bpack + ((cs[k] >> 8) << 3));
+                    fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool in_range = active && idx_b >= bound; // loop bound `index >= FROM`, :549
+                const uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
+                const bool alive = in_range && nb != 0u;
+                lastb = (alive && nb >= bacc) ? idx_b : lastb;
+                bs = alive ? nb : bs;
+                idx_b = alive ? idx_b - 1 : idx_b;
+                active = alive;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (active) {
+                    if (idx_b < bound) {
+                        active = false;
+                    } else {
+                        uint32_t col; // the backward automaton's char -> column maps, at absolute LDS addresses
+                        if (CW == 1) col = lds_u8(a.hdr.off_bcmap + cs[k]);
+                        else col = lds_u8(a.hdr.off_bpages + ((lds_u8(a.hdr.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
+                        if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
+                            const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
+                            const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col) - 1u));
+                            const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
+                            bs = ((bm >> col) & 1u) ? tgt : 0u;
+                        } else if (a.hdr.off_btable) { // wave-uniform: small dense table in LDS
+                            bs = lds_u16(a.hdr.off_btable + (bs * bcols + col) * 2u);
+                        } else { // dense table in HBM / L2 (waited for here: no vmcnt wait on the other paths)
+                            bs = gbt[bs * bcols + col];
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bs));
+                        }
+                        if (bs == 0) {
+                            active = false;
+                        } else {
+                            if (bs >= bacc) lastb = idx_b;
+                            --idx_b;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return lastb;
+}
+
 template <int CW, int MODE, int CHB>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const FindAllArgs fa) {
     using G = Geom<CHB>;
@@ -146,88 +234,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
     uint64_t out0 = 0;      // index of this row's first result slot (dense: row * slots; compact: offsets[row])
     uint32_t cap = 0;       // matches this row may file
 
-    // indexBackwards(en - 1, bound), :536-583, for the lanes of `act`; the tile in LDS holds the row bytes
-    // [tile_b0, tile_b0 + CHB), anything else is read from memory.
     auto backward = [&](bool act, int32_t en, int32_t bound, uint32_t tile_b0) __attribute__((always_inline)) -> int32_t {
-        const uint16_t *gbt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
-        const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
-        int32_t idx_b = en - 1;
-        uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
-        int32_t lastb = a.bhdr.root_accepting ? bound : INT_MAX; // :543-547
-        bool active = act;
-        while (__ballot(active) != 0ull) {
-            uint32_t cs[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int32_t p = idx_b - k;
-                const uint32_t rel = (uint32_t)(p * CW) - tile_b0;     // byte offset inside the tile, if it is there
-                const bool in_tile = rel < (uint32_t)CHB;
-                const uint32_t ad = tile.row_addr + ((in_tile ? rel : 0u) ^ swz16);
-                const uint32_t held = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
-                uint32_t c = 0;
-                if (active && p >= bound) {
-                    c = held;
-                    if (!in_tile) { // text of an earlier tile (rare): waited for inside the branch, as in walk_tile
-                        c = (CW == 1) ? (uint32_t)rowp[p] : (uint32_t)((const uint16_t *)rowp)[p];
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c));
-                    }
-                }
-                cs[k] = c;
-            }
-            if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton
-                uint32_t fb[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (CW == 1) {
-                        fb[k] = lds_u32(a.hdr.off_bpack + (cs[k] << 2));
-                    } else {
-                        const u32x2 pg = lds_u32x2(a.hdr.off_bpack + ((cs[k] >> 8) << 3));
-                        fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool in_range = active && idx_b >= bound; // loop bound `index >= FROM`, :549
-                    const uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
-                    const bool alive = in_range && nb != 0u;
-                    lastb = (alive && nb >= bacc) ? idx_b : lastb;
-                    bs = alive ? nb : bs;
-                    idx_b = alive ? idx_b - 1 : idx_b;
-                    active = alive;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (active) {
-                        if (idx_b < bound) {
-                            active = false;
-                        } else {
-                            uint32_t col; // the backward automaton's char -> column maps, at absolute LDS addresses
-                            if (CW == 1) col = lds_u8(a.hdr.off_bcmap + cs[k]);
-                            else col = lds_u8(a.hdr.off_bpages + ((lds_u8(a.hdr.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
-                            if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
-                                const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
-                                const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col) - 1u));
-                                const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
-                                bs = ((bm >> col) & 1u) ? tgt : 0u;
-                            } else if (a.hdr.off_btable) { // wave-uniform: small dense table in LDS
-                                bs = lds_u16(a.hdr.off_btable + (bs * bcols + col) * 2u);
-                            } else { // dense table in HBM / L2 (waited for here: no vmcnt wait on the other paths)
-                                bs = gbt[bs * bcols + col];
-                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(bs));
-                            }
-                            if (bs == 0) {
-                                active = false;
-                            } else {
-                                if (bs >= bacc) lastb = idx_b;
-                                --idx_b;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        return lastb;
+        return backward_walk<CW>(a, act, en, bound, tile.row_addr, tile_b0, (uint32_t)CHB, swz16, rowp);
     };
 
     // starts of every lane's pending matches (the deferred form): the pending entries are the matches
@@ -320,8 +328,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 const bool file = hit && count < cap;
                 if (hit && !file) *fa.more = 1;
                 done = done || (hit && !file);
-                const bool push = file && !fa.count_only; // (counting: no starts wanted, nothing pends)
-                if (push) fa.ends[out0 + count] = en;
+                const bool keep = file && !fa.count_only;  // (counting: nothing is filed)
+                const bool push = keep && fa.defer != 3u;  // (3: the starts kernel finds the starts afterwards, nothing pends)
+                if (keep) fa.ends[out0 + count] = en;
                 pend_bound = (push && n_pend == 0u) ? cursor : pend_bound;
                 // push: a lane that files nothing shifts by nothing (v_perm selectors chosen per lane)
                 const uint32_t sel_hi = push ? 0x05040302u : 0x07060504u; // {hi.lo16, lo.hi16} | hi unchanged: v_perm_b32(hi, lo, sel), bytes 4-7 = hi
@@ -428,6 +437,105 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
         }
         end_group();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The starts of all filed matches, as a pass of its own (FindAllArgs.defer == 3): find_all_kernel has filed every match's
+// end; match k of a row was searched from the end of match k - 1, so every start is an independent indexBackwards.  The
+// matches of a wave's 64 rows are numbered through (prefix sum of the counts) and handed out 64 at a time, one per lane: no
+// lane waits for another row's longer list of matches, which is what the in-kernel form pays for (a round per pending
+// match of the busiest lane, per tile).  The text: the 32 bytes that end with the match's last
+// char come from memory into the lane's LDS window (two 16-byte loads: the rows were read a moment ago), longer matches
+// read on byte by byte.
+// ------------------------------------------------------------------------------------------------
+template <int CW>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_starts_kernel(const FindAllArgs fa) {
+    const ScanArgs &a = fa.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = blockDim.x >> 6;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u)
+        *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
+    __syncthreads();
+    const uint32_t win_addr = ((a.hdr.lds_bytes + 15u) & ~15u) + ((uint32_t)wave * 64u + (uint32_t)lane) * 32u;
+    const uint64_t n_groups = (a.n_rows + 63) >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * n_waves + wave; g < n_groups; g += (uint64_t)gridDim.x * n_waves) {
+        // the matches of the group's 64 rows, numbered row by row: lane l knows row l's count and the count before it
+        const uint64_t my_row = (g << 6) + lane;
+        uint32_t cnt = 0;
+        if (my_row < a.n_rows) cnt = fa.offsets ? (uint32_t)(fa.offsets[my_row + 1] - fa.offsets[my_row]) : fa.counts[my_row];
+        uint32_t incl = cnt; // inclusive prefix sum over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+            incl += lane >= o ? t : 0u;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t excl = incl - cnt;
+        for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
+            // match j of the group -> its row: the first lane whose inclusive count exceeds j (binary search over the lanes)
+            const uint32_t j = j0 + (uint32_t)lane;
+            const bool act = j < total;
+            uint32_t lo = 0, hi = 63;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t pm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mid << 2), (int)incl);
+                const bool right = pm <= j;
+                lo = right ? mid + 1u : lo;
+                hi = right ? hi : mid;
+            }
+            const uint32_t owner = act ? lo : (uint32_t)lane;
+            const uint32_t k = j - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)excl);
+            const uint64_t row = (g << 6) + owner;
+            const uint64_t out0 = fa.offsets ? (act ? fa.offsets[row] : 0) : row * fa.slots;
+            const uint8_t *rowp = a.rows + (act ? row : 0) * a.stride_bytes;
+            int32_t en = 1, bound = 0;
+            if (act) {
+                en = fa.ends[out0 + k];
+                if (k) bound = fa.ends[out0 + k - 1]; // the match was searched from the end of the one before it
+            }
+            // window: the 16-byte piece holding char en - 1 and the one before it
+            const uint32_t pa = ((uint32_t)(en - 1) * CW) >> 4;
+            const uint32_t pb = pa ? pa - 1u : 0u;
+            u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+            if (act) {
+                va = *(const u32x4 *)(rowp + (uint64_t)pa * 16u);
+                vb = *(const u32x4 *)(rowp + (uint64_t)pb * 16u);
+            }
+            *(lds_u32x4 *)(uintptr_t)(win_addr) = vb;
+            *(lds_u32x4 *)(uintptr_t)(win_addr + 16u) = va;
+            // (a match ending in the row's first piece: the window is that piece alone, in the upper half)
+            const uint32_t win_b0 = pa ? pb * 16u : 0u;
+            const uint32_t w_addr = pa ? win_addr : win_addr + 16u;
+            const int32_t st = backward_walk<CW>(a, act, en, bound, w_addr, win_b0, pa ? 32u : 16u, 0u, rowp);
+            if (act) fa.starts[out0 + k] = st;
+        }
+    }
+}
+
+hipError_t launch_find_all_starts(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream) {
+    if (fa.s.n_rows == 0) return hipSuccess;
+    const size_t p = (fa.s.hdr.lds_bytes + 15u) & ~15u, cap = 160u * 1024u;
+    int waves = 16;
+    while (waves > 1 && p + (size_t)waves * 64 * 32 > cap) waves >>= 1;
+    if (p + (size_t)waves * 64 * 32 > cap) return hipErrorInvalidValue;
+    const uint64_t n_groups = (fa.s.n_rows + 63) >> 6;
+    uint64_t blocks = (n_groups + waves - 1) / waves;
+    if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
+    const size_t lds = p + (size_t)waves * 64 * 32;
+    static thread_local uint64_t configured1 = 0, configured2 = 0;
+    if (char_width == 1) {
+        auto k = find_all_starts_kernel<1>;
+        if (hipError_t e = allow_full_lds((const void *)k, configured1); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, fa);
+    } else {
+        auto k = find_all_starts_kernel<2>;
+        if (hipError_t e = allow_full_lds((const void *)k, configured2); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, fa);
+    }
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
