@@ -5,17 +5,18 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_fa; mkdir -p $O
 for w in c3 c2 c5 c3s; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$w -o t -- python scripts/find_all_probe.py $w 10000000 32 > $O/$w.json 2> $O/$w.err
+  FIND_ALL_PROBE_DENSE_ONLY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$w -o t -- python scripts/find_all_probe.py $w 10000000 32 > $O/$w.prof.json 2> $O/$w.err
+  python scripts/find_all_probe.py $w 10000000 32 2>/dev/null | tail -1 > $O/$w.json
   NEEDLE_FIND_ALL_ROUNDS=1 python scripts/find_all_probe.py $w 10000000 32 2>/dev/null | tail -1 > $O/${w}_rounds.json
 done
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*_agent_info.csv" -delete
 scripts/pmc_find_all.sh c3 r2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY" > $O/pmc_c3.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python scripts/find_all_probe.py c3 10000000 32 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python scripts/find_all_probe.py c3 10000000 32 > /dev/null 2>&1
+FIND_ALL_PROBE_DENSE_ONLY=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python scripts/find_all_probe.py c3 10000000 32 > /dev/null 2>&1
+FIND_ALL_PROBE_DENSE_ONLY=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python scripts/find_all_probe.py c3 10000000 32 > /dev/null 2>&1
 for d in fetch write; do
 python - "$O/$d/p_counter_collection.csv" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "find_all_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "find_all" in r["Kernel_Name"]]
 w = csv.DictWriter(open(sys.argv[1], "w", newline=""), fieldnames=list(rows[0].keys()))
 w.writeheader(); w.writerows(rows)
 PY
