@@ -131,8 +131,11 @@ c = p.contained_in_batch(rows, lens)
 m = p.matches_batch(rows)
 fw, fs, fe = p.find_batch(rows, lens)
 cnt, als, ale, more = p.find_all_dense(rows, 3, lens)  # needle_find_all_host, chunked the same way
+co, cs, ce = p.find_all_csr(rows, lens)                 # needle_find_all_csr_host: offsets run on across the chunks
+assert co[-1] == len(cs) == len(ce) and (np.diff(co)[:100] >= cnt[:100]).all()
 np.save(sys.argv[1], np.concatenate([c.view(np.int64), m.view(np.int64), fw.view(np.int64), fs.astype(np.int64), fe.astype(np.int64),
-                                     cnt.astype(np.int64), als.astype(np.int64).ravel(), ale.astype(np.int64).ravel(), np.array([int(more)])]))
+                                     cnt.astype(np.int64), als.astype(np.int64).ravel(), ale.astype(np.int64).ravel(), np.array([int(more)]),
+                                     co.astype(np.int64), cs.astype(np.int64), ce.astype(np.int64)]))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
