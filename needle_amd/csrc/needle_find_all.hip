@@ -515,16 +515,34 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_starts_kernel(co
     }
 }
 
-hipError_t launch_find_all_starts(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream) {
-    if (fa.s.n_rows == 0) return hipSuccess;
-    const size_t p = (fa.s.hdr.lds_bytes + 15u) & ~15u, cap = 160u * 1024u;
+hipError_t launch_find_all_starts(int char_width, const FindAllArgs &fa_in, int n_cus, hipStream_t stream) {
+    if (fa_in.s.n_rows == 0) return hipSuccess;
+    FindAllArgs fa = fa_in;
+    // The kernel only needs the BACKWARD automaton's pieces of the forward program's LDS part (they sit behind the forward
+    // maps and table, needle_lower.cpp): stage those alone, offsets rebased, and two workgroups of 16 waves fit a CU (the
+    // kernel is bound by the latency of its dependent loads; it takes 45 VGPRs).  Not with a packed UTF-16 backward
+    // automaton, whose page table holds absolute LDS addresses.
+    ProgHeader &h = fa.s.hdr;
+    if (!h.off_bpack) {
+        uint32_t *offs[] = {&h.off_bcmap, &h.off_bptab, &h.off_bpages, &h.off_btable, &h.off_bsp_bm, &h.off_bsp_base, &h.off_bsp_edges};
+        uint32_t b0 = h.lds_bytes;
+        for (uint32_t *o : offs)
+            if (*o && *o < b0) b0 = *o;
+        b0 &= ~15u;
+        for (uint32_t *o : offs)
+            if (*o) *o -= b0;
+        fa.s.prog += b0;
+        h.lds_bytes -= b0;
+    }
+    const size_t p = (h.lds_bytes + 15u) & ~15u, cap = 160u * 1024u;
     int waves = 16;
     while (waves > 1 && p + (size_t)waves * 64 * 32 > cap) waves >>= 1;
     if (p + (size_t)waves * 64 * 32 > cap) return hipErrorInvalidValue;
+    const size_t lds = p + (size_t)waves * 64 * 32;
+    const int per_cu = (waves == 16 && 2 * lds <= cap) ? 2 : 1;
     const uint64_t n_groups = (fa.s.n_rows + 63) >> 6;
     uint64_t blocks = (n_groups + waves - 1) / waves;
-    if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
-    const size_t lds = p + (size_t)waves * 64 * 32;
+    if (blocks > (uint64_t)n_cus * per_cu) blocks = (uint64_t)n_cus * per_cu;
     static thread_local uint64_t configured1 = 0, configured2 = 0;
     if (char_width == 1) {
         auto k = find_all_starts_kernel<1>;
