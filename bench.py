@@ -394,7 +394,7 @@ def measure(workload, args, ctx, headline):
         fa_bytes = n_rows * (256 * cw + 4) + 8 * n_matches
         out["find_all"] = {"ms_per_step": dt * 1e3, "matches": n_matches, "matches_per_s": n_matches / dt, "max_per_row": int(fc.max().item()),
                            "slots": slots, "more": bool(more), "GB/s": fa_bytes / dt / 1e9, "algorithmic_bytes": fa_bytes,
-                           "kernel": "needle::find_all_kernel + needle::find_all_starts_kernel",
+                           "kernel": "needle::find_all_kernel",
                            "note": "every non-overlapping match per row (repeated Matcher.find()), one pass; bytes = rows + 4 B count per row + 8 B per match"}
         del fc, fs, fe
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -20,7 +20,6 @@ namespace needle {
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
 bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows);
 hipError_t launch_find_all(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream); // needle_find_all.hip
-hipError_t launch_find_all_starts(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream);
 hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, const int32_t *s, const int32_t *e, int32_t *cursor,
                                    uint32_t *counts, int32_t *starts, int32_t *ends, int32_t *any_hit, int n_cus, hipStream_t stream);
 hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipStream_t stream);
@@ -993,17 +992,9 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     fa.offsets = d_offsets;
     fa.count_only = count_only ? 1u : 0u;
     static const bool no_defer = getenv("NEEDLE_FIND_ALL_DEFER") && atoi(getenv("NEEDLE_FIND_ALL_DEFER")) == 0; // A/B, tests
-    fa.defer = (a.fixed_len < 0 && !a.hdr.root_accepting && v->row_stride <= 65535 && !no_defer) ? 1u : 0u;
+    fa.defer = (a.fixed_len < 0 && !a.hdr.root_accepting && !no_defer) ? 1u : 0u;
     static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr; // measurement aid: start = the search cursor
     if (fa.defer && dbg_no_backward) fa.defer = 2;
-    // starts as a pass of their own (one lane per match instead of rounds of the busiest lane) when the backward automaton
-    // is walked through tables -- measured on 10M x 256 rows: dictionary 3.28 -> 2.98 ms, sparse dictionary 2.40 -> 2.15; a
-    // PACKED backward automaton is cheap enough in place (C2 rows 1.38 -> 1.54 ms with the extra pass).
-    // NEEDLE_FIND_ALL_SPLIT=0 / 1 forces either form (tests, A/B).
-    static const int split = getenv("NEEDLE_FIND_ALL_SPLIT") ? atoi(getenv("NEEDLE_FIND_ALL_SPLIT")) : -1;
-    const bool want_split = split < 0 ? a.hdr.off_bpack == 0 : split != 0;
-    const bool split_starts = fa.defer == 1u && want_split && !count_only && (d_offsets || d_counts);
-    if (split_starts) fa.defer = 3;
     fa.counts = d_counts;
     fa.starts = d_start;
     fa.ends = d_end;
@@ -1016,7 +1007,6 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     if (hipMemsetAsync(d_more, 0, 4, stream) != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
     fa.more = d_more;
     hipError_t e = launch_find_all((int)v->char_width, fa, n_cus, stream);
-    if (e == hipSuccess && split_starts) e = launch_find_all_starts((int)v->char_width, fa, n_cus, stream);
     if (e != hipSuccess) return done(hip_fail(e, "find_all"));
     if (more) { // the only synchronisation: the caller asked whether its slots sufficed
         int32_t m = 0;

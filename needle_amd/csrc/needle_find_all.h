@@ -9,9 +9,9 @@ namespace needle {
 struct FindAllArgs {
     ScanArgs s;        // rows, lengths, forward program (+ backward maps), backward program, fixed_len; no outputs
     uint32_t slots;    // matches filed per row at most
-    uint32_t defer;    // starts by indexBackwards: 1 = found tile by tile for all pending matches of a wave at once (pattern
-                       // not nullable, row indices fit 16 bits); 3 = not at all here, find_all_starts_kernel follows; 0 =
-                       // every start at the moment its match is found; 2 = 1 without the walks (measurement aid)
+    uint32_t defer;    // starts by indexBackwards: 1 = at the end of each 64-row group, the group's matches handed out one per
+                       // lane (patterns that do not match the empty string); 0 = every start at the moment its match is
+                       // found; 2 = 1 without the walks (measurement aid)
     uint32_t *counts;  // [n_rows]
     int32_t *starts;   // [n_rows][slots]
     int32_t *ends;     // [n_rows][slots]

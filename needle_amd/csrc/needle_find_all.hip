@@ -21,11 +21,15 @@
 // Start indices (indexBackwards, :529-586).  A fixed-length pattern has start = end - L.  Otherwise the backward
 // automaton walks right to left from end - 1, bounded by the cursor the match was searched from.  Doing that at the
 // moment a lane resolves would run the backward walk's code for the one or two lanes resolving in any given
-// iteration; instead a lane pushes `end` on a small register stack (four VGPRs of 16-bit entries; the bound of a
-// match is the `end` of the one before it) and the wave walks backwards for ALL its lanes' pending matches at once,
-// at the end of the tile (whose text is still in LDS) or when a lane's stack is full.  Patterns that match the empty
-// string need every start at once -- an empty match ends its row (see needle_find_all_dev in needle_hip.h) -- and take
-// the immediate form, as do rows too long for 16-bit indices.
+// iteration.  The walk therefore only files the ENDS; at the end of a 64-row group every start is an independent
+// indexBackwards (a match's bound is the end of the one before it), so the group's matches are numbered through (a
+// prefix sum of the lanes' counts) and handed out 64 at a time, one per lane, whichever row they belong to: no lane
+// waits for another row's longer list of matches.  Their text comes back from memory / L2 (the 32 bytes ending with
+// the match's last char, into the lane's by then free tile row).  Patterns that match the empty string need every
+// start at once -- an empty match ends its row (see needle_find_all_dev in needle_hip.h) -- and take the immediate form.
+// (Tried before: a register stack of pending ends flushed tile by tile with the text still in LDS -- a round per pending
+// match of the busiest lane and tile: dictionary 3.3 ms against 2.6; the same rounds as a kernel of its own: 3.0 ms, its
+// re-reads of ends and text all miss the L2.)
 #include "needle_walk.h"
 #include "needle_find_all.h"
 
@@ -227,33 +231,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
     uint32_t len = 0, n_chunks = 1, st = 0, pi = 0, count = 0;
     int32_t last = -1, cursor = 0;
     const uint8_t *rowp = a.rows;
-    // pending matches whose start is still to be found: their ends, newest in the low half of pend[0]
-    uint32_t pend[4] = {0, 0, 0, 0};
-    uint32_t n_pend = 0;
-    int32_t pend_bound = 0; // the cursor the OLDEST pending match was searched from
     uint64_t out0 = 0;      // index of this row's first result slot (dense: row * slots; compact: offsets[row])
     uint32_t cap = 0;       // matches this row may file
 
     auto backward = [&](bool act, int32_t en, int32_t bound, uint32_t tile_b0) __attribute__((always_inline)) -> int32_t {
         return backward_walk<CW>(a, act, en, bound, tile.row_addr, tile_b0, (uint32_t)CHB, swz16, rowp);
-    };
-
-    // starts of every lane's pending matches (the deferred form): the pending entries are the matches
-    // count - n_pend .. count - 1 of the row, newest on top; the bound of each is the end of the one before it
-    auto flush_pending = [&](uint32_t tile_b0) __attribute__((always_inline)) {
-        const uint32_t first = count - n_pend; // matches of this row whose start is filed already
-        while (__ballot(n_pend != 0u) != 0ull) {
-            const bool act = n_pend != 0u;
-            const int32_t en = (int32_t)(pend[0] & 0xFFFFu);
-            pend[0] = __builtin_amdgcn_alignbit(pend[1], pend[0], 16); // pop
-            pend[1] = __builtin_amdgcn_alignbit(pend[2], pend[1], 16);
-            pend[2] = __builtin_amdgcn_alignbit(pend[3], pend[2], 16);
-            pend[3] >>= 16;
-            if (act) --n_pend;
-            const int32_t bound = n_pend ? (int32_t)(pend[0] & 0xFFFFu) : pend_bound;
-            const int32_t s = fa.defer == 2u ? bound : backward(act, en, bound, tile_b0); // (2: measurement aid)
-            if (act) fa.starts[out0 + first + n_pend] = s;
-        }
     };
 
     auto begin_group = [&](uint64_t grp) __attribute__((always_inline)) {
@@ -272,8 +254,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
         last = a.hdr.root_accepting ? 0 : -1; // :356 literal 0 (cursor 0: the same whether 0 < length or not)
         pi = 0;
         count = 0;
-        n_pend = 0;
-        pend_bound = 0;
         out0 = my_row * fa.slots;
         cap = fa.count_only ? 0xFFFFFFFFu : fa.slots;
         if (fa.offsets) {
@@ -328,23 +308,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 const bool file = hit && count < cap;
                 if (hit && !file) *fa.more = 1;
                 done = done || (hit && !file);
-                const bool keep = file && !fa.count_only;  // (counting: nothing is filed)
-                const bool push = keep && fa.defer != 3u;  // (3: the starts kernel finds the starts afterwards, nothing pends)
-                if (keep) fa.ends[out0 + count] = en;
-                pend_bound = (push && n_pend == 0u) ? cursor : pend_bound;
-                // push: a lane that files nothing shifts by nothing (v_perm selectors chosen per lane)
-                const uint32_t sel_hi = push ? 0x05040302u : 0x07060504u; // {hi.lo16, lo.hi16} | hi unchanged: v_perm_b32(hi, lo, sel), bytes 4-7 = hi
-                pend[3] = __builtin_amdgcn_perm(pend[3], pend[2], sel_hi);
-                pend[2] = __builtin_amdgcn_perm(pend[2], pend[1], sel_hi);
-                pend[1] = __builtin_amdgcn_perm(pend[1], pend[0], sel_hi);
-                pend[0] = __builtin_amdgcn_perm(pend[0], (uint32_t)en, push ? 0x05040100u : 0x07060504u);
+                if (file && !fa.count_only) fa.ends[out0 + count] = en; // (counting: nothing is filed)
                 count += file ? 1u : 0u;
-                n_pend += push ? 1u : 0u;
                 cursor = file ? en : cursor;
                 st = file ? start_state : st;
                 last = file ? -1 : last;
                 pi = file ? (((uint32_t)en * CW) >> 4) : pi;
-                if (__ballot(n_pend == 8u) != 0ull) flush_pending(tile_b0);
             } else {
                 int32_t s = en - a.fixed_len;
                 if (a.fixed_len < 0) s = backward(hit, en, cursor, tile_b0);
@@ -374,10 +343,64 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 }
             }
         }
-        if (fa.defer) flush_pending(tile_b0);
     };
-    auto end_group = [&]() __attribute__((always_inline)) {
+    // defer != 0: the starts of the group's matches, found at the end of the group (the walk has filed every match's
+    // end; match k of a row was searched from the end of match k - 1, so every start is an independent indexBackwards).  The
+    // matches of the 64 rows are numbered through (prefix sum of the counts) and handed out 64 at a time, one per lane: no
+    // lane waits for another row's longer list, which is what the tile-by-tile form pays for.  The text comes back from
+    // memory / L2 into the lane's (by now free) tile row; the ends are read back with agent-scope loads (this wave wrote them
+    // a moment ago: the plain stores are in L2 once vmcnt says so, a plain load might still hit a stale L1 line).
+    auto starts_phase = [&](uint64_t grp) __attribute__((always_inline)) {
+        uint32_t incl = count;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+            incl += lane >= o ? t : 0u;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total == 0u) return;
+        const uint32_t excl = incl - count;
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this wave's stores of the ends have reached L2
+        for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const bool act = j < total;
+            uint32_t lo = 0, hi = 63;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) { // the first lane whose inclusive count exceeds j
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t pm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mid << 2), (int)incl);
+                const bool right = pm <= j;
+                lo = right ? mid + 1u : lo;
+                hi = right ? hi : mid;
+            }
+            const uint32_t owner = act ? lo : (uint32_t)lane;
+            const uint32_t k = j - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)excl);
+            const uint64_t o_out0 = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)(uint32_t)out0) |
+                                    ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)(uint32_t)(out0 >> 32)) << 32);
+            const uint8_t *o_rowp = a.rows + ((grp << 6) + owner) * a.stride_bytes;
+            int32_t en = 1, bound = 0;
+            if (act) {
+                en = __hip_atomic_load(&fa.ends[o_out0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k) bound = __hip_atomic_load(&fa.ends[o_out0 + k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const uint32_t pa = ((uint32_t)(en - 1) * CW) >> 4; // window: the piece holding char en - 1 and the one before it
+            const uint32_t pb = pa ? pa - 1u : 0u;
+            u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+            if (act) {
+                va = *(const u32x4 *)(o_rowp + (uint64_t)pa * 16u);
+                vb = *(const u32x4 *)(o_rowp + (uint64_t)pb * 16u);
+            }
+            *(lds_u32x4 *)(uintptr_t)(tile.row_addr) = vb;
+            *(lds_u32x4 *)(uintptr_t)(tile.row_addr + 16u) = va;
+            const uint32_t win_b0 = pa ? pb * 16u : 0u;
+            const uint32_t w_addr = pa ? tile.row_addr : tile.row_addr + 16u;
+            const int32_t st_k = fa.defer == 2u ? bound : backward_walk<CW>(a, act, en, bound, w_addr, win_b0, pa ? 32u : 16u, 0u, o_rowp); // (2: measurement aid)
+            if (act) fa.starts[o_out0 + k] = st_k;
+        }
+    };
+    auto end_group = [&](uint64_t grp) __attribute__((always_inline)) {
         if (row_ok && fa.counts) fa.counts[my_row] = count;
+        if (fa.defer && !fa.count_only) starts_phase(grp);
     };
     auto stage = [&](auto tc) __attribute__((always_inline)) {
         constexpr int T = decltype(tc)::value;
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                     if (ck >= n_chunks || __ballot(!done) == 0ull) break;
                 }
             }
-            end_group();
+            end_group(g);
             g += wave_cnt;
             if (g >= last_group) break;
             if (!have_next) fetch(g, 0);
@@ -435,125 +458,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             walk_tile(ck);
             if (__ballot(!done) == 0ull) break;
         }
-        end_group();
+        end_group(g);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The starts of all filed matches, as a pass of its own (FindAllArgs.defer == 3): find_all_kernel has filed every match's
-// end; match k of a row was searched from the end of match k - 1, so every start is an independent indexBackwards.  The
-// matches of a wave's 64 rows are numbered through (prefix sum of the counts) and handed out 64 at a time, one per lane: no
-// lane waits for another row's longer list of matches, which is what the in-kernel form pays for (a round per pending
-// match of the busiest lane, per tile).  The text: the 32 bytes that end with the match's last
-// char come from memory into the lane's LDS window (two 16-byte loads: the rows were read a moment ago), longer matches
-// read on byte by byte.
-// ------------------------------------------------------------------------------------------------
-template <int CW>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_starts_kernel(const FindAllArgs fa) {
-    const ScanArgs &a = fa.s;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_waves = blockDim.x >> 6;
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
-    for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u)
-        *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
-    __syncthreads();
-    const uint32_t win_addr = ((a.hdr.lds_bytes + 15u) & ~15u) + ((uint32_t)wave * 64u + (uint32_t)lane) * 32u;
-    const uint64_t n_groups = (a.n_rows + 63) >> 6;
-    for (uint64_t g = (uint64_t)blockIdx.x * n_waves + wave; g < n_groups; g += (uint64_t)gridDim.x * n_waves) {
-        // the matches of the group's 64 rows, numbered row by row: lane l knows row l's count and the count before it
-        const uint64_t my_row = (g << 6) + lane;
-        uint32_t cnt = 0;
-        if (my_row < a.n_rows) cnt = fa.offsets ? (uint32_t)(fa.offsets[my_row + 1] - fa.offsets[my_row]) : fa.counts[my_row];
-        uint32_t incl = cnt; // inclusive prefix sum over the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
-            incl += lane >= o ? t : 0u;
-        }
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t excl = incl - cnt;
-        for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
-            // match j of the group -> its row: the first lane whose inclusive count exceeds j (binary search over the lanes)
-            const uint32_t j = j0 + (uint32_t)lane;
-            const bool act = j < total;
-            uint32_t lo = 0, hi = 63;
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const uint32_t pm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mid << 2), (int)incl);
-                const bool right = pm <= j;
-                lo = right ? mid + 1u : lo;
-                hi = right ? hi : mid;
-            }
-            const uint32_t owner = act ? lo : (uint32_t)lane;
-            const uint32_t k = j - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)excl);
-            const uint64_t row = (g << 6) + owner;
-            const uint64_t out0 = fa.offsets ? (act ? fa.offsets[row] : 0) : row * fa.slots;
-            const uint8_t *rowp = a.rows + (act ? row : 0) * a.stride_bytes;
-            int32_t en = 1, bound = 0;
-            if (act) {
-                en = fa.ends[out0 + k];
-                if (k) bound = fa.ends[out0 + k - 1]; // the match was searched from the end of the one before it
-            }
-            // window: the 16-byte piece holding char en - 1 and the one before it
-            const uint32_t pa = ((uint32_t)(en - 1) * CW) >> 4;
-            const uint32_t pb = pa ? pa - 1u : 0u;
-            u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
-            if (act) {
-                va = *(const u32x4 *)(rowp + (uint64_t)pa * 16u);
-                vb = *(const u32x4 *)(rowp + (uint64_t)pb * 16u);
-            }
-            *(lds_u32x4 *)(uintptr_t)(win_addr) = vb;
-            *(lds_u32x4 *)(uintptr_t)(win_addr + 16u) = va;
-            // (a match ending in the row's first piece: the window is that piece alone, in the upper half)
-            const uint32_t win_b0 = pa ? pb * 16u : 0u;
-            const uint32_t w_addr = pa ? win_addr : win_addr + 16u;
-            const int32_t st = backward_walk<CW>(a, act, en, bound, w_addr, win_b0, pa ? 32u : 16u, 0u, rowp);
-            if (act) fa.starts[out0 + k] = st;
-        }
-    }
-}
-
-hipError_t launch_find_all_starts(int char_width, const FindAllArgs &fa_in, int n_cus, hipStream_t stream) {
-    if (fa_in.s.n_rows == 0) return hipSuccess;
-    FindAllArgs fa = fa_in;
-    // The kernel only needs the BACKWARD automaton's pieces of the forward program's LDS part (they sit behind the forward
-    // maps and table, needle_lower.cpp): stage those alone, offsets rebased, and two workgroups of 16 waves fit a CU (the
-    // kernel is bound by the latency of its dependent loads; it takes 45 VGPRs).  Not with a packed UTF-16 backward
-    // automaton, whose page table holds absolute LDS addresses.
-    ProgHeader &h = fa.s.hdr;
-    if (!h.off_bpack) {
-        uint32_t *offs[] = {&h.off_bcmap, &h.off_bptab, &h.off_bpages, &h.off_btable, &h.off_bsp_bm, &h.off_bsp_base, &h.off_bsp_edges};
-        uint32_t b0 = h.lds_bytes;
-        for (uint32_t *o : offs)
-            if (*o && *o < b0) b0 = *o;
-        b0 &= ~15u;
-        for (uint32_t *o : offs)
-            if (*o) *o -= b0;
-        fa.s.prog += b0;
-        h.lds_bytes -= b0;
-    }
-    const size_t p = (h.lds_bytes + 15u) & ~15u, cap = 160u * 1024u;
-    int waves = 16;
-    while (waves > 1 && p + (size_t)waves * 64 * 32 > cap) waves >>= 1;
-    if (p + (size_t)waves * 64 * 32 > cap) return hipErrorInvalidValue;
-    const size_t lds = p + (size_t)waves * 64 * 32;
-    const int per_cu = (waves == 16 && 2 * lds <= cap) ? 2 : 1;
-    const uint64_t n_groups = (fa.s.n_rows + 63) >> 6;
-    uint64_t blocks = (n_groups + waves - 1) / waves;
-    if (blocks > (uint64_t)n_cus * per_cu) blocks = (uint64_t)n_cus * per_cu;
-    static thread_local uint64_t configured1 = 0, configured2 = 0;
-    if (char_width == 1) {
-        auto k = find_all_starts_kernel<1>;
-        if (hipError_t e = allow_full_lds((const void *)k, configured1); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, fa);
-    } else {
-        auto k = find_all_starts_kernel<2>;
-        if (hipError_t e = allow_full_lds((const void *)k, configured2); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(waves * 64), lds, stream, fa);
-    }
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,8 +20,6 @@ PY
 done
 python - <<PY
 import csv, glob, collections
-# a find-all call is one launch of find_all_kernel and, for table-walked backward automata, one of
-# find_all_starts_kernel: counters and durations are added up per call (= per launch of the walk kernel)
 agg = collections.defaultdict(list)
 dur = []
 for f in sorted(glob.glob("$OUT/p*/p_counter_collection.csv")):

@@ -11,7 +11,7 @@ src = os.path.join(root, "gpurun_out", "prof_fa")
 out = []
 out.append("# needle::find_all_kernel, round 2 (`scripts/profile_find_all.sh`: `rocprofv3 --kernel-trace --stats -- python scripts/find_all_probe.py <workload> 10000000 32`)\n")
 out.append("Every non-overlapping match of every row (the reference's repeated `Matcher.find()`), 10⁷ × 256-char rows resident in HBM, 32 result slots per row, "
-           "outputs preallocated.  `probe ms` = host-timed call + synchronise (best of 4); `kernel µs` = rocprofv3 average of `find_all_kernel` (+ `find_all_starts_kernel` where the starts are a pass of their own: c3, c3s); "
+           "outputs preallocated.  `probe ms` = host-timed call + synchronise (best of 4); `kernel µs` = rocprofv3 average of the kernel; "
            "`rounds ms` = the round-per-match form on the same rows (`NEEDLE_FIND_ALL_ROUNDS=1`: one scan of the batch and one stream synchronisation per round).\n")
 out.append("| workload | matches | busiest row | probe ms | kernel µs (calls) | G matches/s | input GB/s | rounds ms | speed-up | count pass ms | compact form ms (count + prefix sum + fill + allocations) |")
 out.append("|---|---|---|---|---|---|---|---|---|---|---|")
@@ -20,8 +20,8 @@ for w in ("c3", "c2", "c5", "c3s"):
     rnd = json.loads(open(os.path.join(src, w + "_rounds.json")).read().strip().splitlines()[-1])
     k_avg, calls = 0.0, None
     stats = os.path.join(src, w, "t_kernel_stats.csv")
-    for r in csv.DictReader(open(stats)):  # the walk kernel + (table-walked backward automata) the starts kernel
-        if "find_all_kernel" in r["Name"] or "find_all_starts_kernel" in r["Name"]:
+    for r in csv.DictReader(open(stats)):
+        if "find_all_kernel" in r["Name"]:
             k_avg += float(r["AverageNs"]) / 1e3
             calls = int(r["Calls"]) if calls is None else calls
     shutil.copy(stats, os.path.join(root, "profiles", "r02_find_all_%s_kernel_stats.csv" % w))
@@ -39,11 +39,11 @@ for line in open(os.path.join(src, "pmc_c3.txt")):
 traffic = {}
 for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     rows = [r for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))) if r["Counter_Name"] == name]
-    calls = max(1, sum(1 for r in rows if "find_all_kernel" in r["Kernel_Name"]))  # walk kernel + starts kernel, per call
+    calls = max(1, sum(1 for r in rows if "find_all_kernel" in r["Kernel_Name"]))
     traffic[name] = sum(float(r["Counter_Value"]) for r in rows) / calls
 cu_cycles = pmc["GRBM_GUI_ACTIVE"] / 8 * 256
 cw = 4e7
-out.append("\n## PMC, C3 dictionary, both kernels of a call added up (one counter group per pass, `scripts/pmc_find_all.sh`)\n")
+out.append("\n## PMC, C3 dictionary (one counter group per pass, `scripts/pmc_find_all.sh`)\n")
 out.append("| counter | per launch |")
 out.append("|---|---|")
 for k in ("kernel_us", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
@@ -63,7 +63,7 @@ out.append("| LDS instructions per char-wave | %.2f |" % (pmc["SQ_INSTS_LDS"] / 
 out.append("| HBM bytes per launch / (rows + 4 B per row + 8 B per match) | %.2f |" % (
     (traffic["FETCH_SIZE"] * 2048 + traffic["WRITE_SIZE"] * 1024) / (1e7 * 260 + 8 * 46586444)))
 out.append("\nThe walk kernel is VALU-issue bound, not HBM bound: an iteration walks a whole 16-byte piece for every lane under the cursor guard and a tile takes as many "
-           "iterations as its busiest lane (DESIGN.md s3).  The starts kernel reads the text of every match again (the 32 bytes before its end).  The written bytes are several "
+           "iterations as its busiest lane (DESIGN.md s3).  At the end of every 64-row group the text of its matches (the 32 bytes before each end) is read again, mostly from L2.  The written bytes are several "
            "times the results (4-byte stores into per-row slots, filed as the matches are found: partial lines leave the L2 before a row's next match arrives).")
 open(os.path.join(root, "profiles", "r02_find_all.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

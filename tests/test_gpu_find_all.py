@@ -65,14 +65,12 @@ print("FIND-ALL-OK")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env,mode", [({}, 2), ({"NEEDLE_FIND_ALL_DEFER": "0"}, 2), ({"NEEDLE_FIND_ALL_ROUNDS": "1"}, 2),
-                                      ({"NEEDLE_FIND_ALL_SPLIT": "0"}, 2),
                                       ({"NEEDLE_MAX_PROG_LDS": "4096", "NEEDLE_HYBRID": "0"}, 3),
                                       ({"NEEDLE_MAX_PROG_LDS": "4096"}, 5), ({"NEEDLE_MAX_PROG_LDS": "20000"}, 5)],
-                         ids=["one-pass", "starts-at-once", "rounds", "starts-in-place", "hbm-table", "hot-rows-4k", "hot-rows-20k"])
+                         ids=["one-pass", "starts-at-once", "rounds", "hbm-table", "hot-rows-4k", "hot-rows-20k"])
 def test_keyword_dictionary_every_match(env, mode):
     """A 300-keyword union (779 states, uint16 table) over 3000 rows of 256 chars: one to two matches per row, up to 8.
-    Children: the one-pass kernel with the starts found by a pass of their own (default for table-walked backward automata),
-    tile by tile in place, or match by match; the round-per-match form;
+    Children: the one-pass kernel with the starts found group by group (default) or match by match, the round-per-match form,
     and the automaton forced out of the LDS (whole table in HBM; hot rows in LDS + HBM table)."""
     r = subprocess.run([sys.executable, "-c", DICTIONARY, str(mode)], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
@@ -176,8 +174,8 @@ def test_every_match_utf16_script_runs():
 
 @pytest.mark.gpu
 def test_every_match_in_rows_beyond_16_bit_indices():
-    """Rows of 70 000 chars: match ends no longer fit the 16-bit pending stack, starts are found match by match; and a
-    row with more matches than slots says so."""
+    """Rows of 70 000 chars (indices beyond 16 bits, hundreds of tiles per row); and a row with more matches than slots
+    says so."""
     import torch
     p, o = _oracle("[0-9]+x")
     rng = np.random.default_rng(9)
