@@ -63,7 +63,7 @@ out.append("| LDS instructions per char-wave | %.2f |" % (pmc["SQ_INSTS_LDS"] / 
 out.append("| HBM bytes per launch / (rows + 4 B per row + 8 B per match) | %.2f |" % (
     (traffic["FETCH_SIZE"] * 2048 + traffic["WRITE_SIZE"] * 1024) / (1e7 * 260 + 8 * 46586444)))
 out.append("\nThe walk kernel is VALU-issue bound, not HBM bound: an iteration walks a whole 16-byte piece for every lane under the cursor guard and a tile takes as many "
-           "iterations as its busiest lane (DESIGN.md s3).  At the end of every 64-row group the text of its matches (the 32 bytes before each end) is read again, mostly from L2.  The written bytes are several "
+           "iterations as its busiest lane (DESIGN.md s3).  At the end of every 64-row group the text of its matches (the 32 bytes before each end) is read again -- FETCH_SIZE says mostly from HBM: the lines have left the L2 by then.  The written bytes are several "
            "times the results (4-byte stores into per-row slots, filed as the matches are found: partial lines leave the L2 before a row's next match arrives).")
 open(os.path.join(root, "profiles", "r02_find_all.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
