@@ -491,6 +491,22 @@ def main():
     }
     out.update(head)
     out["kernel_source_sha"] = kernel_source_sha()
+    if world == 1 and not use_dist and not args.no_extras and args.rows == 10_000_000 and args.regex is None and args.op is None:
+        # C4's per-GPU share at 8 GPUs, measured on this one GPU: the step over a 1.25M-row shard of the
+        # headline batch (and of C3's, whose find() gathers start / end) -- scan kernel vs whole step, i.e. what launch
+        # overhead costs at that size.  No communication here; N > 1 runs report scan_ms / gather_ms themselves.
+        import copy
+        small = copy.copy(args)
+        small.rows, small.steps, small.warmup, small.no_extras, small.no_cpu_baseline = 1_250_000, 200, 10, True, True
+        out["c4_shard_step"] = {}
+        for w in [args.workload] + [x for x in ("c3",) if x != args.workload]:
+            try:
+                r, _ = measure(w, small, ctx, False)
+                out["c4_shard_step"][w] = {"rows": small.rows, "ms_per_step": r["ms_per_step"], "kernel_ms": r["roofline"]["kernel_ms"],
+                                           "overhead_frac": r["ms_per_step"] / r["roofline"]["kernel_ms"] - 1.0,
+                                           "host_issue_us_per_step": r["host_issue_us_per_step"]}
+            except Exception as e:  # noqa: BLE001
+                out["c4_shard_step"][w] = {"error": "%s: %s" % (type(e).__name__, e)}
     if also:
         out["workloads"] = {}
         for w in also:
