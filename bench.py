@@ -187,6 +187,47 @@ class Ctx:
     pass
 
 
+def verify_gather(sh, dev, row0, n_rows, total_rows, is_find, rank):
+    """One extra step whose gathered results are checked against what every rank computed locally (see measure())."""
+    import torch
+    import torch.distributed as dist
+    s = sh.step()
+    full, st, en = sh.wait(s)
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+    def popcount(words):
+        w = words.contiguous().view(torch.uint8)
+        lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=w.device)
+        return int(lut[w.long()].sum().item())
+
+    def checksum(a, b, first_row):
+        idx = (torch.arange(a.numel(), dtype=torch.int64, device=a.device) + first_row) % 65521 + 1
+        return int(((a.long() + 3 * b.long() + 7) * idx).sum().item())
+
+    local_words = (n_rows + 63) // 64
+    mine = torch.tensor([popcount(s["bitmap"][:local_words]) if n_rows else 0,
+                         checksum(s["start"][:n_rows], s["end"][:n_rows], row0) if (is_find and n_rows) else 0],
+                        dtype=torch.int64, device=dev)
+    dist.all_reduce(mine)
+    want_pop, want_sum = int(mine[0].item()), int(mine[1].item())
+    res = {"ok": True, "popcount_ranks": want_pop}
+    if full is not None:  # every rank (all-gather) or rank 0 (find's fan-in)
+        got = popcount(full[:(total_rows + 63) // 64])
+        res["popcount_gathered"] = got
+        res["ok"] = res["ok"] and got == want_pop
+        if is_find:
+            got_sum = checksum(st[:total_rows], en[:total_rows], 0)
+            res["checksum_ranks"], res["checksum_gathered"] = want_sum, got_sum
+            res["ok"] = res["ok"] and got_sum == want_sum
+    ok = torch.tensor([1 if res["ok"] else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    res["ok"] = bool(int(ok.item()))
+    if not res["ok"] and rank == 0:
+        sys.stderr.write("GATHER VERIFICATION FAILED: %r\n" % (res,))
+    return res
+
+
 def measure(workload, args, ctx, headline):
     """One workload, measured as the contract says: W warm-up steps, then exactly K steps bracketed by barrier +
     synchronize on both sides, max over ranks.  -> the dict that becomes the JSON line (headline) or an entry of
@@ -213,7 +254,7 @@ def measure(workload, args, ctx, headline):
 
     # N > 1, find: start / end cross the links as one dword per row (rows are 256 chars: two 16-bit halves)
     sh = ShardedScan(scan, total_rows, world, rank, is_find, dev, n_buffers=args.buffers, comm=ctx.comm, overlap=args.overlap == "on",
-                     pack16=use_dist and is_find)
+                     pack16=use_dist and is_find, max_row_len=rows.shape[1])
     for _ in range(2):  # first launches: program upload, kernel attributes (never part of a captured graph)
         sh.scan_only()
     torch.cuda.synchronize()
@@ -256,6 +297,23 @@ def measure(workload, args, ctx, headline):
     # Device pre-warm, untimed and not the kernel under test: a GPU that has been idle runs its first ~40 ms of load below
     # its steady clocks (measured on the 10M-row batch: C2 0.45 ms per step right after start-up, 0.404 from step ~100 on).
     # The W warm-up steps and the K timed steps below are the contract's; this only makes them steady-state steps.
+    # The same K steps COLD first (device idle for 0.3 s, no pre-warm): what a caller sees who scans one batch now and then.
+    cold = None
+    if args.prewarm_ms > 0:
+        fence()
+        time.sleep(0.3)
+        tc = time.perf_counter()
+        cold_events = []
+        for _ in range(args.steps):
+            _l, ev = step()
+            cold_events.append(ev)
+        fence()
+        cold_s = time.perf_counter() - tc
+        if use_dist:
+            tt = torch.tensor([cold_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            cold_s = float(tt.item())
+        cold = (cold_s / args.steps, sum(a.elapsed_time(b) for a, b in cold_events) / len(cold_events))
     prewarm_ms = 0.0
     if args.prewarm_ms > 0 and n_rows:
         scratch = torch.empty_like(rows)
@@ -283,6 +341,33 @@ def measure(workload, args, ctx, headline):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    # K timed steps are a few ms: a longer run right behind them (>= 100 ms of steps, same protocol) says whether the K steps
+    # were representative of the steady state.  `value` stays the contract's exactly-K-steps figure.
+    steady = None
+    if n_rows or use_dist:
+        ks = max(args.steps, int(0.1 / max(elapsed / args.steps, 1e-6)) + 1)
+        if use_dist:
+            kt = torch.tensor([ks], dtype=torch.int64, device=dev)
+            dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+            ks = int(kt.item())
+        t1 = time.perf_counter()
+        sev = []
+        for _ in range(ks):
+            _l, ev = step()
+            sev.append(ev)
+        fence()
+        steady_s = time.perf_counter() - t1
+        if use_dist:
+            tt = torch.tensor([steady_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            steady_s = float(tt.item())
+        steady = (ks, steady_s / ks, sum(a.elapsed_time(b) for a, b in sev) / len(sev))
+    # N > 1: what the gather delivered must be what the ranks computed -- a mis-ordered or truncated gather would otherwise
+    # still print a clean line.  One more step, then: popcount of the gathered bitmap == sum over ranks of the shards'
+    # popcounts, and for find() a position-weighted checksum of the gathered start / end == the sum of the ranks' own.
+    gather_check = None
+    if use_dist:
+        gather_check = verify_gather(sh, dev, row0, n_rows, total_rows, is_find, rank)
 
     # algorithmic bytes: L*w input bytes + result bytes (1 bit/row; find adds 2 x int32/row)
     per_row = 256 * cw + (8 if is_find else 0)
@@ -297,7 +382,8 @@ def measure(workload, args, ctx, headline):
     props = torch.cuda.get_device_properties(dev)
     inf = pattern.info()
     which = {"contained_in": "contained_in", "find": "forwards", "matches": "matches"}[op_name]
-    mode_names = {0: "packed functions", 1: "LDS table u8", 2: "LDS table u16", 3: "HBM table", 4: "LDS pair table", 5: "LDS hot rows + HBM table"}
+    mode_names = {0: "packed functions", 1: "LDS table u8", 2: "LDS table u16", 3: "HBM table", 4: "LDS pair table", 5: "LDS hot rows + HBM table",
+                  6: "compressed automaton in LDS (dense rows + exception records)"}
     out = {
         "value": bytes_job / step_s / 1e9,
         "unit": "GB/s",
@@ -323,6 +409,17 @@ def measure(workload, args, ctx, headline):
         "host_issue_us_per_step": t_issue / args.steps * 1e6,
         "prewarm": {"ms": prewarm_ms, "what": "untimed copies of the batch before the W warm-up steps (steady clocks)"},
     }
+    if cold is not None:
+        out["cold"] = {"ms_per_step": cold[0] * 1e3, "kernel_ms": cold[1], "steps": args.steps,
+                       "roofline.frac": bytes_gpu / (cold[1] * 1e-3) / 1e9 / HBM_PEAK_GBS if cold[1] > 0 else None,
+                       "what": "the same K steps right after 0.3 s of device idle, before the pre-warm (first steps below steady clocks)"}
+    if steady is not None:
+        out["steady"] = {"steps_effective": steady[0], "ms_per_step": steady[1] * 1e3, "kernel_ms": steady[2],
+                         "roofline.frac": bytes_gpu / (steady[2] * 1e-3) / 1e9 / HBM_PEAK_GBS if steady[2] > 0 else None,
+                         "what": ">= 100 ms of steps right behind the K timed ones (same barriers; not the `value`)"}
+    if gather_check is not None:
+        out["gather_verified"] = gather_check["ok"]
+        out["gather_check"] = gather_check
     # HBM traffic per launch comes from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per
     # MI355X_MICROARCH.md) committed under profiles/ for this workload at this size -- and only if that profile was
     # taken with the kernels being benchmarked now (hash of the device sources); otherwise null.

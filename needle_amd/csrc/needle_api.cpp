@@ -312,6 +312,12 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     const bool need_backward = op == OP_FIND && p->t.fixed_len < 0;
     rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
+    if (d_end_state && (fp->prog.hdr.mode == MODE_HYBRID || fp->prog.hdr.mode == MODE_SPARSE)) {
+        // the speculative-stripe pass wants every stripe's end state in the numbering of the HBM-table layout its fix-up
+        // kernel walks (variant 3); the hot-rows and compressed forms number / encode states their own way
+        rc = get_program(p, which, (int)v->char_width, 3, &fp, &n_cus);
+        if (rc) return rc;
+    }
     if (!d_end_state && wants_stripe_path(v, fp->prog.hdr, d_from != nullptr)) return run_stripe_path(p, op, v, fp, n_cus, d_bitmap, d_start, d_end, stream);
     if (!d_end_state && !d_from && fp->prog.hdr.mode != MODE_PACK) {
         bool done = false;
@@ -347,8 +353,12 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     a.start = d_start;
     a.end = d_end;
     a.end_state = d_end_state;
-    static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr; // measurement aid: start = end
-    if ((no_backward || dbg_no_backward) && op == OP_FIND) a.fixed_len = 0, a.bprog = nullptr; // (speculative pass: only lastMatch is wanted)
+    bool skip_backward = no_backward; // (speculative pass: only lastMatch is wanted)
+#ifdef NEEDLE_TUNING // measurement builds only (scripts/build_tuning.sh): a switch that changes ANSWERS (start = end) never ships
+    static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr;
+    skip_backward = skip_backward || dbg_no_backward;
+#endif
+    if (skip_backward && op == OP_FIND) a.fixed_len = 0, a.bprog = nullptr;
     HIP_TRY(launch_scan(op, (int)v->char_width, a, n_cus, (hipStream_t)stream));
     return NEEDLE_OK;
 }
@@ -816,6 +826,24 @@ int needle_pattern_get_info(const needle_pattern *p, needle_pattern_info *o) {
     return NEEDLE_OK;
 }
 
+int needle_pattern_program_info(const needle_pattern *p, int which, int char_width, int with_backward, needle_program_info *o) {
+    if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    if (which < 0 || which > 2 || (char_width != 1 && char_width != 2)) return fail(NEEDLE_ERR_INVALID, "which / char_width out of range");
+    memset(o, 0, sizeof(*o));
+    const Program pr = lower(p->t, (Which)which, char_width, max_prog_lds(), false, with_backward != 0 && which == W_FORWARDS && p->t.fixed_len < 0);
+    o->mode = (int32_t)pr.hdr.mode;
+    o->n_states = (int32_t)pr.hdr.n_states;
+    o->lds_bytes = (int32_t)pr.hdr.lds_bytes;
+    o->blob_bytes = (int32_t)pr.blob.size();
+    int waves = 0, chb = 0, in_f = 0;
+    if (shape_for_program(pr.hdr, char_width, &waves, &chb, &in_f)) o->waves = waves, o->tile_bytes = chb;
+    o->dense_rows = (int32_t)pr.hdr.sp_dense;
+    o->records = (int32_t)pr.hdr.sp_records;
+    o->chains = (int32_t)pr.hdr.sp_chains;
+    if (pr.hdr.mode == MODE_HYBRID) o->hot_rows = (int32_t)(pr.hdr.hot_bytes / (pr.hdr.n_cols * 2u));
+    return NEEDLE_OK;
+}
+
 int needle_pattern_get_class_map(const needle_pattern *p, uint8_t *cm) {
     if (!p || !cm) return fail(NEEDLE_ERR_INVALID, "NULL argument");
     memcpy(cm, p->t.class_map.data(), 65536);
@@ -993,8 +1021,10 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     fa.count_only = count_only ? 1u : 0u;
     static const bool no_defer = getenv("NEEDLE_FIND_ALL_DEFER") && atoi(getenv("NEEDLE_FIND_ALL_DEFER")) == 0; // A/B, tests
     fa.defer = (a.fixed_len < 0 && !a.hdr.root_accepting && !no_defer) ? 1u : 0u;
-    static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr; // measurement aid: start = the search cursor
+#ifdef NEEDLE_TUNING // measurement builds only: start = the search cursor (wrong answers; never in the shipping library)
+    static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr;
     if (fa.defer && dbg_no_backward) fa.defer = 2;
+#endif
     fa.counts = d_counts;
     fa.starts = d_start;
     fa.ends = d_end;
@@ -1132,18 +1162,43 @@ static int find_all_csr_host_one(const needle_pattern *p, const needle_batch_vie
     for (size_t r = 0; r < n; ++r) offsets[r + 1] = offsets[r] + counts[r];
     const uint64_t m = offsets[n] - offsets[0];
     if (m == 0 || offsets[n] > capacity) return done(NEEDLE_OK); // nothing to file, or the caller's buffers are too small
-    std::vector<uint64_t> local(n + 1);
-    for (size_t r = 0; r <= n; ++r) local[r] = offsets[r] - offsets[0];
-    e = hipMalloc((void **)&d_out, 2 * up16(m * 4));
-    if (e == hipSuccess) e = hipMemcpy(d + o_off, local.data(), (n + 1) * 8, hipMemcpyHostToDevice);
-    if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host offsets"));
-    int more = 0;
-    rc = needle_find_all_csr_dev(p, &dv, (const uint64_t *)(d + o_off), (int32_t *)d_out, (int32_t *)(d_out + up16(m * 4)), &more, nullptr);
-    if (rc) return done(rc);
-    if (more) return done(fail(NEEDLE_ERR_DEVICE, "find_all_csr_host: count pass and fill pass disagree"));
-    e = hipMemcpy(start + offsets[0], d_out, m * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(end + offsets[0], d_out + up16(m * 4), m * 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host download"));
+    // The fill pass runs over sub-ranges of the chunk's rows so that the results resident on the device stay bounded too:
+    // a dense-match batch (a one-char pattern over 256-char rows files ~2 KiB per row) would otherwise ask for several
+    // times the chunk's row bytes in one allocation.  NEEDLE_HOST_RESULT_BYTES: that bound (tests shrink it).
+    static const uint64_t kResultBytes = getenv("NEEDLE_HOST_RESULT_BYTES") ? (uint64_t)atoll(getenv("NEEDLE_HOST_RESULT_BYTES")) : (512ull << 20);
+    const uint64_t max_m = std::max<uint64_t>(kResultBytes / 8, 1);
+    std::vector<std::pair<size_t, size_t>> ranges; // [r0, r1): at least one row, at most max_m matches (one row may exceed it)
+    uint64_t biggest = 0;
+    for (size_t r0 = 0; r0 < n;) {
+        size_t r1 = r0 + 1;
+        while (r1 < n && offsets[r1 + 1] - offsets[r0] <= max_m) ++r1;
+        ranges.emplace_back(r0, r1);
+        biggest = std::max<uint64_t>(biggest, offsets[r1] - offsets[r0]);
+        r0 = r1;
+    }
+    e = hipMalloc((void **)&d_out, 2 * up16(biggest * 4) + 16);
+    if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host results"));
+    std::vector<uint64_t> local;
+    for (const auto &rg : ranges) {
+        const size_t r0 = rg.first, nr = rg.second - rg.first;
+        const uint64_t mr = offsets[rg.second] - offsets[r0];
+        if (mr == 0) continue;
+        local.resize(nr + 1);
+        for (size_t r = 0; r <= nr; ++r) local[r] = offsets[r0 + r] - offsets[r0];
+        e = hipMemcpy(d + o_off, local.data(), (nr + 1) * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host offsets"));
+        needle_batch_view sv = dv;
+        sv.rows = d + r0 * dst_stride;
+        sv.lengths = dv.lengths ? dv.lengths + r0 : nullptr;
+        sv.n_rows = nr;
+        int more = 0;
+        rc = needle_find_all_csr_dev(p, &sv, (const uint64_t *)(d + o_off), (int32_t *)d_out, (int32_t *)(d_out + up16(biggest * 4)), &more, nullptr);
+        if (rc) return done(rc);
+        if (more) return done(fail(NEEDLE_ERR_DEVICE, "find_all_csr_host: count pass and fill pass disagree"));
+        e = hipMemcpy(start + offsets[r0], d_out, mr * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(end + offsets[r0], d_out + up16(biggest * 4), mr * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return done(hip_fail(e, "find_all_csr_host download"));
+    }
     return done(NEEDLE_OK);
 }
 int needle_find_all_csr_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *offsets, int32_t *start, int32_t *end,

@@ -18,6 +18,12 @@ enum Mode : int {
                       // states in breadth-first order from the start state are in LDS, the whole table in HBM; a lane
                       // in a colder state fetches its entry through the scalar cache.  Entries carry the "accepting" bit
                       // (bit 15) so that the numbering is free to follow the breadth-first order.
+    MODE_SPARSE = 6,  // table too large for LDS as a dense [state][column] array, but compressible: the states near the start
+                      // state (breadth-first) keep DENSE rows of uint32 cells, every other state is a "default row + exception"
+                      // chain of 8-byte records -- and the WHOLE automaton is LDS-resident.  A state is the pair
+                      //   (rowA4 = LDS address / 4 of the dense row to read, recB = LDS address of its first record)
+                      // in one dword (recB << 16 | rowA4): a transition is ONE LDS round trip -- the dense cell and the
+                      // record are read in parallel and the record wins when its key is the char's column.
     MODE_PAIR = 4,    // 8-bit rows, <= 256 states, n_states * n_cols^2 entries fit the LDS: TWO chars per dependent
                       // lookup -- uint16 [state][col1][col2] = next state after both | code << 8 (find: 0 no accept,
                       // 1 accepted after the first char only, 2 accepted after the second)
@@ -65,6 +71,19 @@ struct ProgHeader {
                          // of the columns with a live target here, uint16 base[state] at off_bsp_base, and the live targets
                          // back to back at off_bsp_edges: next = bit(col) ? edges[base + popcount(bitmap below col)] : sink
     uint32_t off_bsp_base, off_bsp_edges;
+    // MODE_SPARSE (all addresses relative to the table base: kLdsTable1 for 8-bit rows, off_table for UTF-16 ones):
+    //   [0, (N+1)*4)        the sink's row (all cells 0; the sink is state value 0)
+    //   [sp_rec_base, ..)   records {uint16 key = column * 4, uint16 next_record (0 = none), uint32 target state}: the
+    //                       never-matching dummy of the non-accepting dense states first, then the chains of the non-accepting
+    //                       sparse states, then -- from sp_accept_rec on -- the accepting dummy and the accepting states'
+    //                       chains, so that accepted(s) == (s >= accept_lo) with accept_lo = sp_accept_rec << 16
+    //   [sp_rows_base, ..)  dense rows: uint32 cells [N + 1 columns] = the target's state value
+    // PAD / PRE are not columns in this mode (identity differs for every state: each would cost every sparse state an
+    // exception): the guarded kernels select them after the lookup.
+    uint32_t sp_rec_base, sp_accept_rec, sp_rows_base;
+    uint32_t sp_chains;    // some state needs more than one record: the walk loops while a lane's record has a successor
+    uint32_t sp_pad_ident; // PAD (chars past the row's length) is the identity (matches / containedIn) or leads to the sink
+    uint32_t sp_dense, sp_records; // statistics: dense rows (without the sink), records (without the two dummies)
     uint32_t off_bpack;  // != 0: the backward automaton has <= 5 states and rides along as packed functions: 8-bit rows
                          // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)
                          // followed by its F area.  The backward walk then needs no state-dependent lookup.

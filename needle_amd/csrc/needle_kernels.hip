@@ -37,7 +37,7 @@ bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb
         *tiles_in_f_rows = 1;
         return true;
     }
-    static const int cand[6][2] = {{16, 128}, {12, 128}, {16, 64}, {12, 64}, {8, 64}, {4, 64}};
+    static const int cand[8][2] = {{16, 128}, {12, 128}, {16, 64}, {14, 64}, {12, 64}, {10, 64}, {8, 64}, {4, 64}};
     for (const auto &c : cand) {
         if (p + (size_t)c[0] * 64 * c[1] <= cap) {
             *waves = c[0];
@@ -54,8 +54,9 @@ hipError_t launch_scan(int op, int char_width, const ScanArgs &a_in, int n_cus, 
     if (a_in.n_rows == 0) return hipSuccess;
     {
         static const int short_rows = getenv("NEEDLE_SHORT_ROWS") ? atoi(getenv("NEEDLE_SHORT_ROWS")) : 1; // 0: tuning / tests
-        // (hot-rows automata on short rows take the tiled kernel: the register-resident one has no such mode)
-        if (short_rows && a_in.stride_bytes <= 64 && a_in.hdr.mode != MODE_HYBRID) return launch_short_rows(op, char_width, a_in, n_cus, stream);
+        // (hot-rows and compressed automata on short rows take the tiled kernel: the register-resident one has no such modes)
+        if (short_rows && a_in.stride_bytes <= 64 && a_in.hdr.mode != MODE_HYBRID && a_in.hdr.mode != MODE_SPARSE)
+            return launch_short_rows(op, char_width, a_in, n_cus, stream);
     }
     ScanArgs a = a_in;
     LaunchShape sh;

@@ -11,6 +11,7 @@
 //   * wasAccepted<X>(state)    -> states renumbered so that accepted(s) == (s >= A0)
 #include "needle_lower.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -106,6 +107,234 @@ static ColumnMaps column_maps(const RefTables &t, const RefDfa &d, int char_widt
     }
     return m;
 }
+
+// ---- MODE_SPARSE: "dense rows near the start state + default-row / exception records for every other state" ----------
+// The reference's table (DFAClassBuilder.java:317-333; walked at :438-468) is a dense [state][class] array.  Search
+// automata of big alternations (a keyword dictionary) have thousands of states whose rows differ from the row of a
+// shallower state in one or two cells (Aho-Corasick's failure links, seen from the table).  Here the first states in
+// breadth-first order keep dense rows; every other state is stored as the dense row it mostly equals plus a chain of
+// {column, target} exception records.  The result is verified cell by cell against the dense table before it is used.
+namespace {
+struct SparseImage {
+    std::vector<uint8_t> img; // relative to the table base
+    uint32_t rec_base = 0, accept_rec = 0, rows_base = 0, start = 0, accept_lo = 0, chains = 0, dense = 0, records = 0;
+};
+
+constexpr int kSparseMaxChain = 3; // states that need more exceptions than this against every candidate row become dense
+
+// next_full: device-numbered table [n_dev][n_cols_full] (0 = sink | non-accepting | accepting from accept_lo_dev on); only
+// the columns listed in `cols` take part, renumbered 0 .. cols.size() - 1 in that order.  room: bytes the image may take.
+bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_full, const std::vector<int> &cols, int start_dev,
+                  int accept_lo_dev, size_t room, SparseImage &out) {
+    const int NC = (int)cols.size();
+    const size_t row_bytes = (size_t)NC * 4;
+    if (n_dev < 2 || NC < 1 || NC * 4 > 0xFFFC) return false;
+    // only the columns some char of the haystack's width maps to take part (8-bit rows never see the class of U+FFFF, nor
+    // OVER when maxChar >= 255): compacted copy [n_dev][NC]
+    std::vector<uint16_t> next((size_t)n_dev * NC);
+    for (int s = 0; s < n_dev; ++s)
+        for (int j = 0; j < NC; ++j) next[(size_t)s * NC + j] = next_full[(size_t)s * n_cols_full + cols[j]];
+    n_cols_full = NC;
+    auto cell = [&](int s, int c) -> int { return next[(size_t)s * n_cols_full + c]; };
+    // breadth-first order from the start state; def[s] = the state the automaton would be in had it not seen the first
+    // char of the shortest string leading to s (Aho-Corasick's failure state, derived from the table alone): the row s most
+    // likely shares
+    std::vector<int> order, pos(n_dev, -1), def(n_dev, 0);
+    order.reserve(n_dev);
+    pos[start_dev] = 0;
+    def[start_dev] = start_dev;
+    order.push_back(start_dev);
+    for (size_t h = 0; h < order.size(); ++h) {
+        const int p = order[h];
+        for (int c = 0; c < NC; ++c) {
+            const int s = cell(p, c);
+            if (s == 0 || pos[s] >= 0) continue;
+            pos[s] = (int)order.size();
+            order.push_back(s);
+            int d = p == start_dev ? start_dev : cell(def[p], c);
+            if (d == s) d = start_dev;
+            def[s] = d;
+        }
+    }
+    const int S = (int)order.size(); // reachable states without the sink (unreachable ones -- containedIn's accepting states
+                                     // but the first, see lower() -- get no storage: no cell leads to them)
+
+    std::vector<uint8_t> is_dense(n_dev, 0);
+    std::vector<int> dflt(n_dev, 0);
+    std::vector<std::vector<int>> exc(n_dev); // columns in which s differs from its default row
+    uint64_t work = 0;
+    const uint64_t work_cap = 600ull * 1000 * 1000;
+    auto diff = [&](int s, int d, int stop) { // number of differing cells, counting stops beyond `stop`
+        int n = 0;
+        const uint16_t *a = &next[(size_t)s * n_cols_full], *b = &next[(size_t)d * n_cols_full];
+        for (int c = 0; c < NC && n <= stop; ++c) n += a[c] != b[c];
+        work += (uint64_t)NC;
+        return n;
+    };
+    // with the BFS prefix [0, D) dense: defaults and exceptions of every other state; returns the image size
+    auto evaluate = [&](int D) -> size_t {
+        std::fill(is_dense.begin(), is_dense.end(), 0);
+        is_dense[0] = 1;
+        for (int i = 0; i < D; ++i) is_dense[order[i]] = 1;
+        size_t n_rec = 0, n_dense = (size_t)D;
+        for (int i = D; i < S; ++i) {
+            const int s = order[i];
+            int best = 0, best_n = diff(s, 0, NC); // the sink's row (all cells 0) is always a candidate
+            auto consider = [&](int d) {
+                if (!is_dense[d] || d == best) return;
+                const int n = diff(s, d, best_n);
+                if (n < best_n) best = d, best_n = n;
+            };
+            int x = def[s];
+            for (int hop = 0; hop < 64 && x != 0; ++hop) { // the nearest dense state(s) on the failure chain
+                if (is_dense[x]) { consider(x); break; }
+                const int nx = def[x];
+                if (nx == x) break;
+                x = nx;
+            }
+            consider(start_dev);
+            if (best_n > 1 && work < work_cap) // the heuristic candidates are poor: look at every dense row
+                for (int j = 0; j < D && best_n > 1; ++j) consider(order[j]);
+            if (best_n > kSparseMaxChain) { // no row is close: the state keeps a dense row of its own
+                is_dense[s] = 2;
+                ++n_dense;
+                continue;
+            }
+            dflt[s] = best;
+            exc[s].clear();
+            for (int c = 0; c < NC; ++c)
+                if (cell(s, c) != cell(best, c)) exc[s].push_back(c);
+            n_rec += exc[s].size();
+        }
+        return ((row_bytes + 7) & ~(size_t)7) + (2 + n_rec) * 8 + n_dense * row_bytes + 8;
+    };
+    // the largest dense prefix whose image fits the room
+    int D = (int)std::min<size_t>((size_t)S, room / row_bytes);
+    size_t bytes = 0;
+    for (int iter = 0; iter < 40; ++iter) {
+        bytes = evaluate(D);
+        if (getenv("NEEDLE_SPARSE_DEBUG")) fprintf(stderr, "[sparse] iter %d: S=%d D=%d bytes=%zu room=%zu\n", iter, S, D, bytes, room);
+        if (bytes <= room) break;
+        const size_t over = bytes - room, per_row = row_bytes > 16 ? row_bytes - 8 : 8;
+        const int drop = (int)((over + per_row - 1) / per_row);
+        if (D == 0) return false;
+        D = std::max(0, D - std::max(1, drop));
+    }
+    static const bool dbg = getenv("NEEDLE_SPARSE_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[sparse] S=%d NC=%d room=%zu D=%d bytes=%zu work=%llu\n", S, NC, room, D, bytes, (unsigned long long)work);
+    if (bytes > room) return false;
+    // spare room: promote the states with the longest chains (they cost extra LDS round trips), breadth-first among equals
+    for (int want = kSparseMaxChain; want >= 2; --want)
+        for (int i = D; i < S; ++i) {
+            const int s = order[i];
+            if (is_dense[s] || (int)exc[s].size() != want) continue;
+            const size_t nb = bytes + row_bytes - 8 * exc[s].size();
+            if (nb > room) continue;
+            is_dense[s] = 2;
+            exc[s].clear();
+            bytes = nb;
+        }
+
+    // ---- addresses
+    const uint32_t rec_base = (uint32_t)((row_bytes + 7) & ~(size_t)7);
+    std::vector<uint32_t> rec_at(n_dev, 0); // address of a sparse state's first record (its acceptance class's dummy when it has none)
+    uint32_t at = rec_base;
+    const uint32_t dummy_nonacc = at;
+    at += 8;
+    uint32_t n_records = 0, chains = 0;
+    auto place = [&](bool accepting) {
+        for (int i = 0; i < S; ++i) {
+            const int s = order[i];
+            if (is_dense[s] || (s >= accept_lo_dev) != accepting) continue;
+            if (exc[s].empty()) continue;
+            rec_at[s] = at;
+            at += 8u * (uint32_t)exc[s].size();
+            n_records += (uint32_t)exc[s].size();
+            if (exc[s].size() > 1) chains = 1;
+        }
+    };
+    place(false);
+    const uint32_t dummy_acc = at;
+    at += 8;
+    place(true);
+    if (dbg) fprintf(stderr, "[sparse] records end at %u (%u records, chains %u)\n", at, n_records, chains);
+    if (at > 0x10000u) return false; // record addresses are 16-bit fields
+    const uint32_t rows_base = (at + 3u) & ~3u;
+    std::vector<uint32_t> row_at(n_dev, 0);
+    uint32_t n_dense = 0;
+    {
+        uint32_t r = rows_base;
+        for (int i = 0; i < S; ++i)
+            if (is_dense[order[i]]) { row_at[order[i]] = r; r += (uint32_t)row_bytes; ++n_dense; }
+        if (r / 4 > 0xFFFFu || r > room + 8) return false;
+        out.img.assign(r, 0);
+    }
+    auto value = [&](int s) -> uint32_t { // state value: recB << 16 | rowA4
+        if (s == 0) return 0u;
+        const bool acc = s >= accept_lo_dev;
+        if (is_dense[s]) return ((acc ? dummy_acc : dummy_nonacc) << 16) | (row_at[s] >> 2);
+        const uint32_t rec = exc[s].empty() ? (acc ? dummy_acc : dummy_nonacc) : rec_at[s];
+        return (rec << 16) | (row_at[dflt[s]] >> 2); // row_at[0] = 0: the sink's row
+    };
+    auto put32 = [&](uint32_t off, uint32_t v) { memcpy(&out.img[off], &v, 4); };
+    put32(dummy_nonacc, 0xFFFFu); // key 0xFFFF: no column * 4 equals it; no successor; target unused
+    put32(dummy_acc, 0xFFFFu);
+    for (int i = 0; i < S; ++i) {
+        const int s = order[i];
+        if (is_dense[s]) {
+            for (int c = 0; c < NC; ++c) put32(row_at[s] + 4u * (uint32_t)c, value(cell(s, c)));
+        } else {
+            for (size_t k = 0; k < exc[s].size(); ++k) {
+                const uint32_t a = rec_at[s] + 8u * (uint32_t)k;
+                const uint32_t nxt = k + 1 < exc[s].size() ? a + 8u : 0u;
+                put32(a, ((uint32_t)exc[s][k] * 4u) | (nxt << 16));
+                put32(a + 4, value(cell(s, exc[s][k])));
+            }
+        }
+    }
+    out.rec_base = rec_base;
+    out.accept_rec = dummy_acc;
+    out.rows_base = rows_base;
+    out.start = value(start_dev);
+    out.accept_lo = dummy_acc << 16;
+    out.chains = chains;
+    out.dense = n_dense;
+    out.records = n_records;
+
+    // ---- verification: walk the image the way the kernel does (needle_walk.h, apply<MODE_SPARSE>) for every state and
+    // column and compare with the dense table
+    auto rd32 = [&](uint32_t off) -> uint32_t {
+        uint32_t v = 0;
+        if ((size_t)off + 4 <= out.img.size()) memcpy(&v, &out.img[off], 4); // (out-of-range DS reads return 0)
+        return v;
+    };
+    for (int s = 0; s < n_dev; ++s) {
+        if (s != 0 && pos[s] < 0) continue;
+        const uint32_t sv = value(s);
+        if ((sv >= out.accept_lo) != (s >= accept_lo_dev && s != 0)) return false;
+        for (int c = 0; c < NC; ++c) {
+            const uint32_t col4 = (uint32_t)c * 4u;
+            const uint32_t a = rd32((sv & 0xFFFFu) * 4u + col4);
+            uint32_t b0 = rd32(sv >> 16), b1 = rd32((sv >> 16) + 4);
+            bool hit = (b0 & 0xFFFFu) == col4;
+            uint32_t nx = hit ? b1 : a;
+            int guard = 0;
+            while (!hit && b0 > 0xFFFFu && guard++ < 16) {
+                const uint32_t r = b0 >> 16;
+                b0 = rd32(r);
+                b1 = rd32(r + 4);
+                hit = (b0 & 0xFFFFu) == col4;
+                nx = hit ? b1 : nx;
+            }
+            if (nx != value(cell(s, c))) {
+                if (dbg) fprintf(stderr, "[sparse] verification failed: state %d column %d\n", s, c);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+} // namespace
 
 Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
               bool with_backward_maps, bool no_pair) {
@@ -229,7 +458,9 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         }
         // ... and a backward automaton of <= 6 states as packed functions (same device numbering as `bp`): its walk is
         // then 8 independent char -> F lookups and a chain of v_bfe_u32, not 8 x (2-3 dependent lookups)
-        const Program pk = lower(t, W_BACKWARDS, char_width, 64u << 10, false, false, false);
+        Program pk;
+        pk.hdr.mode = MODE_GLOBAL;
+        if (t.dfa[W_BACKWARDS].n_states + 1 <= 5) pk = lower(t, W_BACKWARDS, char_width, 64u << 10, false, false, false);
         if (pk.hdr.mode == MODE_PACK && (char_width == 1 || pk.hdr.lds_bytes <= (24u << 10))) {
             p.hdr.bpack_start_off = pk.hdr.start_off;
             p.hdr.bpack_accept_off = pk.hdr.accept_off;
@@ -352,7 +583,72 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         const uint32_t elem = (mode == MODE_TABLE16) ? 2u : 1u;
         if (char_width == 2 && (uint32_t)n_cols * elem > 255u) mode = MODE_GLOBAL; // pages hold column * elem in a byte
         build(mode);
-        if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget) {
+        bool sparse_done = false;
+        if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget && !no_pair) {
+            // Too big for a dense table in LDS.  First choice: the compressed whole-automaton form (MODE_SPARSE, above).
+            // NEEDLE_SPARSE=0 turns it off (A/B, tests of the hot-rows mode); NEEDLE_SPARSE_ROOM: LDS bytes the program may take
+            // (default: what leaves room for 16 waves x 64-byte tiles).
+            static const bool sparse_on = !(getenv("NEEDLE_SPARSE") && atoi(getenv("NEEDLE_SPARSE")) == 0);
+            static const size_t sparse_room = getenv("NEEDLE_SPARSE_ROOM") ? (size_t)atol(getenv("NEEDLE_SPARSE_ROOM")) : (size_t)(96u << 10);
+            // columns in use: the reference classes (and OVER) that some code unit of this width maps to, renumbered densely
+            std::vector<int> cols, col_id(n_cols, -1);
+            {
+                std::vector<uint8_t> used(n_cols, 0);
+                if (char_width == 1) for (int c = 0; c < 256; ++c) used[cm.cmap8[c]] = 1;
+                else for (uint8_t c : cm.pages) used[c] = 1;
+                for (int k = 0; k < n_cols; ++k)
+                    if (used[k]) { col_id[k] = (int)cols.size(); cols.push_back(k); }
+            }
+            const int NC = (int)cols.size();
+            const bool cols_ok = char_width == 1 || NC * 4 <= 256; // UTF-16: the pages hold column * 4 in a byte
+            if (sparse_on && cols_ok) {
+                // containedIn: every accepting state is absorbing -- one state as far as the walk is concerned
+                std::vector<uint16_t> canon;
+                const std::vector<uint16_t> *tab = &next;
+                if (contained && accept_lo < n_dev) {
+                    canon = next;
+                    for (auto &v : canon)
+                        if ((int)v >= accept_lo) v = (uint16_t)accept_lo;
+                    for (int k = 0; k < n_cols; ++k) canon[(size_t)accept_lo * n_cols + k] = (uint16_t)accept_lo;
+                    tab = &canon;
+                }
+                p.blob.clear();
+                p.hdr.off_bcmap = p.hdr.off_bptab = p.hdr.off_bpages = p.hdr.off_btable = p.hdr.off_bpack = 0;
+                if (char_width == 1) {
+                    p.blob.assign(kLdsTable1, 0);
+                    for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, (uint32_t)col_id[cm.cmap8[c]] * 4u);
+                } else {
+                    p.blob.assign(kLdsPages2Table + cm.pages.size(), 0);
+                    for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
+                    for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Table + i] = (uint8_t)(col_id[cm.pages[i]] * 4);
+                    while (p.blob.size() % 16) p.blob.push_back(0);
+                }
+                const size_t fixed = p.blob.size() + (with_backward_maps ? (char_width == 1 ? 256 : 256 + bm.pages.size()) + 64 : 0) + 64;
+                const size_t room = std::min(lds_table_budget, sparse_room);
+                SparseImage im;
+                if (room > fixed && build_sparse(*tab, n_dev, n_cols, cols, dev[0], accept_lo, room - fixed, im)) {
+                    p.hdr.off_table = (uint32_t)p.blob.size();
+                    p.blob.insert(p.blob.end(), im.img.begin(), im.img.end());
+                    mode = MODE_SPARSE;
+                    emit_backward_maps();
+                    while (p.blob.size() % 16) p.blob.push_back(0);
+                    p.hdr.lds_bytes = (uint32_t)p.blob.size();
+                    p.hdr.start = im.start;
+                    p.hdr.accept_lo = im.accept_lo;
+                    p.hdr.sp_rec_base = im.rec_base;
+                    p.hdr.sp_accept_rec = im.accept_rec;
+                    p.hdr.sp_rows_base = im.rows_base;
+                    p.hdr.sp_chains = im.chains;
+                    p.hdr.sp_pad_ident = (which == W_MATCHES || contained) ? 1u : 0u;
+                    p.hdr.sp_dense = im.dense;
+                    p.hdr.sp_records = im.records;
+                    sparse_done = true;
+                } else {
+                    build(mode); // (the dense layout again, for the fallbacks below)
+                }
+            }
+        }
+        if (!sparse_done && mode != MODE_GLOBAL && p.blob.size() > lds_table_budget) {
             mode = MODE_GLOBAL;
             build(mode);
             // Hot rows in LDS + the whole table in HBM.  Search automata on real text sit in the few states near their

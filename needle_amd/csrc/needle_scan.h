@@ -68,6 +68,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         wk.pad_b = a.hdr.pad_col * 2u;
         wk.pre_b = (a.hdr.pad_col + 1u) * 2u;
     }
+    if (MODE == MODE_SPARSE) wk.pad_e = wk.pre_e = 0; // (any valid column: the guarded walk overrides the result, needle_walk.h)
+    wk.sp_chains = a.hdr.sp_chains;
+    wk.sp_pad_ident = a.hdr.sp_pad_ident;
     wk.table_off = a.hdr.off_table;
     wk.lane4 = (uint32_t)(lane & 31) * 4u; // lanes l and l+32 are served in different LDS passes: 32 copies suffice
     wk.gtable = (const uint16_t *)(a.prog + (MODE == MODE_HYBRID ? a.hdr.off_gtable : a.hdr.off_table));
@@ -287,9 +290,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         else res = row_ok && (st >= accept_lo);
         if (!POOLED) {
             const uint64_t word = __ballot(res);
-            if (lane == 0) a.bitmap[grp] = word;
+            // In a kernel with a pool the word is written by an agent-scope ATOMIC store: rows the group deferred OR their
+            // bits into this same word later (below), from another lane of this same wave.  Both are then atomic accesses
+            // of one address issued in program order by one wavefront, which the memory pipeline keeps in issue order per
+            // address up to the L2 (the point of coherence); a plain store would leave that to how the vector L1 happens to
+            // drain.  (Relaxed: no fence, no vmcnt wait -- the tile prefetch in flight is not drained.)
+            if (lane == 0) {
+                if (POOL) __hip_atomic_store(&a.bitmap[grp], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else a.bitmap[grp] = word;
+            }
         } else if (res) {
-            atomicOr((unsigned long long *)&a.bitmap[my_row >> 6], 1ull << (my_row & 63));
+            __hip_atomic_fetch_or(&a.bitmap[my_row >> 6], 1ull << (my_row & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (a.end_state && row_ok) a.end_state[my_row] = st; // (speculative stripes, table modes only: the state at the stripe's end)
         if (OP != OP_FIND) return;
@@ -441,12 +452,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         snap_pi = 1 << 24; // (beyond any real piece) nothing of the row's earlier text is held: indexBackwards reads it from memory
         snapB_ok = false;
         carry_ok = false;
-        const uint32_t unit = p_ck / NT;
+        // (free slots gather row 0, unit 0: a valid address whatever the batch -- their stale row / chunk could point anywhere)
+        const uint32_t g_row = in_pool ? p_row : 0u;
+        const uint32_t unit = in_pool ? p_ck / NT : 0u;
         // gather: slot s of the LDS tile = the row of pool lane s
 #pragma unroll
         for (int j = 0; j < G::kInstrs; ++j) {
             const uint32_t slot = (uint32_t)(j * G::kRowsPerInstr) + row_in_instr;
-            const uint32_t srow = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slot << 2), (int)p_row);
+            const uint32_t srow = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slot << 2), (int)g_row);
             const uint32_t sunit = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slot << 2), (int)unit);
             const uint32_t kk = p_in_row ^ (uint32_t)G::swz((int)slot);
             const uint8_t *ptr = a.rows + (uint64_t)srow * a.stride_bytes + (uint64_t)sunit * (NT * CHB) + kk * 16u;
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         }
         p_st = st;
         p_last = last;
-        p_ck += NT;
+        p_ck = in_pool ? p_ck + NT : 0u; // (only rows in the pool advance)
     };
 
     if (g < last_group) {
@@ -584,6 +597,7 @@ static hipError_t launch_m(const ScanArgs &a, bool guard, LaunchShape sh, hipStr
     case MODE_TABLE16: return launch_g<OP, CW, MODE_TABLE16>(a, guard, sh, s);
     case MODE_PAIR: return CW == 1 ? launch_g<OP, 1, MODE_PAIR>(a, guard, sh, s) : hipErrorInvalidValue; // 8-bit rows only
     case MODE_HYBRID: return launch_g<OP, CW, MODE_HYBRID>(a, guard, sh, s);
+    case MODE_SPARSE: return launch_g<OP, CW, MODE_SPARSE>(a, guard, sh, s);
     default: return launch_g<OP, CW, MODE_GLOBAL>(a, guard, sh, s);
     }
 }

@@ -128,6 +128,8 @@ struct Walk {
     uint32_t lane4;     // lane * 4 (byte 0 of the packed-mode F address)
     const uint16_t *gtable; // MODE_GLOBAL / MODE_HYBRID: the whole table in HBM
     uint32_t hot_last;      // MODE_HYBRID: byte offset of the last table entry held in LDS (hot_bytes - 2)
+    uint32_t sp_chains;     // MODE_SPARSE: some state has more than one exception record (wave-uniform)
+    uint32_t sp_pad_ident;  // MODE_SPARSE: PAD is the identity (matches / containedIn) rather than the way to the sink
 };
 
 template <int CW>
@@ -157,6 +159,8 @@ __device__ __forceinline__ uint32_t lookup(const Walk &wk, uint32_t w, bool in_r
             col = lds_u8(or_byte<(2 * K) & 3>(pg, w) + kLdsPages2Table);                // pages hold column * element size
         }
     }
+    // (opaque to the optimiser: else the record-key compare of apply() is narrowed to 16 bits and col re-extended with a v_and per char)
+    if (MODE == MODE_SPARSE) asm("" : "+v"(col));
     if (GUARD) {
         col = in_row ? col : ((MODE == MODE_PAIR && (K & 1)) ? wk.pad_b : wk.pad_e);
         col = before_cursor ? ((MODE == MODE_PAIR && (K & 1)) ? wk.pre_b : wk.pre_e) : col;
@@ -186,6 +190,36 @@ __device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t 
             v = (__lane_id() == (unsigned)l) ? e : v;
         }
         return v;
+    }
+    if (MODE == MODE_SPARSE) {
+        // st = recB << 16 | rowA4 (needle_device.h): the cell of the dense row the state reads (its own, or its default
+        // row's) and the state's first exception record are fetched side by side -- ONE LDS round trip; the record wins when
+        // its key is this char's column * 4.  Dense states point at a dummy record whose key matches nothing: all of them
+        // read one address, which the LDS broadcasts.  col = column * 4.
+        const uint32_t tb = CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off;
+        uint32_t a_addr;
+        asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(a_addr) : "v"(st), "v"(col)); // (st & 0xFFFF) * 4 + col
+        const uint32_t a = lds_u32(a_addr + tb);
+        u32x2 b = lds_u32x2((st >> 16) + tb);
+        bool hit = (b[0] & 0xFFFFu) == col;
+        uint32_t nxt = hit ? b[1] : a;
+        // States with two or three exceptions chain their records (the key's dword carries the next record's address in
+        // its high half): rare lanes, but the test sits on every char's dependent chain, so it is kept to one VALU compare
+        // and two scalar ops -- lane masks straight from the compares (a ballot of the combined predicate costs two more
+        // VALU ops), no flag test in front of it (programs without chains simply never branch).
+        const uint64_t chained = __builtin_amdgcn_uicmp(b[0], 0xFFFFu, 34 /* ugt */) & ~__builtin_amdgcn_uicmp(b[0] & 0xFFFFu, col, 32 /* eq */);
+        if (__builtin_expect(chained != 0ull, 0)) {
+            bool more = (chained >> __lane_id()) & 1ull;
+            do {
+                if (more) {
+                    b = lds_u32x2((b[0] >> 16) + tb);
+                    hit = (b[0] & 0xFFFFu) == col;
+                    nxt = hit ? b[1] : nxt;
+                    more = !hit && b[0] > 0xFFFFu;
+                }
+            } while (__ballot(more) != 0ull);
+        }
+        return nxt;
     }
     const uint32_t i = __umul24(st, wk.ncols_e) + col;
     if (MODE == MODE_GLOBAL) return wk.gtable[i];
@@ -244,6 +278,10 @@ __device__ __forceinline__ void piece_lookups(const Walk &wk, const uint32_t (&w
             }
 #undef NEEDLE_PG
 #undef NEEDLE_CE
+            if (MODE == MODE_SPARSE) {
+#pragma unroll
+                for (int i = 0; i < CPP; ++i) asm("" : "+v"(col[i]));
+            }
             if (GUARD) {
 #pragma unroll
                 for (int i = 0; i < CPP; ++i) {
@@ -328,6 +366,11 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
     } else
 #pragma unroll
     for (int i = 0; i < CPP; ++i) {
+        if (MODE == MODE_SPARSE && GUARD) { // PAD / PRE are not columns of this mode: selected after the lookup
+            uint32_t ns = apply<MODE, CW>(wk, st, col[i]);
+            ns = (p0 + i < rem) ? ns : (wk.sp_pad_ident ? st : 0u);
+            st = (p0 + i < skip) ? st : ns;
+        } else
         st = apply<MODE, CW>(wk, st, col[i]);
         if (OP == OP_FIND) {
             bool acc = st >= accept_lo;

@@ -48,7 +48,10 @@ class MultiDevice:
         if op == "find":
             st = torch.empty(total, dtype=torch.int32, device=root)
             en = torch.empty(total, dtype=torch.int32, device=root)
-        torch.cuda.synchronize()  # the shards were produced on torch's streams; the library runs on its own
+        # the shards were produced on torch's streams of THEIR devices; the library reads them on its own (non-blocking)
+        # streams: every device involved has to be idle first (torch.cuda.synchronize() alone waits for the current one)
+        for d in sorted(set(self.devices)):
+            torch.cuda.synchronize(d)
         _check(_lib.lib().needle_multi_scan(self._h, pattern._h, OPS[op], views, words.data_ptr(),
                                             st.data_ptr() if st is not None else None, en.data_ptr() if en is not None else None))
         _check(_lib.lib().needle_multi_sync(self._h))

@@ -177,6 +177,12 @@ class Pattern:
                 "fixed_len": i.fixed_len, "min_len": i.min_len, "max_len": i.max_len,
                 "kernel_mode": dict(zip(WHICH, i.kernel_mode))}
 
+    def program_info(self, which="forwards", char_width=1, with_backward=True):
+        """How one automaton is lowered for the device (host-side diagnostics: needs no GPU)."""
+        i = _lib.ProgramInfo()
+        _check(_lib.lib().needle_pattern_program_info(self._h, list(WHICH).index(which), char_width, int(with_backward), ctypes.byref(i)))
+        return {k: getattr(i, k) for k, _ in i._fields_}
+
     def tables(self):
         """The pattern's tables in the reference layout (class map, stride, 4 x (table, accepting, max_char))."""
         inf = self.info()
@@ -374,9 +380,14 @@ class Pattern:
         import torch
         v = self._dev_view(rows, lengths)
         n = rows.shape[0]
-        with torch.cuda.device(rows.device):
-            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
-            counts = self.count_matches_batch(rows, lengths, stream)
+        # the count pass, the prefix sum (torch) and the fill pass all run on ONE stream: a caller-supplied raw stream is made
+        # torch's current stream for the torch ops in between (else the cumsum could read counts the count kernel has not
+        # written yet, and the fill pass offsets the cumsum has not)
+        dev = rows.device
+        one = torch.cuda.current_stream(dev) if stream is None else torch.cuda.ExternalStream(stream, device=dev)
+        with torch.cuda.device(dev), torch.cuda.stream(one):
+            s = one.cuda_stream
+            counts = self.count_matches_batch(rows, lengths, s)
             offsets = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)
             torch.cumsum(counts, 0, out=offsets[1:])
             total = int(offsets[-1].item())

@@ -17,6 +17,9 @@ import torch
 import torch.distributed as dist
 
 
+PACK16_MAX_ROW_LEN = 65534  # needle_pack_start_end16_dev: offsets 0 .. 65534 fit a half word, 0xFFFF is "no match"
+
+
 def shard_range(total_rows, world, rank):
     """Contiguous row block of `rank`; block boundaries are multiples of 64 rows so that every shard's bitmap is
     whole uint64 words.  -> (row0, n_rows)"""
@@ -140,7 +143,8 @@ class ShardedScan:
     ~0.1 ms; three separately issued collectives cost the host more than that).  `n_buffers` result sets rotate so that
     step k + 1 may scan while the gather of step k is still in flight."""
 
-    def __init__(self, scan, total_rows, world, rank, is_find, device, n_buffers=2, comm=None, overlap=None, pack16=False):
+    def __init__(self, scan, total_rows, world, rank, is_find, device, n_buffers=2, comm=None, overlap=None, pack16=False,
+                 max_row_len=None):
         """comm: a needle_amd.multi.RankComm -- the gather is then ONE call into the library's own RCCL communicator (GPU
         runs); without it the gather goes through torch.distributed (any backend: the gloo tests).
         overlap (with comm): issue the gather on a side stream so that the next scan runs beside it.  That costs two
@@ -149,8 +153,10 @@ class ShardedScan:
         against 101 us -- so the default is the scan's own stream."""
         self.scan, self.total_rows, self.world, self.rank, self.is_find = scan, total_rows, world, rank, is_find
         self.comm, self.side = comm, None
-        # pack16 (find, rows of at most 65 534 chars: the caller's promise): start / end cross the links as one dword per row
-        self.pack16 = bool(pack16) and is_find
+        # pack16 (find): start / end cross the links as one dword per row, two 16-bit halves with 0xFFFF = no match -- exact
+        # only for rows of at most 65 534 chars (an end of 65 535 would read as "no match", longer offsets would be cut).
+        # The caller states the longest row (max_row_len); longer rows, or no statement at all, keep the 8-byte form.
+        self.pack16 = bool(pack16) and is_find and max_row_len is not None and int(max_row_len) <= PACK16_MAX_ROW_LEN
         self.overlap = bool(overlap)
         if comm is not None and self.overlap:
             self.side = torch.cuda.Stream(device=device)

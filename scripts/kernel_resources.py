@@ -5,7 +5,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "needle_amd", "csrc")
 names = {"0": "matches", "1": "containedIn", "2": "find"}
-modes = {"0": "pack", "1": "table8", "2": "table16", "3": "hbm", "4": "pair", "5": "hot-rows"}
+modes = {"0": "pack", "1": "table8", "2": "table16", "3": "hbm", "4": "pair", "5": "hot-rows", "6": "sparse"}
 procs = []
 tmp = tempfile.mkdtemp()
 for tu in ("needle_scan_matches", "needle_scan_contained", "needle_scan_find1", "needle_scan_find2"):

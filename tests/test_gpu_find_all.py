@@ -194,3 +194,33 @@ def test_every_match_in_rows_beyond_16_bit_indices():
         assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == want[i]
     c2, s2, e2, more2 = p.find_all_dense(t, 5)
     assert more2 and (c2.cpu().numpy() == 5).all() and (s2.cpu().numpy() == st[:, :5]).all() and (e2.cpu().numpy() == en[:, :5]).all()
+
+
+DENSE_HOST = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from needle_amd.pattern import DFACompiler
+from test_compile_matches_txt import oracle_for
+# a one-char pattern over rows of that char class: ~stride matches per row, i.e. results several times the row bytes
+p = DFACompiler.compile("[a-f]", "t", 0)
+o, _ = oracle_for("[a-f]", 0)
+rng = np.random.default_rng(5)
+n, stride = 3000, 96
+rows = rng.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=(n, stride))
+offs, st, en = p.find_all_csr(rows)               # needle_find_all_csr_host: the fill pass in sub-ranges of rows
+want = [o.find_all(rows[i]) for i in range(0, n, 37)]
+assert offs[-1] == len(st) == len(en) and offs[-1] > 4 * n * 8  # > 8 KiB budget many times over
+for k, i in enumerate(range(0, n, 37)):
+    assert list(zip(st[offs[i]:offs[i + 1]].tolist(), en[offs[i]:offs[i + 1]].tolist())) == want[k], i
+assert (en - st == 1).all() and (np.diff(offs) == (rows < ord("g")).sum(1)).all()
+print("DENSE-HOST-OK")
+'''
+
+
+@pytest.mark.gpu
+def test_csr_host_dense_matches_bounded_results():
+    """needle_find_all_csr_host on a dense-match batch with the device-resident result budget shrunk to 8 KiB: the fill pass
+    runs over many sub-ranges of the chunk's rows and the pieces line up (ADVICE round 2: results were unbounded)."""
+    env = dict(os.environ, NEEDLE_HOST_RESULT_BYTES="8192")
+    r = subprocess.run([sys.executable, "-c", DENSE_HOST], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert "DENSE-HOST-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

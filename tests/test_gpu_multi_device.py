@@ -131,7 +131,7 @@ def test_sharded_scan_step_through_the_library_communicator():
         torch.cuda.synchronize()
         assert (unpack_bitmap(bm, total) == m).all() and (st.cpu().numpy() == s).all() and (en.cpu().numpy() == e).all()
     # start / end packed to one dword per row before the gather (the pack / unpack kernels of the library)
-    shp = ShardedScan(lambda bm, st, en: p.find_batch(rows, out=(bm, st, en)), total, 1, 0, True, torch.device("cuda", 0), comm=comm, pack16=True)
+    shp = ShardedScan(lambda bm, st, en: p.find_batch(rows, out=(bm, st, en)), total, 1, 0, True, torch.device("cuda", 0), comm=comm, pack16=True, max_row_len=rows.shape[1])
     sp = shp.step()
     assert sp["buf"].numel() == shp.per_rows + 2 * shp.per_words
     bm, st, en = shp.wait(sp)
@@ -170,3 +170,9 @@ def test_bench_two_ranks_on_one_gpu(workload):
     assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["config"]["rows_total"] == 200000 and d2["config"]["rows_per_gpu"] == 100032
     assert abs(d2["matched_fraction"] - d1["matched_fraction"]) < 1e-12
     assert d2["scan_ms"] > 0 and "gather_ms" in d2 and d2["gather"]["issued_by"] == "torch.distributed"
+    # the gather is checked against what the ranks computed (popcount of the gathered bitmap; find: a position-weighted
+    # checksum of the gathered start / end) -- a mis-ordered gather must not print a clean line
+    assert d2["gather_verified"] is True and d2["gather_check"]["popcount_gathered"] == d2["gather_check"]["popcount_ranks"]
+    if d2["config"]["result"].startswith("bitmap+start/end"):
+        assert d2["gather_check"]["checksum_gathered"] == d2["gather_check"]["checksum_ranks"]
+    assert "gather_verified" not in d1 and d1["cold"]["ms_per_step"] > 0 and d1["steady"]["steps_effective"] >= 3

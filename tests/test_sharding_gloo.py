@@ -60,9 +60,13 @@ def _worker(rank, world, port, total_rows, q):
         else:
             assert full is None and st is None and en is None
         # the same step with start / end travelling as one dword per row (two 16-bit halves, 0xFFFF = -1)
-        shp = ShardedScan(scan, total_rows, world, rank, True, "cpu", n_buffers=2, pack16=True)
+        shp = ShardedScan(scan, total_rows, world, rank, True, "cpu", n_buffers=2, pack16=True, max_row_len=rows.shape[1] if n else 256)
+        assert shp.pack16
         sp = shp.step()
         assert sp["buf"].numel() == shp.per_rows + 2 * shp.per_words  # half the start / end bytes on the wire
+        # rows the halves cannot hold (or no stated length at all) keep the 8-byte form instead of truncating silently
+        assert not ShardedScan(scan, total_rows, world, rank, True, "cpu", pack16=True, max_row_len=65535).pack16
+        assert not ShardedScan(scan, total_rows, world, rank, True, "cpu", pack16=True).pack16
         fullp, stp, enp = shp.wait(sp)
         if rank == 0:
             assert (fullp == full).all() and (stp == st).all() and (enp == en).all()
@@ -79,6 +83,27 @@ def _worker(rank, world, port, total_rows, q):
         full_c, _, _ = shc.wait(shc.step())
         assert (full_c == gather_bitmap(_pack(bits), total_rows, world, rank)).all()
         _, _, e = o.batch_find(rows) if n else (None, None, np.zeros(0, np.int32))
+        # bench.py's self-check of an N > 1 run (popcount of the gathered bitmap, position-weighted checksum of the gathered
+        # start / end against what the ranks computed): passes on the real gather, trips on a gather that delivers the
+        # shards in the wrong order
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import verify_gather
+        for find_op, step_obj in ((True, sh), (True, shp), (False, shc)):
+            chk = verify_gather(step_obj, "cpu", row0, n, total_rows, find_op, rank)
+            assert chk["ok"] and chk["popcount_gathered" if (rank == 0 or not find_op) else "popcount_ranks"] == chk["popcount_ranks"]
+        if world > 1 and total_rows > 64 * world:
+            real_wait = sh.wait
+
+            def swapped(s_):  # rank 0 sees the shards' rows rotated by one shard
+                f, a, b = real_wait(s_)
+                if a is None:
+                    return f, a, b
+                k = sh.per_rows
+                return f, torch.roll(a, k), torch.roll(b, k)
+            sh.wait = swapped
+            assert not verify_gather(sh, "cpu", row0, n, total_rows, True, rank)["ok"]
+            sh.wait = real_wait
         ends_all = gather_rows(torch.from_numpy(e.astype(np.int32)), total_rows, world, rank)
         if rank == 0:
             assert (ends_all == en).all()
