@@ -10,14 +10,14 @@ NEEDLE_OK, ERR_INVALID, ERR_SYNTAX, ERR_COMPILE, ERR_UNSUPPORTED, ERR_DEVICE = 0
 
 EXPORTS = [
     "needle_version", "needle_last_error", "needle_device_count", "needle_compile", "needle_pattern_from_tables",
-    "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_program_info", "needle_pattern_get_class_map", "needle_pattern_get_table",
+    "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_program_info", "needle_pattern_match_lengths", "needle_pattern_get_class_map", "needle_pattern_get_table",
     "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_find_next_dev", "needle_find_all_dev", "needle_count_matches_dev", "needle_find_all_csr_dev", "needle_find_all_host", "needle_find_all_csr_host",
     "needle_pack_start_end16_dev", "needle_unpack_start_end16_dev", "needle_matches_host",
-    "needle_contained_in_host", "needle_find_host", "needle_matcher_create", "needle_matcher_destroy",
+    "needle_contained_in_host", "needle_find_host", "needle_find_compact_dev", "needle_find_compact_host", "needle_find_packed16_host", "needle_matcher_create", "needle_matcher_destroy",
     "needle_matcher_matches", "needle_matcher_contained_in", "needle_matcher_find", "needle_matcher_find_range",
     "needle_matcher_start", "needle_matcher_end", "needle_rows_from_packed_dev", "needle_matches_packed_host",
     "needle_contained_in_packed_host", "needle_find_packed_host",
-    "needle_multi_create", "needle_multi_destroy", "needle_multi_device_count", "needle_multi_stream", "needle_multi_scan",
+    "needle_multi_create", "needle_multi_destroy", "needle_multi_device_count", "needle_multi_stream", "needle_multi_transport", "needle_multi_scan",
     "needle_multi_sync", "needle_scan_host_multi", "needle_multi_unique_id", "needle_multi_create_rank",
     "needle_multi_all_gather_u64", "needle_multi_gather_i32",
 ]
@@ -84,6 +84,7 @@ def lib():
     L.needle_pattern_serialize.argtypes = [VP, VP, ctypes.c_size_t, P(ctypes.c_size_t)]
     L.needle_pattern_deserialize.argtypes = [VP, ctypes.c_size_t, P(VP)]
     L.needle_pattern_get_info.argtypes = [VP, P(PatternInfo)]
+    L.needle_pattern_match_lengths.argtypes = [VP, P(ctypes.c_int32), P(ctypes.c_int32), P(ctypes.c_int32), P(ctypes.c_int32), VP, VP, VP]
     L.needle_pattern_program_info.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, P(ProgramInfo)]
     L.needle_pattern_get_class_map.argtypes = [VP, VP]
     L.needle_pattern_get_table.argtypes = [VP, I, VP, VP]
@@ -101,6 +102,9 @@ def lib():
     for n in ("needle_matches_host", "needle_contained_in_host"):
         getattr(L, n).argtypes = [VP, P(BatchView), VP]
     L.needle_find_host.argtypes = [VP, P(BatchView), VP, VP, VP]
+    L.needle_find_compact_dev.argtypes = [VP, P(BatchView), VP, VP, ctypes.c_uint64, VP, VP]
+    L.needle_find_compact_host.argtypes = [VP, P(BatchView), VP, VP, ctypes.c_uint64, P(ctypes.c_uint64)]
+    L.needle_find_packed16_host.argtypes = [VP, P(BatchView), VP, VP]
     L.needle_rows_from_packed_dev.argtypes = [P(PackedView), VP, ctypes.c_uint64, VP, VP, VP]
     for n in ("needle_matches_packed_host", "needle_contained_in_packed_host"):
         getattr(L, n).argtypes = [VP, P(PackedView), VP]
@@ -119,6 +123,8 @@ def lib():
     L.needle_multi_device_count.argtypes = [VP]
     L.needle_multi_stream.argtypes = [VP, I]
     L.needle_multi_stream.restype = VP
+    L.needle_multi_transport.argtypes = [VP]
+    L.needle_multi_transport.restype = ctypes.c_char_p
     L.needle_multi_scan.argtypes = [VP, VP, I, P(BatchView), VP, VP, VP]
     L.needle_multi_sync.argtypes = [VP]
     L.needle_scan_host_multi.argtypes = [VP, VP, I, P(BatchView), VP, VP, VP]

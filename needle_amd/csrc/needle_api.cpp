@@ -45,6 +45,44 @@ namespace needle {
 int set_error(int code, const std::string &msg) { return fail(code, msg); } // (needle_multi.cpp reports through the same channel)
 } // namespace needle
 
+// Stream-ordered scratch memory comes from a pool of the library's own, one per device, that KEEPS what it is given back:
+// HIP's default pool returns freed memory to the driver at the next synchronisation point (release threshold 0), so a
+// caller that synchronises after every call would pay a fresh driver allocation of tens of megabytes per call
+// (needle_find_compact_dev: 2.5 ms per step on a 10M-row batch before this).
+namespace needle {
+hipError_t scratch_malloc(void **out, size_t bytes, hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<int, hipMemPool_t> pools;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemPool_t pool = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = pools.find(dev);
+        if (it == pools.end()) {
+            hipMemPoolProps props;
+            memset(&props, 0, sizeof(props));
+            props.allocType = hipMemAllocationTypePinned;
+            props.handleTypes = hipMemHandleTypeNone;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
+                uint64_t keep = UINT64_MAX;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            } else {
+                (void)hipGetLastError();
+                pool = nullptr; // (no pool of our own: the device's default one)
+            }
+            it = pools.emplace(dev, pool).first;
+        }
+        pool = it->second;
+    }
+    return pool ? hipMallocFromPoolAsync(out, bytes, pool, stream) : hipMallocAsync(out, bytes, stream);
+}
+hipError_t scratch_free(void *p, hipStream_t stream) { return hipFreeAsync(p, stream); }
+} // namespace needle
+
 static int hip_fail(hipError_t e, const char *what) {
     return fail(NEEDLE_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -67,8 +105,11 @@ struct needle_pattern {
     // variant: 0 plain, 1 global-walk layout (backward automaton of find), 2 forward + backward column maps,
     //          3 HBM-table layout forced (column maps + uint16 table in one blob: the speculative-stripe fix-up walks it)
     //          4 / 5 as 0 / 2 without the pair table (the one-pass find-all kernel)
+    //          6 the find-all "lengths" automaton (W_FORWARDS only; absent when the pattern does not allow it)
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
+    int ml_state = 0;       // 0: not analysed yet, 1: find-all can report starts as end - length (ml), -1: it cannot
+    MatchLengths ml;
     ~needle_pattern() {
         for (auto &kv : cache)
             if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
@@ -95,6 +136,22 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
+        if (variant == 6) { // find-all, "lengths" form: the refined forward automaton + pend[] (needle_lower.h)
+            if (p->ml_state == 0) {
+                p->ml = match_length_automaton(p->t);
+                p->ml_state = p->ml.ok ? 1 : -1;
+            }
+            if (p->ml_state < 0) {
+                *out = nullptr;
+                return NEEDLE_OK;
+            }
+            dp.prog = lower_match_lengths(p->t, p->ml, cw, max_prog_lds());
+            if (dp.prog.blob.empty()) { // (does not fit the LDS as a plain table: the ordinary program with backward walks)
+                p->cache.emplace(key, DevProgram());
+                *out = nullptr;
+                return NEEDLE_OK;
+            }
+        } else
         dp.prog = lower(p->t, (Which)which, cw, variant == 3 ? 0 : max_prog_lds(), variant == 1, variant == 2 || variant == 5, variant >= 4);
         HIP_TRY(hipMalloc((void **)&dp.d_blob, dp.prog.blob.size()));
         if (hipError_t ce = hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice); ce != hipSuccess) {
@@ -103,7 +160,7 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
         }
         it = p->cache.emplace(key, std::move(dp)).first;
     }
-    *out = &it->second;
+    *out = it->second.d_blob ? &it->second : nullptr; // (variant 6: an empty entry = "not available for this pattern / width")
     return NEEDLE_OK;
 }
 
@@ -169,9 +226,9 @@ static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v
             sa.bhdr = bp->prog.hdr;
         }
     }
-    HIP_TRY(hipMallocAsync((void **)&sa.fn, (size_t)sa.n_rows * sa.spr * 4, (hipStream_t)stream));
+    HIP_TRY(scratch_malloc((void **)&sa.fn, (size_t)sa.n_rows * sa.spr * 4, (hipStream_t)stream));
     hipError_t e = launch_long_rows((int)v->char_width, sa, n_cus, (hipStream_t)stream);
-    (void)hipFreeAsync(sa.fn, (hipStream_t)stream);
+    (void)scratch_free(sa.fn, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "launch_long_rows");
     return NEEDLE_OK;
 }
@@ -220,9 +277,9 @@ static int run_speculative_stripes(needle_pattern *p, int op, const needle_batch
     // slen | spec_end_state | spec_last | spec_start(unused) | entry | entry_done | true_end_state | true_last  (4 B each), bitmap, flag
     uint8_t *tmp = nullptr;
     const size_t o_bm = 8 * ns * 4, o_flag = o_bm + words * 8, total = o_flag + 16;
-    HIP_TRY(hipMallocAsync((void **)&tmp, total, stream));
+    HIP_TRY(scratch_malloc((void **)&tmp, total, stream));
     auto finish = [&](int code) {
-        (void)hipFreeAsync(tmp, stream);
+        (void)scratch_free(tmp, stream);
         return code;
     };
     uint32_t *u = (uint32_t *)tmp;
@@ -844,6 +901,35 @@ int needle_pattern_program_info(const needle_pattern *p, int which, int char_wid
     return NEEDLE_OK;
 }
 
+// The find-all "lengths" automaton (needle_lower.h), for inspection and CPU-side tests: 1 in *available when the pattern
+// allows it.  table: n_states * (stride + 1) int16 (reference layout + one column for chars beyond *max_char, -1 = dead);
+// accepting, pend: n_states bytes each.
+int needle_pattern_match_lengths(const needle_pattern *cp, int32_t *available, int32_t *n_states, int32_t *n_dead, int32_t *max_char,
+                                 int16_t *table, uint8_t *accepting, uint8_t *pend) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p || !available) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->ml_state == 0) {
+        p->ml = match_length_automaton(p->t);
+        p->ml_state = p->ml.ok ? 1 : -1;
+    }
+    *available = p->ml_state > 0 ? 1 : 0;
+    if (!*available) return NEEDLE_OK;
+    if (n_states) *n_states = p->ml.dfa.n_states;
+    if (n_dead) *n_dead = p->ml.n_dead;
+    if (max_char) *max_char = p->ml.dfa.max_char;
+    if (table) {
+        const int N = p->t.stride;
+        for (int s = 0; s < p->ml.dfa.n_states; ++s) {
+            memcpy(table + (size_t)s * (N + 1), &p->ml.dfa.table[(size_t)s * N], (size_t)N * 2);
+            table[(size_t)s * (N + 1) + N] = p->ml.over[s];
+        }
+    }
+    if (accepting) memcpy(accepting, p->ml.dfa.accepting.data(), p->ml.dfa.accepting.size());
+    if (pend) memcpy(pend, p->ml.pend.data(), p->ml.pend.size());
+    return NEEDLE_OK;
+}
+
 int needle_pattern_get_class_map(const needle_pattern *p, uint8_t *cm) {
     if (!p || !cm) return fail(NEEDLE_ERR_INVALID, "NULL argument");
     memcpy(cm, p->t.class_map.data(), 65536);
@@ -960,9 +1046,9 @@ static int find_all_rounds(const needle_pattern *p, const needle_batch_view *v, 
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     uint8_t *tmp = nullptr; // cursor | start | end (int32 each) | bitmap | any-hit flag
     const size_t o_cur = 0, o_s = n * 4, o_e = 2 * n * 4, o_bm = (3 * n * 4 + 15) & ~(size_t)15, o_flag = o_bm + words * 8;
-    HIP_TRY(hipMallocAsync((void **)&tmp, o_flag + 16, stream));
+    HIP_TRY(scratch_malloc((void **)&tmp, o_flag + 16, stream));
     auto done = [&](int code) {
-        (void)hipFreeAsync(tmp, stream);
+        (void)scratch_free(tmp, stream);
         return code;
     };
     if (hipMemsetAsync(tmp + o_cur, 0, n * 4, stream) != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));
@@ -995,8 +1081,19 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     if (stride_bytes >= (1ull << 26)) return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more: only needle_find_all_dev (round per match) takes them");
     const DevProgram *fp = nullptr, *bp = nullptr;
     int n_cus = 0;
-    const bool need_backward = p->t.fixed_len < 0;
-    int rc = get_program(p, W_FORWARDS, (int)v->char_width, need_backward ? 5 : 4, &fp, &n_cus);
+    bool need_backward = p->t.fixed_len < 0;
+    int rc = NEEDLE_OK;
+    // start = end - (the match length the automaton's end state remembers): no backward walks at all, when the pattern
+    // allows it (needle_lower.h: keyword unions and the like).  NEEDLE_FIND_ALL_LENGTHS=0: off (A/B, tests).
+    static const bool lengths_on = !(getenv("NEEDLE_FIND_ALL_LENGTHS") && atoi(getenv("NEEDLE_FIND_ALL_LENGTHS")) == 0);
+    bool lmode = false;
+    if (need_backward && lengths_on && !count_only) {
+        rc = get_program(p, W_FORWARDS, (int)v->char_width, 6, &fp, &n_cus);
+        if (rc) return rc;
+        lmode = fp != nullptr;
+        if (lmode) need_backward = false;
+    }
+    if (!lmode) rc = get_program(p, W_FORWARDS, (int)v->char_width, need_backward ? 5 : 4, &fp, &n_cus);
     if (rc) return rc;
     FindAllArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -1010,6 +1107,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     a.prog = fp->d_blob;
     a.hdr = fp->prog.hdr;
     a.fixed_len = p->t.fixed_len;
+    fa.lmode = lmode ? 1u : 0u;
     if (need_backward) {
         rc = get_program(p, W_BACKWARDS, (int)v->char_width, 1, &bp, nullptr);
         if (rc) return rc;
@@ -1020,7 +1118,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     fa.offsets = d_offsets;
     fa.count_only = count_only ? 1u : 0u;
     static const bool no_defer = getenv("NEEDLE_FIND_ALL_DEFER") && atoi(getenv("NEEDLE_FIND_ALL_DEFER")) == 0; // A/B, tests
-    fa.defer = (a.fixed_len < 0 && !a.hdr.root_accepting && !no_defer) ? 1u : 0u;
+    fa.defer = (a.fixed_len < 0 && !a.hdr.root_accepting && !no_defer && !lmode) ? 1u : 0u;
 #ifdef NEEDLE_TUNING // measurement builds only: start = the search cursor (wrong answers; never in the shipping library)
     static const bool dbg_no_backward = getenv("NEEDLE_DEBUG_NO_BACKWARD") != nullptr;
     if (fa.defer && dbg_no_backward) fa.defer = 2;
@@ -1029,9 +1127,9 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     fa.starts = d_start;
     fa.ends = d_end;
     int32_t *d_more = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&d_more, 16, stream));
+    HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
     auto done = [&](int code) {
-        (void)hipFreeAsync(d_more, stream);
+        (void)scratch_free(d_more, stream);
         return code;
     };
     if (hipMemsetAsync(d_more, 0, 4, stream) != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync"));

@@ -84,6 +84,9 @@ struct ProgHeader {
     uint32_t sp_chains;    // some state needs more than one record: the walk loops while a lane's record has a successor
     uint32_t sp_pad_ident; // PAD (chars past the row's length) is the identity (matches / containedIn) or leads to the sink
     uint32_t sp_dense, sp_records; // statistics: dense rows (without the sink), records (without the two dummies)
+    // find-all "lengths" form (needle_lower.h, MatchLengths): pend[] by device state in LDS; the dead-with-a-pending-match
+    // states are the device ids fa_dead_lo .. fa_dead_lo + fa_dead_n - 1
+    uint32_t fa_len_off, fa_dead_lo, fa_dead_n;
     uint32_t off_bpack;  // != 0: the backward automaton has <= 5 states and rides along as packed functions: 8-bit rows
                          // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)
                          // followed by its F area.  The backward walk then needs no state-dependent lookup.

@@ -40,13 +40,19 @@ namespace needle {
 // that piece whatever its state is, and the caller masks their accept flags.  Accept flags are LOGGED, one shift per
 // char (walk_piece selects a position per char: three VALU ops in a walk that is issue-bound under its guards):
 // returns the flags of the piece's chars, char i at bit i.
-template <int CW, int MODE>
+// CUT (the "lengths" form on the piece a ragged row ends in): chars from in_row on take the PAD column, which there leads
+// to the dead state that remembers the pending match -- the state the piece ends in is then the one the ROW ends in.
+template <int CW, int MODE, bool CUT = false>
 __device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t (&w)[4], uint32_t skip_rel, uint32_t accept_lo,
-                                                  uint32_t &st) {
+                                                  uint32_t &st, uint32_t in_row = 0) {
     constexpr int CPP = 16 / CW;
     uint32_t col[CPP];
     piece_lookups<MODE, CW, false>(wk, w, 0, 0, 0, col);
     if (MODE == MODE_PACK) lds_fence();
+    if (CUT) {
+#pragma unroll
+        for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < in_row) ? col[i] : wk.pad_e;
+    }
 #pragma unroll
     for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < skip_rel) ? wk.pre_e : col[i];
     uint32_t h = 0;
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             }
             const uint32_t w[4] = {v[0], v[1], v[2], v[3]}; // (a piece beyond the row: whatever is there -- its flags are masked)
             const uint32_t skip_rel = (uint32_t)cursor > p0 ? (uint32_t)cursor - p0 : 0u; // < CPP: the cursor's piece, or none
+            const uint32_t st_old = st;
             uint32_t st_new = st;
             uint32_t acc = walk_piece_fa<CW, MODE>(wk, w, skip_rel, accept_lo, st_new);
             const uint32_t in_row = len > p0 ? len - p0 : 0u; // chars of the piece inside the row (all, if >= CPP)
@@ -294,14 +301,42 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             acc = active ? acc : 0u;
             last = acc ? (int32_t)(p0 + 32u - (uint32_t)__builtin_clz(acc)) : last;
             st = active ? st_new : st;
-            const bool ended = active && (st_new == 0u || p0 + CPP >= len);
+            // (fa_dead_n: the "lengths" automaton's dead-with-a-match-pending states; 0 for every other program)
+            const bool ended = active && (st_new == 0u || st_new - a.hdr.fa_dead_lo < a.hdr.fa_dead_n || p0 + CPP >= len);
             pi += (active && !ended) ? 1u : 0u;
             if (__ballot(ended) == 0ull) continue;
             // ---- find() returns for the lanes of `ended` (:629-657)
             const bool hit = ended && last >= 0;
             const int32_t en = last;
             if (ended && !hit) done = true; // no further match in this row
-            if (fa.defer) {
+            if (fa.lmode) {
+                // The "lengths" automaton (needle_lower.h): the state the search ended in remembers how long its last match
+                // was -- start = end - pend[state], no indexBackwards (DFAClassBuilder.java:640-646 generalised per state).
+                // A ragged row that ends INSIDE this piece was walked past its end above (harmless for the flags, which are
+                // masked, but not for the state): that piece is walked again from its entry state with the PAD column.
+                uint32_t st_end = st_new;
+                if (MODE == MODE_TABLE8 || MODE == MODE_TABLE16) { // (the only modes such a program has)
+                    const bool cut = hit && in_row < (uint32_t)CPP;
+                    if (__ballot(cut) != 0ull) {
+                        uint32_t st_fix = st_old;
+                        (void)walk_piece_fa<CW, MODE, true>(wk, w, skip_rel, accept_lo, st_fix, in_row);
+                        st_end = cut ? st_fix : st_end;
+                    }
+                }
+                const int32_t mlen = (int32_t)lds_u8(a.hdr.fa_len_off + st_end);
+                const bool file = hit && count < cap;
+                if (hit && !file) *fa.more = 1;
+                done = done || (hit && !file);
+                if (file && !fa.count_only) {
+                    fa.starts[out0 + count] = en - mlen;
+                    fa.ends[out0 + count] = en;
+                }
+                count += file ? 1u : 0u;
+                cursor = file ? en : cursor;
+                st = file ? start_state : st;
+                last = file ? -1 : last;
+                pi = file ? (((uint32_t)en * CW) >> 4) : pi;
+            } else if (fa.defer) {
                 // not nullable, start by indexBackwards: the match is not empty and ends beyond its cursor -- the row goes on.
                 // Written as selects, not branches: this block runs in most iterations (some lane of 64 has just resolved)
                 // and every divergent branch costs a copy of the loop-carried lane state per path.

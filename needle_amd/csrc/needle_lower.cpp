@@ -11,6 +11,7 @@
 //   * wasAccepted<X>(state)    -> states renumbered so that accepted(s) == (s >= A0)
 #include "needle_lower.h"
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -718,6 +719,227 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     }
     while (p.blob.size() % 16) p.blob.push_back(0);
     p.hdr.mode = mode;
+    return p;
+}
+
+} // namespace needle
+
+// ---- per-state match lengths for find-all (needle_lower.h) -----------------------------------------------------------
+namespace needle {
+
+MatchLengths match_length_automaton(const RefTables &t) {
+    MatchLengths out;
+    const RefDfa &F = t.dfa[W_FORWARDS], &M = t.dfa[W_MATCHES];
+    const int N = t.stride;
+    if (F.n_states < 1 || M.n_states < 1 || F.accepting[0] || M.accepting[0]) return out; // (empty matches: the immediate form)
+    // the alphabet: what the two automata can tell apart -- (class, beyond F's maxChar, beyond M's maxChar) of some code unit
+    std::vector<std::array<int, 3>> syms;
+    {
+        std::map<std::array<int, 3>, int> seen;
+        for (int c = 0; c < 65536; ++c) {
+            const std::array<int, 3> k = {(int)t.class_map[c], c > F.max_char ? 1 : 0, c > M.max_char ? 1 : 0};
+            if (seen.emplace(k, 0).second) syms.push_back(k);
+        }
+    }
+    const int S = (int)syms.size();
+    auto stepF = [&](int f, const std::array<int, 3> &y) { return y[1] ? -1 : (int)F.table[(size_t)f * N + y[0]]; };
+    auto stepM = [&](int m, const std::array<int, 3> &y) { return y[2] ? -1 : (int)M.table[(size_t)m * N + y[0]]; };
+    // 1. product of the search automaton with the runs of the anchored automaton started at every position since the search
+    // began: a run = (state of M, chars read).  The longest accepting run is what indexBackwards would find.
+    typedef std::vector<uint32_t> Runs; // sorted (m << 8 | age)
+    std::map<std::pair<int, Runs>, int> index;
+    std::vector<std::pair<int, Runs>> prod;
+    std::vector<int> trans; // prod x S
+    std::vector<int> outL;  // match length of an accepting product state, 0 otherwise
+    const size_t kMaxProd = 60000;
+    auto intern = [&](int f, Runs &&r) -> int {
+        auto key = std::make_pair(f, std::move(r));
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        const int id = (int)prod.size();
+        index.emplace(key, id);
+        int L = 0;
+        if (F.accepting[f]) {
+            for (uint32_t x : key.second)
+                if (M.accepting[x >> 8]) L = std::max(L, (int)(x & 255u));
+            if (L == 0) L = -1; // the search automaton accepts but no anchored run does: the two disagree -- give up
+        }
+        outL.push_back(L);
+        prod.push_back(std::move(key));
+        return id;
+    };
+    intern(0, Runs());
+    for (size_t i = 0; i < prod.size(); ++i) {
+        if (prod.size() > kMaxProd) { if (getenv("NEEDLE_ML_DEBUG")) fprintf(stderr, "[ml] product too big\n"); return out; }
+        if (outL[i] < 0) { if (getenv("NEEDLE_ML_DEBUG")) fprintf(stderr, "[ml] F accepts (state %d) without an accepting anchored run\n", prod[i].first); return out; }
+        trans.resize((i + 1) * S, -1);
+        for (int y = 0; y < S; ++y) {
+            const int f = prod[i].first;
+            const int f2 = stepF(f, syms[y]);
+            if (f2 < 0) continue;
+            Runs r;
+            r.reserve(prod[i].second.size() + 1);
+            bool too_old = false;
+            for (uint32_t x : prod[i].second) {
+                const int m2 = stepM((int)(x >> 8), syms[y]);
+                if (m2 < 0) continue;
+                const uint32_t age = (x & 255u) + 1u;
+                if (age > 250u) too_old = true;
+                r.push_back(((uint32_t)m2 << 8) | age);
+            }
+            const int m1 = stepM(0, syms[y]);
+            if (m1 >= 0) r.push_back(((uint32_t)m1 << 8) | 1u);
+            if (too_old || r.size() > 64) { if (getenv("NEEDLE_ML_DEBUG")) fprintf(stderr, "[ml] unbounded runs\n"); return out; } // unbounded match lengths (`[0-9]+`, `a.*b`): keep indexBackwards
+            std::sort(r.begin(), r.end());
+            const int id = intern(f2, std::move(r)); // (may reallocate prod: indices only from here on)
+            trans[i * S + y] = id;
+        }
+    }
+    const int P = (int)prod.size();
+    // 2. Moore minimisation with the match length as output: the smallest automaton whose accepting states each stand for
+    // ONE length (1000 keywords of 3..5 chars: 1401 states -> 1463)
+    std::vector<int> part(P), nxt_part(P);
+    {
+        std::map<int, int> cls;
+        for (int i = 0; i < P; ++i) part[i] = cls.emplace(outL[i], (int)cls.size()).first->second;
+    }
+    for (size_t n_cls = 0;;) {
+        std::map<std::vector<int>, int> sig;
+        std::vector<int> key(S + 1);
+        for (int i = 0; i < P; ++i) {
+            key[0] = part[i];
+            for (int y = 0; y < S; ++y) key[y + 1] = trans[(size_t)i * S + y] < 0 ? -1 : part[trans[(size_t)i * S + y]];
+            nxt_part[i] = sig.emplace(key, (int)sig.size()).first->second;
+        }
+        part.swap(nxt_part);
+        if (sig.size() == n_cls) break;
+        n_cls = sig.size();
+    }
+    int Q = 0;
+    for (int i = 0; i < P; ++i) Q = std::max(Q, part[i] + 1);
+    std::vector<int> rep(Q, -1);
+    for (int i = 0; i < P; ++i)
+        if (rep[part[i]] < 0) rep[part[i]] = i;
+    // 3. remember the last match until the automaton dies: states (q, pending length); deaths with a match pending lead
+    // to D_L.  (Keyword unions: no growth at all -- their accepting states die on every char.)
+    std::vector<int> lens; // distinct match lengths, ascending
+    for (int q = 0; q < Q; ++q)
+        if (outL[rep[q]] > 0) lens.push_back(outL[rep[q]]);
+    std::sort(lens.begin(), lens.end());
+    lens.erase(std::unique(lens.begin(), lens.end()), lens.end());
+    if (lens.empty() || lens.size() > 64) { if (getenv("NEEDLE_ML_DEBUG")) fprintf(stderr, "[ml] lens %zu\n", lens.size()); return out; }
+    const int K = (int)lens.size();
+    auto dead_of = [&](int L) { return 1 + (int)(std::lower_bound(lens.begin(), lens.end(), L) - lens.begin()); };
+    std::map<std::pair<int, int>, int> pidx;
+    std::vector<std::pair<int, int>> pst; // ref states 1 + K ..: (q, pending)
+    auto pin = [&](int q, int pend) -> int {
+        auto it = pidx.find({q, pend});
+        if (it != pidx.end()) return it->second;
+        const int id = (int)pst.size();
+        pidx.emplace(std::make_pair(q, pend), id);
+        pst.push_back({q, pend});
+        return id;
+    };
+    // ref numbering: 0 = start, 1 .. K = D_L, then the other (q, pending) states in discovery order
+    auto ref_of = [&](int pid) { return pid == 0 ? 0 : pid + K; };
+    pin(part[0], 0);
+    std::vector<int16_t> table;
+    for (size_t i = 0; i < pst.size(); ++i) {
+        if (pst.size() + K > 16383) return out; // DFACompiler.checkForOverLongDFAs, DFACompiler.java:76-83
+        const int q = pst[i].first, pend = pst[i].second;
+        // (a class with chars on both sides of a maxChar is two symbols here but ONE table column: representable only if
+        // both symbols lead to the same place -- checked below)
+        std::vector<int> row(N + 1, -2); // the reference classes, then OVER: every char beyond EITHER automaton's maxChar
+        for (int y = 0; y < S; ++y) {
+            const int tq = trans[(size_t)rep[q] * S + y];
+            int tgt;
+            if (tq < 0) tgt = pend ? dead_of(pend) : -1;
+            else {
+                const int q2 = part[tq];
+                const int L2 = outL[rep[q2]];
+                tgt = ref_of(pin(q2, L2 > 0 ? L2 : pend));
+            }
+            int &cell = row[(syms[y][1] || syms[y][2]) ? N : syms[y][0]];
+            if (cell != -2 && cell != tgt) { if (getenv("NEEDLE_ML_DEBUG")) fprintf(stderr, "[ml] column conflict: state (%d,%d) class %d over %d/%d: %d vs %d\n", q, pend, syms[y][0], syms[y][1], syms[y][2], cell, tgt); return out; }
+            cell = tgt;
+        }
+        for (int c = 0; c <= N; ++c) table.push_back((int16_t)(row[c] == -2 ? (pend ? dead_of(pend) : -1) : row[c]));
+    }
+    const int n_ref = 1 + K + (int)pst.size() - 1;
+    out.dfa.n_states = n_ref;
+    out.dfa.max_char = std::min(F.max_char, M.max_char); // chars beyond it take the OVER column: out.over[]
+    out.over.assign(n_ref, (int16_t)-1);
+    out.dfa.table.assign((size_t)n_ref * N, (int16_t)-1);
+    out.dfa.accepting.assign(n_ref, 0);
+    out.pend.assign(n_ref, 0);
+    for (int k = 0; k < K; ++k) { // D_L: absorbing, not accepting
+        for (int c = 0; c < N; ++c) out.dfa.table[(size_t)(1 + k) * N + c] = (int16_t)(1 + k);
+        out.over[1 + k] = (int16_t)(1 + k);
+        out.pend[1 + k] = (uint8_t)lens[k];
+    }
+    for (size_t i = 0; i < pst.size(); ++i) {
+        const int r = ref_of((int)i);
+        for (int c = 0; c < N; ++c) out.dfa.table[(size_t)r * N + c] = table[i * (N + 1) + c];
+        out.over[r] = table[i * (N + 1) + N];
+        const int L = outL[rep[pst[i].first]];
+        out.dfa.accepting[r] = L > 0 ? 1 : 0;
+        out.pend[r] = (uint8_t)(L > 0 ? L : pst[i].second);
+    }
+    out.n_dead = K;
+    out.ok = true;
+    return out;
+}
+
+Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget) {
+    RefTables t2 = t;
+    t2.dfa[W_FORWARDS] = ml.dfa;
+    Program p = lower(t2, W_FORWARDS, char_width, lds_table_budget, false, false, true);
+    if (p.hdr.mode != MODE_TABLE8 && p.hdr.mode != MODE_TABLE16) { // (the other modes number or store states their own way)
+        p.blob.clear();
+        p.hdr.mode = MODE_GLOBAL;
+        return p;
+    }
+    // device ids as lower() hands them out: 0 sink | non-accepting in ref order | accepting in ref order
+    const int n_ref = ml.dfa.n_states, n_cols = (int)p.hdr.n_cols, N = t.stride;
+    std::vector<int> dev(n_ref);
+    int next_id = 1;
+    for (int s = 0; s < n_ref; ++s)
+        if (!ml.dfa.accepting[s]) dev[s] = next_id++;
+    for (int s = 0; s < n_ref; ++s)
+        if (ml.dfa.accepting[s]) dev[s] = next_id++;
+    const uint32_t elem = p.hdr.mode == MODE_TABLE16 ? 2u : 1u;
+    auto put = [&](int s_dev, int col, int v) {
+        const size_t o = p.hdr.off_table + ((size_t)s_dev * n_cols + col) * elem;
+        p.blob[o] = (uint8_t)(v & 255);
+        if (elem == 2) p.blob[o + 1] = (uint8_t)(v >> 8);
+    };
+    // the end of the row (PAD) ends the search like any dying transition: with a match pending it leads to D_L, not to the
+    // sink; OVER (a char beyond the refined automaton's maxChar = the smaller of the two automata's) has a target of its own
+    // per state (lower() sends both to the sink for the index walks)
+    std::vector<uint8_t> pend_dev(n_ref + 1, 0);
+    auto dead_ref = [&](int L) { // ref id of D_L
+        for (int k = 1; k <= ml.n_dead; ++k)
+            if (ml.pend[k] == L) return k;
+        return -1;
+    };
+    for (int s = 0; s < n_ref; ++s) {
+        pend_dev[dev[s]] = ml.pend[s];
+        const int L = ml.pend[s];
+        put(dev[s], N, ml.over[s] < 0 ? 0 : dev[ml.over[s]]); // OVER: beyond the refined automaton's maxChar
+        put(dev[s], N + 1, L ? dev[dead_ref(L)] : 0);         // PAD: the row's end
+    }
+    while (p.blob.size() % 16) p.blob.push_back(0);
+    p.hdr.fa_len_off = (uint32_t)p.blob.size();
+    p.blob.insert(p.blob.end(), pend_dev.begin(), pend_dev.end());
+    while (p.blob.size() % 16) p.blob.push_back(0);
+    p.hdr.lds_bytes = (uint32_t)p.blob.size();
+    p.hdr.fa_dead_lo = (uint32_t)dev[1];
+    p.hdr.fa_dead_n = (uint32_t)ml.n_dead;
+    for (int k = 1; k <= ml.n_dead; ++k)
+        if (dev[k] != dev[1] + (k - 1)) { // (ref states 1 .. K are non-accepting and consecutive: so are their device ids)
+            p.blob.clear();
+            p.hdr.mode = MODE_GLOBAL;
+        }
     return p;
 }
 

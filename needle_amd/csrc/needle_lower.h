@@ -46,4 +46,25 @@ bool validate_tables(const RefTables &t, std::string &err);
 Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
               bool with_backward_maps = false, bool no_pair = false);
 
+// ---- find-all without backward walks (needle_find_all.hip, "lengths" form) -----------------------------------------
+// The reference finds a match's start by walking the reversed automaton back from its end (indexBackwards,
+// DFAClassBuilder.java:529-586) unless the WHOLE pattern has one length (Factorization.canOnlyHaveOneLength, :640-646).
+// Generalised here per STATE: the forward search automaton is refined (a product with the runs of the anchored automaton
+// started at every position, Moore-minimised with the match length as output) until every accepting state stands for ONE
+// match length, and then made to REMEMBER the length of its last match until it dies -- dead states "D_L" instead of the
+// sink.  A find() that ends in state s then reports start = end - pend[s]: no backward walk, no second look at the text.
+// Possible for keyword unions and other patterns whose accepting runs have bounded, state-determined lengths; anything
+// else (an accepting state reachable with two match lengths and no finite refinement, e.g. `[0-9]+`) keeps indexBackwards.
+struct MatchLengths {
+    bool ok = false;
+    RefDfa dfa;                // refined forward search automaton; ref state 0 = start, states 1 .. n_dead = D_L (absorbing)
+    std::vector<uint8_t> pend; // per ref state: the match length a find() ending there reports (0: no match pending)
+    std::vector<int16_t> over; // per ref state: the target on a char beyond dfa.max_char (-1 = dead, nothing pending)
+    int n_dead = 0;
+};
+MatchLengths match_length_automaton(const RefTables &t);
+// The device program of that automaton (table modes only; mode == MODE_GLOBAL with an empty blob when it does not fit the
+// LDS): hdr.fa_len_off = LDS offset of pend[] by DEVICE state, hdr.fa_dead_lo / fa_dead_n = device ids of the D_L states.
+Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget);
+
 } // namespace needle

@@ -100,7 +100,10 @@ struct needle_multi {
         uint8_t *p = nullptr;
         size_t cap = 0;
     };
-    std::vector<Buf> local; // per shard: results of a shard that is not written in place (bitmap | start | end)
+    std::vector<Buf> local; // per shard: results of a shard that is not written in place (bitmap | start | end | packed)
+    Buf root_stage;         // on devices[0]: the peers' packed start / end (one dword per row) before they are unpacked
+    hipEvent_t stage_free = nullptr; // recorded on the root's stream behind the unpack: the next call's pushes wait for it
+    std::string transport_note; // why RCCL is not carrying the gather, if it was wanted
 };
 
 extern "C" {
@@ -135,20 +138,40 @@ int needle_multi_create(const int *devices, int n_devices, unsigned flags, needl
     // RCCL carries the gather between distinct devices (and, for tests of the plumbing on a single GPU, a one-rank
     // communicator sending to itself: NEEDLE_MULTI_LOOPBACK).  Shards that share a device are gathered by copies.
     if ((n_devices > 1 && distinct) || (m->loopback && n_devices == 1)) {
+        // No RCCL (library not loadable, ncclCommInitAll refused, NEEDLE_MULTI_NO_RCCL=1): the gather falls back to
+        // peer-to-peer copies over the same xGMI links (hipMemcpyPeerAsync on each shard's stream) -- a handle is still
+        // made; needle_multi_transport() says which path it took and why.
         std::lock_guard<std::mutex> lk(g_rccl_mu);
         std::string err;
-        if (!g_rccl.load(err)) {
-            needle_multi_destroy(m);
-            return fail(NEEDLE_ERR_DEVICE, err);
+        static const bool no_rccl = getenv("NEEDLE_MULTI_NO_RCCL") && atoi(getenv("NEEDLE_MULTI_NO_RCCL")) != 0;
+        if (no_rccl) {
+            m->transport_note = "NEEDLE_MULTI_NO_RCCL=1";
+        } else if (!g_rccl.load(err)) {
+            m->transport_note = err;
+        } else {
+            m->comm.assign(n_devices, nullptr);
+            const int rc = g_rccl.CommInitAll(m->comm.data(), n_devices, m->dev.data());
+            if (rc != 0) {
+                m->comm.clear();
+                m->transport_note = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc);
+            } else {
+                m->rccl = true;
+            }
         }
-        m->comm.assign(n_devices, nullptr);
-        int rc = g_rccl.CommInitAll(m->comm.data(), n_devices, m->dev.data());
-        if (rc != 0) {
-            m->comm.clear();
+        if (!m->rccl && m->loopback && n_devices == 1) { // (the loopback handle exists to exercise RCCL: without it, fail)
+            const std::string why = m->transport_note;
             needle_multi_destroy(m);
-            return fail(NEEDLE_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc));
+            return fail(NEEDLE_ERR_DEVICE, why);
         }
-        m->rccl = true;
+        if (!m->rccl) // peers write into the root's memory directly when the runtime allows it (else it stages the copies)
+            for (int i = 1; i < n_devices; ++i) {
+                int can = 0;
+                if (m->dev[i] != m->dev[0] && hipDeviceCanAccessPeer(&can, m->dev[i], m->dev[0]) == hipSuccess && can) {
+                    (void)hipSetDevice(m->dev[i]);
+                    (void)hipDeviceEnablePeerAccess(m->dev[0], 0); // (already enabled: an error we do not care about)
+                    (void)hipGetLastError();
+                }
+            }
     }
     *out = m;
     return NEEDLE_OK;
@@ -162,6 +185,8 @@ void needle_multi_destroy(needle_multi *m) {
         if (i < m->stream.size() && m->stream[i]) (void)hipStreamSynchronize(m->stream[i]);
         if (i < m->comm.size() && m->comm[i]) (void)g_rccl.CommDestroy(m->comm[i]);
         if (i < m->local.size() && m->local[i].p) (void)hipFree(m->local[i].p);
+        if (i == 0 && m->root_stage.p) (void)hipFree(m->root_stage.p);
+        if (i == 0 && m->stage_free) (void)hipEventDestroy(m->stage_free);
         if (i < m->done.size() && m->done[i]) (void)hipEventDestroy(m->done[i]);
         if (i < m->stream.size() && m->stream[i]) (void)hipStreamDestroy(m->stream[i]);
     }
@@ -282,6 +307,18 @@ int needle_unpack_start_end16_dev(const uint32_t *d_in, uint64_t n, int32_t *d_s
 int needle_multi_device_count(const needle_multi *m) { return m ? (int)m->dev.size() : 0; }
 void *needle_multi_stream(const needle_multi *m, int i) { return (m && i >= 0 && i < (int)m->stream.size()) ? (void *)m->stream[i] : nullptr; }
 
+// "rccl" | "peer-copy: <why RCCL is not used>" | "local" (every shard on one device: plain device copies)
+const char *needle_multi_transport(const needle_multi *m) {
+    static thread_local std::string s;
+    if (!m) return "";
+    if (m->rccl) return "rccl";
+    bool distinct = false;
+    for (size_t i = 1; i < m->dev.size(); ++i) distinct = distinct || m->dev[i] != m->dev[0];
+    if (!distinct) return "local";
+    s = "peer-copy: " + m->transport_note;
+    return s.c_str();
+}
+
 int needle_multi_sync(needle_multi *m) {
     if (!m) return fail(NEEDLE_ERR_INVALID, "handle is NULL");
     DeviceGuard guard;
@@ -321,8 +358,18 @@ int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const ne
     struct Part { // where shard g's results sit before the gather (g > 0, or g == 0 in loopback mode)
         uint64_t *bm;
         int32_t *st, *en;
+        uint32_t *packed; // find, shard on another device than the root: start / end as one dword per row for the link
+        uint64_t stage_off; // ... and where they land in the root's staging buffer (dwords)
     };
-    std::vector<Part> part(n, Part{nullptr, nullptr, nullptr});
+    std::vector<Part> part(n, Part{nullptr, nullptr, nullptr, nullptr, 0});
+    // find(): start / end of a shard on ANOTHER device cross the link as one dword per row (two 16-bit halves, 0xFFFF = no
+    // match: needle_pack_start_end16_dev) and are unpacked on the root -- half the bytes every peer pushes to the root.
+    // Exact for rows of at most 65 534 chars; longer rows keep the two int32 arrays.  NEEDLE_MULTI_PACK16=0 turns it off,
+    // =2 also packs shards that share the root's device (tests on a one-GPU box).
+    static const int pack_env = getenv("NEEDLE_MULTI_PACK16") ? atoi(getenv("NEEDLE_MULTI_PACK16")) : 1;
+    bool can_pack = find && pack_env != 0;
+    for (int g = 0; g < n; ++g) can_pack = can_pack && (shards[g].n_rows == 0 || shards[g].row_stride <= 65534);
+    uint64_t stage_rows = 0;
     for (int g = 0; g < n; ++g) {
         hipError_t e = hipSetDevice(m->dev[g]);
         if (e != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
@@ -333,7 +380,9 @@ int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const ne
             if (rc) return fail(rc, needle_last_error());
             continue;
         }
-        const size_t o_st = (size_t)words * 8, o_en = o_st + (find ? (size_t)rows * 4 : 0), total = o_en + (find ? (size_t)rows * 4 : 0);
+        const bool pack = can_pack && rows && (m->dev[g] != m->dev[0] || pack_env == 2);
+        const size_t o_st = (size_t)words * 8, o_en = o_st + (find ? (size_t)rows * 4 : 0), o_pk = o_en + (find ? (size_t)rows * 4 : 0),
+                     total = o_pk + (pack ? (size_t)rows * 4 : 0);
         needle_multi::Buf &b = m->local[g];
         if (b.cap < total) {
             if (b.p) {
@@ -346,10 +395,41 @@ int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const ne
             if ((e = hipMalloc((void **)&b.p, want)) != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
             b.cap = want;
         }
-        part[g] = Part{(uint64_t *)b.p, (int32_t *)(b.p + o_st), (int32_t *)(b.p + o_en)};
+        part[g] = Part{(uint64_t *)b.p, (int32_t *)(b.p + o_st), (int32_t *)(b.p + o_en), pack ? (uint32_t *)(b.p + o_pk) : nullptr, stage_rows};
         int rc = scan(g, part[g].bm, part[g].st, part[g].en);
+        if (rc == NEEDLE_OK && pack) rc = needle_pack_start_end16_dev(part[g].st, part[g].en, rows, part[g].packed, m->stream[g]);
         if (rc) return fail(rc, needle_last_error());
+        if (pack) stage_rows += rows;
     }
+    if (stage_rows) { // the root's staging buffer for the packed halves
+        hipError_t e = hipSetDevice(m->dev[0]);
+        needle_multi::Buf &b = m->root_stage;
+        if (e == hipSuccess && b.cap < stage_rows * 4) {
+            if (b.p) {
+                (void)hipStreamSynchronize(m->stream[0]);
+                (void)hipFree(b.p);
+            }
+            b.p = nullptr;
+            b.cap = 0;
+            const size_t want = (size_t)stage_rows * 4 + (size_t)stage_rows + 256;
+            if ((e = hipMalloc((void **)&b.p, want)) == hipSuccess) b.cap = want;
+        }
+        if (e != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("root staging buffer: ") + hipGetErrorString(e));
+    }
+    uint32_t *const stage = (uint32_t *)m->root_stage.p;
+    auto unpack_on_root = [&]() -> int { // after the root's stream has the peers' halves: back to the ABI's two int32 arrays
+        (void)hipSetDevice(m->dev[0]);
+        for (int g = 0; g < n; ++g)
+            if (part[g].packed) {
+                const int rc = needle_unpack_start_end16_dev(stage + part[g].stage_off, shards[g].n_rows, d_start + row0[g], d_end + row0[g], m->stream[0]);
+                if (rc) return rc;
+            }
+        if (stage_rows) {
+            if (!m->stage_free && hipEventCreateWithFlags(&m->stage_free, hipEventDisableTiming) != hipSuccess) return fail(NEEDLE_ERR_DEVICE, "hipEventCreate");
+            if (hipEventRecord(m->stage_free, m->stream[0]) != hipSuccess) return fail(NEEDLE_ERR_DEVICE, "hipEventRecord");
+        }
+        return NEEDLE_OK;
+    };
     // ---- gather to the root
     if (m->rccl) {
         int rc = g_rccl.GroupStart();
@@ -357,25 +437,39 @@ int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const ne
             if (!part[g].bm || shards[g].n_rows == 0) continue;
             const uint64_t rows = shards[g].n_rows, words = (rows + 63) / 64;
             (void)hipSetDevice(m->dev[g]);
+            const bool pk = part[g].packed != nullptr;
             rc = g_rccl.Send(part[g].bm, words, kNcclUint64, 0, m->comm[g], m->stream[g]);
-            if (rc == 0 && find) rc = g_rccl.Send(part[g].st, rows, kNcclInt32, 0, m->comm[g], m->stream[g]);
-            if (rc == 0 && find) rc = g_rccl.Send(part[g].en, rows, kNcclInt32, 0, m->comm[g], m->stream[g]);
+            if (rc == 0 && find && pk) rc = g_rccl.Send(part[g].packed, rows, kNcclInt32, 0, m->comm[g], m->stream[g]);
+            if (rc == 0 && find && !pk) rc = g_rccl.Send(part[g].st, rows, kNcclInt32, 0, m->comm[g], m->stream[g]);
+            if (rc == 0 && find && !pk) rc = g_rccl.Send(part[g].en, rows, kNcclInt32, 0, m->comm[g], m->stream[g]);
             (void)hipSetDevice(m->dev[0]);
             if (rc == 0) rc = g_rccl.Recv(d_bitmap + row0[g] / 64, words, kNcclUint64, g, m->comm[0], m->stream[0]);
-            if (rc == 0 && find) rc = g_rccl.Recv(d_start + row0[g], rows, kNcclInt32, g, m->comm[0], m->stream[0]);
-            if (rc == 0 && find) rc = g_rccl.Recv(d_end + row0[g], rows, kNcclInt32, g, m->comm[0], m->stream[0]);
+            if (rc == 0 && find && pk) rc = g_rccl.Recv(stage + part[g].stage_off, rows, kNcclInt32, g, m->comm[0], m->stream[0]);
+            if (rc == 0 && find && !pk) rc = g_rccl.Recv(d_start + row0[g], rows, kNcclInt32, g, m->comm[0], m->stream[0]);
+            if (rc == 0 && find && !pk) rc = g_rccl.Recv(d_end + row0[g], rows, kNcclInt32, g, m->comm[0], m->stream[0]);
         }
         const int rc2 = g_rccl.GroupEnd();
         if (rc == 0) rc = rc2;
         if (rc != 0) return fail(NEEDLE_ERR_DEVICE, std::string("RCCL gather: ") + g_rccl.GetErrorString(rc));
+        if (const int urc = unpack_on_root()) return fail(urc, needle_last_error()); // (queued behind the receives on the root's stream)
     } else {
         for (int g = 0; g < n; ++g) {
             if (!part[g].bm || shards[g].n_rows == 0) continue;
             const uint64_t rows = shards[g].n_rows, words = (rows + 63) / 64;
             hipError_t e = hipSetDevice(m->dev[g]);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_bitmap + row0[g] / 64, part[g].bm, words * 8, hipMemcpyDefault, m->stream[g]);
-            if (e == hipSuccess && find) e = hipMemcpyAsync(d_start + row0[g], part[g].st, rows * 4, hipMemcpyDefault, m->stream[g]);
-            if (e == hipSuccess && find) e = hipMemcpyAsync(d_end + row0[g], part[g].en, rows * 4, hipMemcpyDefault, m->stream[g]);
+            // every peer pushes its results to the root on its own stream: device-to-device copies when the shard shares
+            // the root's device, peer-to-peer copies (its own xGMI link to the root) otherwise
+            const int sd = m->dev[g], rd = m->dev[0];
+            auto push = [&](void *dst, const void *src, size_t bytes) {
+                return sd == rd ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, m->stream[g])
+                                : hipMemcpyPeerAsync(dst, rd, src, sd, bytes, m->stream[g]);
+            };
+            const bool pk = part[g].packed != nullptr;
+            if (e == hipSuccess && pk && m->stage_free) e = hipStreamWaitEvent(m->stream[g], m->stage_free, 0); // the last call's unpack has read the staging buffer
+            if (e == hipSuccess) e = push(d_bitmap + row0[g] / 64, part[g].bm, words * 8);
+            if (e == hipSuccess && find && pk) e = push(stage + part[g].stage_off, part[g].packed, rows * 4);
+            if (e == hipSuccess && find && !pk) e = push(d_start + row0[g], part[g].st, rows * 4);
+            if (e == hipSuccess && find && !pk) e = push(d_end + row0[g], part[g].en, rows * 4);
             if (e == hipSuccess) e = hipEventRecord(m->done[g], m->stream[g]);
             if (e == hipSuccess && g != 0) {
                 (void)hipSetDevice(m->dev[0]);
@@ -383,6 +477,7 @@ int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const ne
             }
             if (e != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("gather copy: ") + hipGetErrorString(e));
         }
+        if (const int urc = unpack_on_root()) return fail(urc, needle_last_error()); // (the root's stream has waited for every push)
     }
     return NEEDLE_OK;
 }

@@ -25,6 +25,10 @@ class MultiDevice:
         if h and _lib is not None and _lib._lib is not None:
             _lib._lib.needle_multi_destroy(h)
 
+    def transport(self):
+        """What carries the gather: "rccl", "peer-copy: <why RCCL is not used>" or "local" (every shard on one device)."""
+        return _lib.lib().needle_multi_transport(self._h).decode()
+
     def scan(self, pattern, op, shards, lengths=None):
         """shards: one 2-D device tensor per device (every one but the last with a multiple of 64 rows), lengths: None or
         one int32 device tensor per shard.  -> (bitmap int64 words, start, end) on the root device (start / end None

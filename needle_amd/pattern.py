@@ -183,6 +183,24 @@ class Pattern:
         _check(_lib.lib().needle_pattern_program_info(self._h, list(WHICH).index(which), char_width, int(with_backward), ctypes.byref(i)))
         return {k: getattr(i, k) for k, _ in i._fields_}
 
+    def match_length_automaton(self):
+        """The refined forward automaton behind find-all's "lengths" form (needle_pattern_match_lengths), or None when the
+        pattern does not allow it -> {"n_states", "n_dead", "max_char", "table" int16[n, stride + 1] (last column: chars beyond max_char), "accepting"
+        bool[n], "pend" uint8[n]}."""
+        L = _lib.lib()
+        avail, n, nd, mc = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(L.needle_pattern_match_lengths(self._h, ctypes.byref(avail), ctypes.byref(n), ctypes.byref(nd), ctypes.byref(mc), None, None, None))
+        if not avail.value:
+            return None
+        stride = self.info()["stride"]
+        table = np.zeros(n.value * (stride + 1), dtype=np.int16)
+        acc = np.zeros(n.value, dtype=np.uint8)
+        pend = np.zeros(n.value, dtype=np.uint8)
+        _check(L.needle_pattern_match_lengths(self._h, ctypes.byref(avail), ctypes.byref(n), ctypes.byref(nd), ctypes.byref(mc), table.ctypes.data,
+                                              acc.ctypes.data, pend.ctypes.data))
+        return {"n_states": n.value, "n_dead": nd.value, "max_char": mc.value, "table": table.reshape(n.value, stride + 1),
+                "accepting": acc.astype(bool), "pend": pend}
+
     def tables(self):
         """The pattern's tables in the reference layout (class map, stride, 4 x (table, accepting, max_char))."""
         inf = self.info()
@@ -446,6 +464,62 @@ class Pattern:
         """(bitmap words, start int32[n], end int32[n]); unmatched rows have start = end = -1.  out: optional
         caller-owned (bitmap int64, start int32, end int32) device tensors."""
         return self._run("find", rows, lengths, stream, out)
+
+    MATCH_REC = np.dtype([("row", np.uint32), ("start", np.uint16), ("end", np.uint16)])  # needle_match_rec
+
+    def find_compact(self, rows, lengths=None, stream=None, out=None):
+        """find() with the MATCHED rows only, in row order, as {row u32, start u16, end u16} records
+        (needle_find_compact_dev / _host: 8 bytes per matched row instead of 8 per row; rows of at most 65 534 chars).
+        Host rows (numpy) -> (bitmap words, records as a MATCH_REC array); device rows (torch) -> (bitmap words,
+        records int32[cap, 2] tensor whose rows are the raw records, n_matched as a 1-element int64 device tensor);
+        out: optional caller-owned (bitmap int64, records int32[cap, 2], count int64[1]) device tensors."""
+        L = _lib.lib()
+        if isinstance(rows, np.ndarray):
+            rows = np.ascontiguousarray(rows)
+            if rows.dtype == np.int16:
+                rows = rows.view(np.uint16)
+            assert rows.ndim == 2 and rows.dtype in (np.uint8, np.uint16)
+            n, stride = rows.shape
+            v = BatchView()
+            v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.ctypes.data, rows.dtype.itemsize, n, stride, stride
+            if lengths is not None:
+                lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+                v.lengths = lengths.ctypes.data
+            words = np.zeros((n + 63) // 64, dtype=np.uint64)
+            recs = np.zeros(n, dtype=self.MATCH_REC)
+            m = ctypes.c_uint64(0)
+            _check(L.needle_find_compact_host(self._h, ctypes.byref(v), words.ctypes.data, recs.ctypes.data, n, ctypes.byref(m)))
+            return words, recs[:m.value]
+        import torch
+        v = self._dev_view(rows, lengths)
+        n = rows.shape[0]
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            if out is not None:
+                words, recs, cnt = out
+            else:
+                words = torch.empty((n + 63) // 64, dtype=torch.int64, device=rows.device)
+                recs = torch.empty((n, 2), dtype=torch.int32, device=rows.device)
+                cnt = torch.zeros(1, dtype=torch.int64, device=rows.device)
+            _check(L.needle_find_compact_dev(self._h, ctypes.byref(v), words.data_ptr(), recs.data_ptr(), recs.shape[0], cnt.data_ptr(), s))
+        return words, recs, cnt
+
+    def find_packed16_host(self, rows, lengths=None):
+        """needle_find_packed16_host: host rows -> (bitmap words, uint32[n]: low half start, high half end, 0xFFFF = no match)."""
+        L = _lib.lib()
+        rows = np.ascontiguousarray(rows)
+        if rows.dtype == np.int16:
+            rows = rows.view(np.uint16)
+        n, stride = rows.shape
+        v = BatchView()
+        v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.ctypes.data, rows.dtype.itemsize, n, stride, stride
+        if lengths is not None:
+            lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+            v.lengths = lengths.ctypes.data
+        words = np.zeros((n + 63) // 64, dtype=np.uint64)
+        se = np.zeros(n, dtype=np.uint32)
+        _check(L.needle_find_packed16_host(self._h, ctypes.byref(v), words.ctypes.data, se.ctypes.data))
+        return words, se
 
     # ---- haystacks packed back to back (one char buffer + offsets: what a JNI host gets from a String[])
     def _run_packed_host(self, op, data, offsets):

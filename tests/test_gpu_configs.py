@@ -155,12 +155,14 @@ def test_host_buffer_entry_points_match_device_entry_points():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hybrid,lds,mode", [("0", "4096", 3), ("1", "4096", 5), ("1", "20000", 5)])
+@pytest.mark.parametrize("hybrid,lds,mode", [("0", "4096", 3), ("1", "4096", 5), ("1", "20000", 5), ("1", "20000", 6), ("1", "12000", 6)])
 def test_hbm_resident_table_modes_match_oracle(hybrid, lds, mode):
     """Automata too large for the LDS: forced through NEEDLE_MAX_PROG_LDS in a child process on a keyword-union
     pattern; same parity bar as the LDS-table mode.  Mode 3 = whole table walked out of HBM / L2 (NEEDLE_HYBRID=0);
     mode 5 = the rows of the first states in breadth-first order in LDS (a few dozen rows at 4 KiB -- most steps then take
-    the cold path through the scalar cache -- or about half the automaton at 20 KB), the whole table in HBM."""
+    the cold path through the scalar cache -- or about half the automaton at 20 KB), the whole table in HBM; mode 6 = the
+    compressed automaton (dense rows near the start state + exception records, chains included at 12 KB), the first
+    choice when it fits -- the other modes are then reached with NEEDLE_SPARSE=0.  UTF-16 rows of the same text too."""
     import subprocess
     import sys
     code = r'''
@@ -188,7 +190,7 @@ assert (unpack_bitmap(fw, n) == of).all() and (fs.cpu().numpy() == ofs).all() an
 print("GLOBAL-MODE-OK")
 '''
     import os
-    env = dict(os.environ, NEEDLE_MAX_PROG_LDS=lds, NEEDLE_HYBRID=hybrid)
+    env = dict(os.environ, NEEDLE_MAX_PROG_LDS=lds, NEEDLE_HYBRID=hybrid, NEEDLE_SPARSE="1" if mode == 6 else "0")
     r = subprocess.run([sys.executable, "-c", code, str(mode)], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "GLOBAL-MODE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

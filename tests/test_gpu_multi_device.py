@@ -3,6 +3,8 @@ would drive it).  The GPU box has ONE device, so: (a) several shards on device 0
 (per-shard streams and result buffers, the root's in-place first block, the gather into shard order) -- equal to the
 unsharded scan and to the oracle; (b) the RCCL plumbing itself (dlopen, communicator, grouped ncclSend / ncclRecv on the
 shard streams) with a one-rank communicator sending to itself (NEEDLE_MULTI_LOOPBACK)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -176,3 +178,64 @@ def test_bench_two_ranks_on_one_gpu(workload):
     if d2["config"]["result"].startswith("bitmap+start/end"):
         assert d2["gather_check"]["checksum_gathered"] == d2["gather_check"]["checksum_ranks"]
     assert "gather_verified" not in d1 and d1["cold"]["ms_per_step"] > 0 and d1["steady"]["steps_effective"] >= 3
+
+
+PACKED = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from needle_amd.multi import MultiDevice
+from needle_amd.pattern import unpack_bitmap
+from needle_amd.sharding import shard_range
+from test_gpu_multi_device import compiled, _batch
+p, o = compiled("[0-9]+")
+for n_shards, total, loopback in ((2, 64 * 300 + 11, False), (3, 64 * 90, False), (1, 64 * 50 + 3, True)):
+    host = _batch(total, seed=3 + n_shards)
+    md = MultiDevice([0] * n_shards, loopback=loopback)
+    assert md.transport() == ("rccl" if loopback else "local"), md.transport()
+    shards = []
+    for g in range(n_shards):
+        r0, cnt = shard_range(total, n_shards, g)
+        shards.append(torch.from_numpy(host[r0:r0 + cnt]).cuda().contiguous())
+    m, s, e = o.batch_find(host, threads=4)
+    for rep in range(3):  # (the root's staging buffer is reused call after call)
+        words, st, en = md.scan(p, "find", shards)
+        assert (unpack_bitmap(words, total) == m).all() and (st.cpu().numpy() == s).all() and (en.cpu().numpy() == e).all(), (n_shards, rep)
+    assert (unpack_bitmap(md.scan(p, "contained_in", shards)[0], total) == o.batch_contained_in(host, threads=4)).all()
+# rows longer than the 16-bit halves can hold keep the two int32 arrays (here: a stride of 65 600 chars, match near the end)
+long_rows = np.full((128, 65600), ord("a"), dtype=np.uint8)
+long_rows[::3, 65590:65595] = ord("7")
+md = MultiDevice([0, 0])
+halves = [torch.from_numpy(long_rows[:64]).cuda(), torch.from_numpy(long_rows[64:]).cuda()]
+words, st, en = md.scan(p, "find", halves)
+m, s, e = o.batch_find(long_rows, threads=4)
+assert (unpack_bitmap(words, 128) == m).all() and (st.cpu().numpy() == s).all() and (en.cpu().numpy() == e).all()
+assert int(en.max()) == 65595
+print("PACKED-OK")
+'''
+
+
+@pytest.mark.gpu
+def test_multi_scan_find_through_the_packed_form():
+    """needle_multi_scan's find(): start / end of the non-root shards cross to the root as one dword per row (two 16-bit
+    halves) and are unpacked there -- forced on for shards that share the one GPU of this box (NEEDLE_MULTI_PACK16=2), over
+    device copies and over the one-rank RCCL loopback; rows beyond 65 534 chars keep the int32 arrays."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, NEEDLE_MULTI_PACK16="2")
+    r = subprocess.run([sys.executable, "-c", PACKED], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert "PACKED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_multi_handle_without_rccl_falls_back_to_copies():
+    """NEEDLE_MULTI_NO_RCCL=1: a handle is still made (on this box every shard shares device 0: plain device copies; between
+    distinct devices the same code issues hipMemcpyPeerAsync) and says which transport it uses."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = PACKED.replace('assert md.transport() == ("rccl" if loopback else "local"), md.transport()',
+                          'assert md.transport() == "local", md.transport()').replace("(1, 64 * 50 + 3, True)", "(4, 64 * 50 + 3, False)")
+    env = dict(os.environ, NEEDLE_MULTI_NO_RCCL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert "PACKED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
