@@ -12,14 +12,15 @@ HEADERS = ["needle_device.h", "needle_walk.h", "needle_scan.h", "needle_find_all
 
 
 PROBE_LIB = os.path.join(HERE, "libneedle_probe.so")  # measurement aid for bench.py, not part of the product ABI
-PROBE_SRC = os.path.join(CSRC, "stream_probe.hip")
+PROBE_SRCS = [os.path.join(CSRC, "stream_probe.hip"), os.path.join(CSRC, "prefix_probe.hip")]
 
 
 def build_probe(force=False):
-    """The trivial read-reduce kernel bench.py uses to measure this GPU's streaming-read ceiling."""
-    if force or not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_SRC) > os.path.getmtime(PROBE_LIB):
+    """Measurement kernels: the trivial read-reduce kernel bench.py uses to measure this GPU's streaming-read ceiling, and the
+    literal-prefix scan behind the f-4 A/B (scripts/prefix_prefilter_ab.py)."""
+    if force or not os.path.exists(PROBE_LIB) or any(os.path.getmtime(f) > os.path.getmtime(PROBE_LIB) for f in PROBE_SRCS):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", PROBE_LIB, PROBE_SRC])
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", PROBE_LIB] + PROBE_SRCS)
     return PROBE_LIB
 
 

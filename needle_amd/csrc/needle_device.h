@@ -84,6 +84,12 @@ struct ProgHeader {
     uint32_t sp_chains;    // some state needs more than one record: the walk loops while a lane's record has a successor
     uint32_t sp_pad_ident; // PAD (chars past the row's length) is the identity (matches / containedIn) or leads to the sink
     uint32_t sp_dense, sp_records; // statistics: dense rows (without the sink), records (without the two dummies)
+    // Window addressing (table modes, needle_lower.cpp): when the char -> column map is constant below some char and constant
+    // above another one, the table's columns are the CHARS of the window in between (the chars cl - 1 and ch + 1 standing
+    // for everything below / above) and the per-char column-map lookup -- one LDS read per char -- becomes one clamp:
+    // column offset = min(max(char * element size, win_lo_e), win_hi_e).  The offset is NOT rebased to 0: the table sits
+    // win_lo_e bytes further up instead.  n_cols / pad_col describe the window layout then.
+    uint32_t win_on, win_lo_e, win_hi_e;
     // find-all "lengths" form (needle_lower.h, MatchLengths): pend[] by device state in LDS; the dead-with-a-pending-match
     // states are the device ids fa_dead_lo .. fa_dead_lo + fa_dead_n - 1
     uint32_t fa_len_off, fa_dead_lo, fa_dead_n;

@@ -109,6 +109,41 @@ static ColumnMaps column_maps(const RefTables &t, const RefDfa &d, int char_widt
     return m;
 }
 
+// ---- window addressing (needle_device.h) ------------------------------------------------------------------------------
+// The reference walks `state = T[cls + state * N]` with `cls = BYTE_CLASSES[c]` (DFAClassBuilder.java:438-468): two dependent
+// loads per char.  On the GPU the class lookup is an LDS read per char that competes with the transition lookups for the
+// same LDS cycles (a third of them on a keyword dictionary).  When the char -> column map is constant below some char and
+// constant above another (an ASCII-letter dictionary: everything below 'a' and everything above 'z' is "other"), the
+// table can be indexed by the CHAR instead -- columns = the chars of the window, each a copy of its class's column -- and
+// the lookup becomes a clamp in registers.
+namespace {
+struct Window {
+    bool ok = false;
+    int cl = 0, ch = 0, W = 0; // chars cl .. ch are the table's columns; cl stands for every char below it, ch for every one above
+    std::vector<int> cols;     // class column (OVER included) of char cl + j
+};
+// `same(a, b)`: columns a and b have the same content in this automaton (such chars may share a run)
+template <typename Same>
+Window find_window(const ColumnMaps &cm, int char_width, Same same) {
+    const int maxc = char_width == 1 ? 255 : 65535;
+    auto col = [&](int c) -> int { return char_width == 1 ? cm.cmap8[c] : cm.pages[(size_t)cm.ptab[c >> 8] * 256 + (c & 255)]; };
+    int p = 1;
+    while (p <= maxc && same(col(p), col(0))) ++p; // chars [0, p) behave alike
+    int q = maxc;
+    while (q > 0 && same(col(q - 1), col(maxc))) --q; // chars [q, maxc] behave alike
+    Window w;
+    w.cl = p - 1;
+    if (w.cl & 1) --w.cl; // (even: the hot-rows mode reads its HBM table in dwords at win_lo_e-biased offsets)
+    w.ch = std::max(q, w.cl);
+    w.W = w.ch - w.cl + 1;
+    if (w.W > 1024) return w;
+    w.cols.resize(w.W);
+    for (int j = 0; j < w.W; ++j) w.cols[j] = col(w.cl + j);
+    w.ok = true;
+    return w;
+}
+} // namespace
+
 // ---- MODE_SPARSE: "dense rows near the start state + default-row / exception records for every other state" ----------
 // The reference's table (DFAClassBuilder.java:317-333; walked at :438-468) is a dense [state][class] array.  Search
 // automata of big alternations (a keyword dictionary) have thousands of states whose rows differ from the row of a
@@ -125,11 +160,16 @@ constexpr int kSparseMaxChain = 3; // states that need more exceptions than this
 
 // next_full: device-numbered table [n_dev][n_cols_full] (0 = sink | non-accepting | accepting from accept_lo_dev on); only
 // the columns listed in `cols` take part, renumbered 0 .. cols.size() - 1 in that order.  room: bytes the image may take.
-bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_full, const std::vector<int> &cols, int start_dev,
+bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_full, const std::vector<int> &cols, int col_bias, int start_dev,
                   int accept_lo_dev, size_t room, SparseImage &out) {
+    // col_bias (window addressing): the walk's column offsets are (col_bias + j) * 4, not rebased -- every row sits col_bias
+    // cells further up than its address says, and the record keys carry the bias
     const int NC = (int)cols.size();
     const size_t row_bytes = (size_t)NC * 4;
-    if (n_dev < 2 || NC < 1 || NC * 4 > 0xFFFC) return false;
+    const uint32_t bias4 = (uint32_t)col_bias * 4u;
+    if (n_dev < 2 || NC < 1 || (NC + col_bias) * 4 > 0xFFFC) return false;
+    if (room <= bias4) return false;
+    room -= bias4;
     // only the columns some char of the haystack's width maps to take part (8-bit rows never see the class of U+FFFF, nor
     // OVER when maxChar >= 255): compacted copy [n_dev][NC]
     std::vector<uint16_t> next((size_t)n_dev * NC);
@@ -236,8 +276,8 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
             bytes = nb;
         }
 
-    // ---- addresses
-    const uint32_t rec_base = (uint32_t)((row_bytes + 7) & ~(size_t)7);
+    // ---- addresses (physical, relative to the table base; a row's ADDRESS field is its physical start minus bias4)
+    const uint32_t rec_base = (uint32_t)((bias4 + row_bytes + 7) & ~(size_t)7);
     std::vector<uint32_t> rec_at(n_dev, 0); // address of a sparse state's first record (its acceptance class's dummy when it has none)
     uint32_t at = rec_base;
     const uint32_t dummy_nonacc = at;
@@ -267,15 +307,16 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
         uint32_t r = rows_base;
         for (int i = 0; i < S; ++i)
             if (is_dense[order[i]]) { row_at[order[i]] = r; r += (uint32_t)row_bytes; ++n_dense; }
-        if (r / 4 > 0xFFFFu || r > room + 8) return false;
+        if (r / 4 > 0xFFFFu || r > room + bias4 + 8) return false;
         out.img.assign(r, 0);
     }
+    row_at[0] = bias4; // the sink's row
     auto value = [&](int s) -> uint32_t { // state value: recB << 16 | rowA4
         if (s == 0) return 0u;
         const bool acc = s >= accept_lo_dev;
-        if (is_dense[s]) return ((acc ? dummy_acc : dummy_nonacc) << 16) | (row_at[s] >> 2);
+        if (is_dense[s]) return ((acc ? dummy_acc : dummy_nonacc) << 16) | ((row_at[s] - bias4) >> 2);
         const uint32_t rec = exc[s].empty() ? (acc ? dummy_acc : dummy_nonacc) : rec_at[s];
-        return (rec << 16) | (row_at[dflt[s]] >> 2); // row_at[0] = 0: the sink's row
+        return (rec << 16) | ((row_at[dflt[s]] - bias4) >> 2); // (the sink's row: address 0)
     };
     auto put32 = [&](uint32_t off, uint32_t v) { memcpy(&out.img[off], &v, 4); };
     put32(dummy_nonacc, 0xFFFFu); // key 0xFFFF: no column * 4 equals it; no successor; target unused
@@ -288,7 +329,7 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
             for (size_t k = 0; k < exc[s].size(); ++k) {
                 const uint32_t a = rec_at[s] + 8u * (uint32_t)k;
                 const uint32_t nxt = k + 1 < exc[s].size() ? a + 8u : 0u;
-                put32(a, ((uint32_t)exc[s][k] * 4u) | (nxt << 16));
+                put32(a, ((uint32_t)exc[s][k] * 4u + bias4) | (nxt << 16));
                 put32(a + 4, value(cell(s, exc[s][k])));
             }
         }
@@ -314,7 +355,7 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
         const uint32_t sv = value(s);
         if ((sv >= out.accept_lo) != (s >= accept_lo_dev && s != 0)) return false;
         for (int c = 0; c < NC; ++c) {
-            const uint32_t col4 = (uint32_t)c * 4u;
+            const uint32_t col4 = (uint32_t)c * 4u + bias4;
             const uint32_t a = rd32((sv & 0xFFFFu) * 4u + col4);
             uint32_t b0 = rd32(sv >> 16), b1 = rd32((sv >> 16) + 4);
             bool hit = (b0 & 0xFFFFu) == col4;
@@ -419,6 +460,49 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     const size_t pair_bytes = (size_t)n_dev * n_cols * n_cols * 2;
     if (!no_pair && mode == MODE_TABLE8 && char_width == 1 && pair_bytes <= pair_budget && pair_bytes + 4096 <= lds_table_budget) mode = MODE_PAIR;
 
+    // Window addressing for the table modes (needle_device.h; not for the plain layouts other kernels walk: global_walk, the
+    // HBM-table variant with no LDS budget, the find-all programs).  NEEDLE_WINDOW=0 turns it off (A/B, tests).
+    Window win;
+    {
+        static const bool window_on = !(getenv("NEEDLE_WINDOW") && atoi(getenv("NEEDLE_WINDOW")) == 0);
+        if (window_on && !no_pair && lds_table_budget > 0 && mode != MODE_PACK && mode != MODE_PAIR) {
+            auto same = [&](int a, int b) {
+                if (a == b) return true;
+                for (int st = 0; st < n_dev; ++st)
+                    if (next[(size_t)st * n_cols + a] != next[(size_t)st * n_cols + b]) return false;
+                return true;
+            };
+            win = find_window(cm, char_width, same);
+            // worth it when the window is not much wider than the classes it replaces (a dictionary over [a-z]: 28 chars for 29
+            // classes), or the table is small anyway
+            const size_t e = mode == MODE_TABLE16 ? 2 : 1;
+            const size_t bytes_w = (size_t)n_dev * (win.W + 2) * e, bytes_c = (size_t)n_dev * n_cols * e;
+            if (win.ok && !(bytes_w <= bytes_c * 5 / 4 || bytes_w <= (16u << 10))) win.ok = false;
+        }
+    }
+    // a table in window layout: columns = the window's chars (each a copy of its class's column), then PAD and PRE
+    auto window_table = [&](const std::vector<uint16_t> &tab, int n_rows) {
+        const int nw = win.W + 2;
+        std::vector<uint16_t> o((size_t)n_rows * nw);
+        for (int st = 0; st < n_rows; ++st) {
+            for (int j = 0; j < win.W; ++j) o[(size_t)st * nw + j] = tab[(size_t)st * n_cols + win.cols[j]];
+            o[(size_t)st * nw + win.W] = tab[(size_t)st * n_cols + PAD];
+            o[(size_t)st * nw + win.W + 1] = tab[(size_t)st * n_cols + PRE];
+        }
+        return o;
+    };
+    auto set_window_header = [&](uint32_t elem) {
+        p.hdr.win_on = 1;
+        p.hdr.win_lo_e = (uint32_t)win.cl * elem;
+        p.hdr.win_hi_e = (uint32_t)win.ch * elem;
+        p.hdr.n_cols = (uint32_t)win.W + 2;
+        p.hdr.pad_col = (uint32_t)(win.cl + win.W); // (column offsets are not rebased: PAD is "char ch + 1", PRE "char ch + 2")
+    };
+    auto clear_window_header = [&]() {
+        p.hdr.win_on = p.hdr.win_lo_e = p.hdr.win_hi_e = 0;
+        p.hdr.n_cols = n_cols;
+        p.hdr.pad_col = PAD;
+    };
     ColumnMaps bm;
     if (with_backward_maps) bm = column_maps(t, t.dfa[W_BACKWARDS], char_width);
     auto emit_backward_maps = [&]() {
@@ -556,6 +640,25 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         auto build = [&](Mode m) {
             const uint32_t elem = (m == MODE_TABLE16) ? 2u : 1u;
             p.blob.clear();
+            clear_window_header();
+            if (win.ok && m != MODE_GLOBAL) {
+                // window addressing: no column maps; the table sits win_lo_e bytes above where the kernels' fixed offsets point
+                set_window_header(elem);
+                const std::vector<uint16_t> tw = window_table(next, n_dev);
+                if (char_width == 1) p.blob.assign(kLdsTable1 + p.hdr.win_lo_e, 0);
+                else p.blob.assign(16, 0);
+                p.hdr.off_table = (uint32_t)p.blob.size() - (char_width == 1 ? p.hdr.win_lo_e : 0u);
+                if (m == MODE_TABLE8) {
+                    for (uint16_t v : tw) p.blob.push_back((uint8_t)v);
+                } else {
+                    const uint8_t *b = (const uint8_t *)tw.data();
+                    p.blob.insert(p.blob.end(), b, b + tw.size() * 2);
+                }
+                if (char_width == 2) p.hdr.off_table = 16; // (the kernels subtract win_lo_e themselves: 32-bit address math)
+                emit_backward_maps();
+                p.hdr.lds_bytes = (uint32_t)p.blob.size();
+                return;
+            }
             if (char_width == 1) {
                 p.blob.assign(512, 0); // cmap16 at kLdsCmap1 = 0
                 for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, cm.cmap8[c] * elem);
@@ -582,7 +685,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             }
         };
         const uint32_t elem = (mode == MODE_TABLE16) ? 2u : 1u;
-        if (char_width == 2 && (uint32_t)n_cols * elem > 255u) mode = MODE_GLOBAL; // pages hold column * elem in a byte
+        if (char_width == 2 && (uint32_t)n_cols * elem > 255u && !win.ok) mode = MODE_GLOBAL; // pages hold column * elem in a byte
         build(mode);
         bool sparse_done = false;
         if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget && !no_pair) {
@@ -601,7 +704,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                     if (used[k]) { col_id[k] = (int)cols.size(); cols.push_back(k); }
             }
             const int NC = (int)cols.size();
-            const bool cols_ok = char_width == 1 || NC * 4 <= 256; // UTF-16: the pages hold column * 4 in a byte
+            const bool cols_ok = char_width == 1 || NC * 4 <= 256 || win.ok; // UTF-16: the pages hold column * 4 in a byte
             if (sparse_on && cols_ok) {
                 // containedIn: every accepting state is absorbing -- one state as far as the walk is concerned
                 std::vector<uint16_t> canon;
@@ -613,21 +716,37 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                     for (int k = 0; k < n_cols; ++k) canon[(size_t)accept_lo * n_cols + k] = (uint16_t)accept_lo;
                     tab = &canon;
                 }
-                p.blob.clear();
-                p.hdr.off_bcmap = p.hdr.off_bptab = p.hdr.off_bpages = p.hdr.off_btable = p.hdr.off_bpack = 0;
-                if (char_width == 1) {
-                    p.blob.assign(kLdsTable1, 0);
-                    for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, (uint32_t)col_id[cm.cmap8[c]] * 4u);
-                } else {
-                    p.blob.assign(kLdsPages2Table + cm.pages.size(), 0);
-                    for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
-                    for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Table + i] = (uint8_t)(col_id[cm.pages[i]] * 4);
-                    while (p.blob.size() % 16) p.blob.push_back(0);
-                }
-                const size_t fixed = p.blob.size() + (with_backward_maps ? (char_width == 1 ? 256 : 256 + bm.pages.size()) + 64 : 0) + 64;
                 const size_t room = std::min(lds_table_budget, sparse_room);
                 SparseImage im;
-                if (room > fixed && build_sparse(*tab, n_dev, n_cols, cols, dev[0], accept_lo, room - fixed, im)) {
+                bool built = false;
+                for (int attempt = win.ok ? 0 : 1; attempt < 2 && !built; ++attempt) { // window addressing first, column maps else
+                    const bool w = attempt == 0;
+                    p.blob.clear();
+                    clear_window_header();
+                    p.hdr.off_bcmap = p.hdr.off_bptab = p.hdr.off_bpages = p.hdr.off_btable = p.hdr.off_bpack = 0;
+                    if (w) {
+                        p.blob.assign(char_width == 1 ? (size_t)kLdsTable1 : 16, 0);
+                    } else if (char_width == 1) {
+                        p.blob.assign(kLdsTable1, 0);
+                        for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, (uint32_t)col_id[cm.cmap8[c]] * 4u);
+                    } else {
+                        if (NC * 4 > 256) break;
+                        p.blob.assign(kLdsPages2Table + cm.pages.size(), 0);
+                        for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
+                        for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Table + i] = (uint8_t)(col_id[cm.pages[i]] * 4);
+                        while (p.blob.size() % 16) p.blob.push_back(0);
+                    }
+                    const size_t fixed = p.blob.size() + (with_backward_maps ? (char_width == 1 ? 256 : 256 + bm.pages.size()) + 64 : 0) + 64;
+                    if (room <= fixed) continue;
+                    built = w ? build_sparse(*tab, n_dev, n_cols, win.cols, win.cl, dev[0], accept_lo, room - fixed, im)
+                              : build_sparse(*tab, n_dev, n_cols, cols, 0, dev[0], accept_lo, room - fixed, im);
+                    if (built && w) {
+                        set_window_header(4);
+                        p.hdr.n_cols = n_cols; // (PAD / PRE are no columns in this mode; n_cols stays the reference's)
+                        p.hdr.pad_col = PAD;
+                    }
+                }
+                if (built) {
                     p.hdr.off_table = (uint32_t)p.blob.size();
                     p.blob.insert(p.blob.end(), im.img.begin(), im.img.end());
                     mode = MODE_SPARSE;
@@ -657,10 +776,12 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             // the rows of the first states in breadth-first order are the ones worth the LDS.  The hot prefix is sized
             // to leave room for 16 waves x 64-byte tiles.  NEEDLE_HYBRID=0: plain HBM table (tests, A/B).
             static const bool hybrid_on = !(getenv("NEEDLE_HYBRID") && atoi(getenv("NEEDLE_HYBRID")) == 0);
-            const size_t row_bytes = (size_t)n_cols * 2;
-            const bool cols_ok = char_width == 1 || row_bytes <= 255;
+            const bool hw = win.ok; // window addressing: rows of W + 2 cells, no column maps
+            const size_t row_bytes = (size_t)(hw ? win.W + 2 : n_cols) * 2;
+            const bool cols_ok = char_width == 1 || row_bytes <= 255 || hw;
             const size_t room = std::min<size_t>(lds_table_budget, 96u << 10);
-            const size_t fixed = p.hdr.lds_bytes + 64; // column maps (+ backward maps) as just built for the HBM-table layout
+            // column maps (+ backward maps) as just built for the HBM-table layout
+            const size_t fixed = p.hdr.lds_bytes + 64 + (hw ? (size_t)win.cl * 2 : 0);
             const size_t hot_rows = room > fixed ? std::min<size_t>((room - fixed) / row_bytes, (size_t)n_dev) : 0;
             if (hybrid_on && cols_ok && hot_rows >= 32 && n_dev <= 0x8000) {
                 // breadth-first numbering from the start state (0 stays the sink)
@@ -696,7 +817,17 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                 }
                 // layout: column maps (element size 2) | hot rows | backward maps || whole table (HBM only)
                 p.blob.clear();
+                clear_window_header();
                 p.hdr.off_bcmap = p.hdr.off_bptab = p.hdr.off_bpages = p.hdr.off_btable = p.hdr.off_bpack = 0;
+                if (hw) { // the table in window layout, physically win_lo_e bytes above the offsets the kernels use
+                    set_window_header(2);
+                    nh = window_table(nh, n_dev);
+                    p.blob.assign(char_width == 1 ? (size_t)kLdsTable1 + p.hdr.win_lo_e : 16, 0);
+                    p.hdr.hot_bytes = (uint32_t)(hot_rows * row_bytes);
+                    p.hdr.off_table = char_width == 1 ? (uint32_t)kLdsTable1 : 16u;
+                    const uint8_t *b = (const uint8_t *)nh.data();
+                    p.blob.insert(p.blob.end(), b, b + p.hdr.hot_bytes);
+                } else {
                 if (char_width == 1) {
                     p.blob.assign(512, 0);
                     for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, cm.cmap8[c] * 2u);
@@ -707,6 +838,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                 }
                 p.hdr.hot_bytes = (uint32_t)(hot_rows * row_bytes);
                 p.hdr.off_table = append(p.blob, nh.data(), p.hdr.hot_bytes);
+                }
                 emit_backward_maps();
                 while (p.blob.size() % 16) p.blob.push_back(0);
                 p.hdr.lds_bytes = (uint32_t)p.blob.size();

@@ -68,13 +68,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         wk.pad_b = a.hdr.pad_col * 2u;
         wk.pre_b = (a.hdr.pad_col + 1u) * 2u;
     }
-    if (MODE == MODE_SPARSE) wk.pad_e = wk.pre_e = 0; // (any valid column: the guarded walk overrides the result, needle_walk.h)
+    if (MODE == MODE_SPARSE) wk.pad_e = wk.pre_e = a.hdr.win_lo_e; // (any valid column: the guarded walk overrides the result, needle_walk.h)
+    // window addressing (needle_device.h): the column offset is the clamped char itself; the table sits win_lo bytes further up
+    wk.win_on = a.hdr.win_on;
+    wk.win_lo = a.hdr.win_lo_e;
+    wk.win_hi = a.hdr.win_hi_e;
     wk.sp_chains = a.hdr.sp_chains;
     wk.sp_pad_ident = a.hdr.sp_pad_ident;
-    wk.table_off = a.hdr.off_table;
+    // (window addressing: column offsets are not rebased -- wraps are fine in 32-bit address math; the compressed form carries
+    // the bias inside its image)
+    wk.table_off = a.hdr.off_table - (MODE == MODE_SPARSE ? 0u : a.hdr.win_lo_e);
     wk.lane4 = (uint32_t)(lane & 31) * 4u; // lanes l and l+32 are served in different LDS passes: 32 copies suffice
     wk.gtable = (const uint16_t *)(a.prog + (MODE == MODE_HYBRID ? a.hdr.off_gtable : a.hdr.off_table));
-    wk.hot_last = a.hdr.hot_bytes - 2u;
+    if (MODE == MODE_HYBRID) wk.gtable = (const uint16_t *)((const uint8_t *)wk.gtable - a.hdr.win_lo_e);
+    wk.hot_last = a.hdr.hot_bytes - 2u + a.hdr.win_lo_e;
     // packed mode: a state is the bit offset of its field in F (needle_device.h)
     const uint32_t accept_lo = MODE == MODE_PACK ? a.hdr.accept_off : a.hdr.accept_lo;
     const uint32_t start_state = MODE == MODE_PACK ? a.hdr.start_off : a.hdr.start;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
     __syncthreads();
     Walk wk;
     wk.ncols_e = 0, wk.pad_e = a.hdr.pad_f, wk.pre_e = a.hdr.pre_f, wk.table_off = 0, wk.gtable = nullptr;
+    wk.win_on = 0, wk.win_lo = 0, wk.win_hi = 0, wk.sp_chains = 0, wk.sp_pad_ident = 0;
     wk.lane4 = (uint32_t)(lane & 31) * 4u;
     constexpr int CPL = 64 / CW; // chars per lane and stripe
     const uint32_t accept_lo = a.hdr.accept_off;
@@ -608,7 +609,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
         wk.pad_b = a.hdr.pad_col * 2u;
         wk.pre_b = (a.hdr.pad_col + 1u) * 2u;
     }
-    wk.table_off = a.hdr.off_table;
+    wk.table_off = a.hdr.off_table - a.hdr.win_lo_e; // (window addressing, needle_device.h)
+    wk.win_on = a.hdr.win_on, wk.win_lo = a.hdr.win_lo_e, wk.win_hi = a.hdr.win_hi_e;
+    wk.sp_chains = 0, wk.sp_pad_ident = 0;
     wk.lane4 = (uint32_t)(lane & 31) * 4u;
     wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
     const uint32_t accept_lo = MODE == MODE_PACK ? a.hdr.accept_off : a.hdr.accept_lo;

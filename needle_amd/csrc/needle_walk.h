@@ -100,6 +100,20 @@ __device__ __forceinline__ uint32_t or_byte(uint32_t a, uint32_t w) { // a | (by
     return r;
 }
 
+template <int K>
+__device__ __forceinline__ uint32_t shl_word(uint32_t w, uint32_t sh) { // (16-bit half K of w) << sh
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(sh), "v"(w));
+    if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(sh), "v"(w));
+    return r;
+}
+
+// element size of a mode's table cells as a shift (window addressing: char << shift, clamped, IS the column offset)
+template <int MODE>
+__device__ __forceinline__ constexpr uint32_t elem_shift() {
+    return MODE == MODE_SPARSE ? 2u : (MODE == MODE_TABLE16 || MODE == MODE_HYBRID) ? 1u : 0u;
+}
+
 // LDS reads at an ABSOLUTE LDS byte address through address-space-3 pointers.  The dynamic segment starts at LDS
 // address 0 (this file declares no static __shared__; scan_kernel traps if that ever changes), so table offsets
 // are plain immediates: going through `smem` costs a `v_add 0` (late-resolved symbol) per access, going through
@@ -128,6 +142,7 @@ struct Walk {
     uint32_t lane4;     // lane * 4 (byte 0 of the packed-mode F address)
     const uint16_t *gtable; // MODE_GLOBAL / MODE_HYBRID: the whole table in HBM
     uint32_t hot_last;      // MODE_HYBRID: byte offset of the last table entry held in LDS (hot_bytes - 2)
+    uint32_t win_on, win_lo, win_hi; // window addressing (needle_device.h): clamp bounds of char * element size
     uint32_t sp_chains;     // MODE_SPARSE: some state has more than one exception record (wave-uniform)
     uint32_t sp_pad_ident;  // MODE_SPARSE: PAD is the identity (matches / containedIn) rather than the way to the sink
 };
@@ -233,6 +248,34 @@ template <int MODE, int CW, bool GUARD>
 __device__ __forceinline__ void piece_lookups(const Walk &wk, const uint32_t (&w)[4], uint32_t p0, uint32_t rem, uint32_t skip,
                                               uint32_t (&col)[16 / CW]) {
     constexpr int CPP = 16 / CW;
+    if (MODE != MODE_PACK && MODE != MODE_PAIR && wk.win_on) { // wave-uniform: window addressing -- no column-map lookup at all
+        const uint32_t sh = elem_shift<MODE>();
+        const uint32_t lo_v = wk.win_lo;
+#define NEEDLE_WIN(I, EXPR)                                                        \
+    {                                                                              \
+        uint32_t c = EXPR;                                                         \
+        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(lo_v), "s"(wk.win_hi)); /* one SGPR per VOP3 on gfx9 */ \
+        if (GUARD) {                                                               \
+            c = (p0 + (I) < rem) ? c : wk.pad_e;                                   \
+            c = (p0 + (I) < skip) ? wk.pre_e : c;                                  \
+        }                                                                          \
+        col[I] = c;                                                                \
+    }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if constexpr (CW == 1) {
+                NEEDLE_WIN(d * 4 + 0, shl_byte<0>(w[d], sh))
+                NEEDLE_WIN(d * 4 + 1, shl_byte<1>(w[d], sh))
+                NEEDLE_WIN(d * 4 + 2, shl_byte<2>(w[d], sh))
+                NEEDLE_WIN(d * 4 + 3, shl_byte<3>(w[d], sh))
+            } else {
+                NEEDLE_WIN(d * 2 + 0, shl_word<0>(w[d], sh))
+                NEEDLE_WIN(d * 2 + 1, shl_word<1>(w[d], sh))
+            }
+        }
+#undef NEEDLE_WIN
+        return;
+    }
     // all state-independent lookups of the piece first (they pipeline in the LDS) ...
     if (CW == 2) {
         // UTF-16: two dependent lookups per char before the state chain -- packed mode: page table -> F; table modes:
