@@ -116,6 +116,8 @@ struct ScanArgs {
     int32_t *start;
     int32_t *end;
     uint32_t *end_state;    // optional: the automaton state (device id) in which every row's walk stopped
+    uint32_t short_window;   // short_kernel (rows <= 64 B), find(): LDS holds an 80-byte slot per lane behind the program -- the
+                             // matched rows' text goes there for the backward walk instead of being re-read from memory
     uint32_t defer_max_live; // survivor pool (needle_kernels.hip): a group with at most this many unresolved rows after
                              // a 128-byte line hands them to its wave's pool and ends; 0 = off
 };

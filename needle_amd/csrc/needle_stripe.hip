@@ -588,7 +588,10 @@ hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, 
 // step per 64 rows whatever their length (45 G rows/s: 0.76 TB/s on 16-byte rows).  Always "guarded": per-row lengths
 // and find() cursors cost a few selects on at most 64 chars.
 // ------------------------------------------------------------------------------------------------
-template <int OP, int CW, int MODE>
+// GUARD = false: every row fills its stride and there are no cursors -- the per-char length / cursor selects go, and packed
+// automata log find()'s accept flags (one v_alignbit per char) instead of selecting a position per char (needle_walk.h).
+constexpr uint32_t kShortSlotBytes = 80; // LDS slot per lane for the backward walk's text (20 dwords apart: 4-way bank conflicts at worst)
+template <int OP, int CW, int MODE, bool GUARD>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -650,11 +653,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
         int32_t last = -1;
         if (OP == OP_FIND && a.hdr.root_accepting) last = ((uint32_t)cursor < len) ? cursor : 0; // :356, :440
         int32_t last_rel = -1;
+        constexpr bool HIST = !GUARD && OP == OP_FIND && MODE == MODE_PACK;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if ((uint32_t)j < n_pieces) {
                 const uint32_t w[4] = {cur[j][0], cur[j][1], cur[j][2], cur[j][3]};
-                walk_piece<OP, CW, MODE, true>(wk, w, (uint32_t)(j * CPP), len, (uint32_t)cursor, accept_lo, st, last_rel);
+                uint32_t acc_hist = 0;
+                walk_piece<OP, CW, MODE, GUARD, HIST>(wk, w, (uint32_t)(j * CPP), len, (uint32_t)cursor, accept_lo, st, last_rel, &acc_hist);
+                if (HIST && acc_hist) // the piece's accept flags: char i at bit 32 - CPP + i; the last accepting one is the highest set bit
+                    last_rel = (int32_t)(j * CPP) + (31 - (int32_t)__builtin_clz(acc_hist)) - (32 - CPP) + 1;
             }
         }
         if (OP == OP_FIND) last = last_rel >= 0 ? last_rel : last;
@@ -668,6 +675,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
             const int32_t e = res ? last : -1;
             if (a.fixed_len >= 0) {
                 s = res ? last - a.fixed_len : -1; // :640-646
+            } else if (a.short_window) {
+                // indexBackwards(end - 1, FROM), :536-583, on the row's text parked in this lane's LDS slot (it is in
+                // registers, which cannot be indexed per lane): one ds_read per char instead of a load from L2, and the packed /
+                // popcount-compressed / small dense forms of the backward automaton that ride in the program (needle_walk.h)
+                const uint32_t slot = ((a.hdr.lds_bytes + 15u) & ~15u) + ((uint32_t)wave * 64u + (uint32_t)lane) * kShortSlotBytes;
+                if (res) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((uint32_t)j < n_pieces) *(lds_u32x4 *)(uintptr_t)(slot + 16u * j) = cur[j];
+                }
+                const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
+                const int32_t sb = backward_walk<CW>(a, res, last, cursor, slot, 0u, (uint32_t)a.stride_bytes, 0u, rowp);
+                s = res ? sb : -1;
             } else {
                 // indexBackwards(end - 1, FROM), :536-583.  Column map (and a small backward table) in LDS, the row's
                 // chars re-read 8 at a time from its line (fetched a moment ago: L2).
@@ -719,13 +739,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
     }
 }
 
-template <int OP, int CW, int MODE>
-static hipError_t launch_short_one(const ScanArgs &a, int grid, size_t lds, hipStream_t stream) {
-    auto k = short_kernel<OP, CW, MODE>;
+template <int OP, int CW, int MODE, bool GUARD>
+static hipError_t launch_short_g(const ScanArgs &a, int grid, size_t lds, hipStream_t stream) {
+    auto k = short_kernel<OP, CW, MODE, GUARD>;
     static thread_local uint64_t configured = 0;
     if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(kWavesPerBlock * 64), lds, stream, a);
     return hipGetLastError();
+}
+template <int OP, int CW, int MODE>
+static hipError_t launch_short_one(const ScanArgs &a_in, int grid, size_t lds, hipStream_t stream) {
+    ScanArgs a = a_in;
+    // every row fills its stride, no cursors: the unguarded walk
+    const bool full = !a.lengths && !a.from && a.row_len != 0 && (uint64_t)a.row_len * CW == a.stride_bytes;
+    // find() by indexBackwards: room for the lanes' text slots behind the program?
+    a.short_window = 0;
+    if (OP == OP_FIND && a.fixed_len < 0 && lds + (size_t)kWavesPerBlock * 64 * kShortSlotBytes <= 160u * 1024u) {
+        a.short_window = 1;
+        lds += (size_t)kWavesPerBlock * 64 * kShortSlotBytes;
+    }
+    return full ? launch_short_g<OP, CW, MODE, false>(a, grid, lds, stream) : launch_short_g<OP, CW, MODE, true>(a, grid, lds, stream);
 }
 template <int OP, int CW>
 static hipError_t launch_short_m(const ScanArgs &a, int grid, size_t lds, hipStream_t s) {

@@ -428,6 +428,94 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
     } // lane_live
 }
 
+// indexBackwards(en - 1, bound), DFAClassBuilder.java:536-583, for the lanes of `act`.  The row bytes [win_b0, win_b0 +
+// win_bytes) are in LDS at win_addr (byte b at win_addr + ((b - win_b0) ^ swz16): the find-all tile is bank-swizzled, a
+// plain window is not); anything else is read from memory.  The backward automaton rides in the forward program's LDS part
+// (packed functions, popcount-compressed rows, a small dense table) or is walked out of HBM / L2.
+template <int CW>
+__device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, int32_t en, int32_t bound, uint32_t win_addr, uint32_t win_b0,
+                                                 uint32_t win_bytes, uint32_t swz16, const uint8_t *rowp) {
+    const uint16_t *gbt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
+    const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
+    int32_t idx_b = en - 1;
+    uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
+    int32_t lastb = a.bhdr.root_accepting ? bound : INT_MAX; // :543-547
+    bool active = act;
+    while (__ballot(active) != 0ull) {
+        uint32_t cs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int32_t p = idx_b - k;
+            const uint32_t rel = (uint32_t)(p * CW) - win_b0;      // byte offset inside the window, if it is there
+            const bool in_tile = rel < win_bytes;
+            const uint32_t ad = win_addr + ((in_tile ? rel : 0u) ^ swz16);
+            const uint32_t held = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
+            uint32_t c = 0;
+            if (active && p >= bound) {
+                c = held;
+                if (!in_tile) { // text outside the window (rare): waited for inside the branch, as in walk_tile
+                    c = (CW == 1) ? (uint32_t)rowp[p] : (uint32_t)((const uint16_t *)rowp)[p];
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(c));
+                }
+            }
+            cs[k] = c;
+        }
+        if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton
+            uint32_t fb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (CW == 1) {
+                    fb[k] = lds_u32(a.hdr.off_bpack + (cs[k] << 2));
+                } else {
+                    const u32x2 pg = lds_u32x2(a.hdr.off_bpack + ((cs[k] >> 8) << 3));
+                    fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool in_range = active && idx_b >= bound; // loop bound `index >= FROM`, :549
+                const uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
+                const bool alive = in_range && nb != 0u;
+                lastb = (alive && nb >= bacc) ? idx_b : lastb;
+                bs = alive ? nb : bs;
+                idx_b = alive ? idx_b - 1 : idx_b;
+                active = alive;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (active) {
+                    if (idx_b < bound) {
+                        active = false;
+                    } else {
+                        uint32_t col; // the backward automaton's char -> column maps, at absolute LDS addresses
+                        if (CW == 1) col = lds_u8(a.hdr.off_bcmap + cs[k]);
+                        else col = lds_u8(a.hdr.off_bpages + ((lds_u8(a.hdr.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
+                        if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
+                            const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
+                            const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col) - 1u));
+                            const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
+                            bs = ((bm >> col) & 1u) ? tgt : 0u;
+                        } else if (a.hdr.off_btable) { // wave-uniform: small dense table in LDS
+                            bs = lds_u16(a.hdr.off_btable + (bs * bcols + col) * 2u);
+                        } else { // dense table in HBM / L2 (waited for here: no vmcnt wait on the other paths)
+                            bs = gbt[bs * bcols + col];
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bs));
+                        }
+                        if (bs == 0) {
+                            active = false;
+                        } else {
+                            if (bs >= bacc) lastb = idx_b;
+                            --idx_b;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return lastb;
+}
+
 // Host side: let kernel `fn` use the whole 160 KiB of LDS.  The attribute belongs to (function, device): it is set
 // once per device a host thread launches `fn` on (a bit mask of devices already done, per instantiation).
 inline hipError_t allow_full_lds(const void *fn, uint64_t &done_mask) {
