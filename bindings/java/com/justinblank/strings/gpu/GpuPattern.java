@@ -140,6 +140,41 @@ public final class GpuPattern implements Pattern, AutoCloseable {
         return new Matches(offsets, start, end);
     }
 
+    /** Result of {@link #findCompact}: the matched rows in row order; match k is row[k], [start[k], end[k]). */
+    public static final class MatchedRows {
+        public final long[] bitmap;
+        public final int[] row;
+        public final int[] start;
+        public final int[] end;
+
+        MatchedRows(long[] bitmap, int[] row, int[] start, int[] end) {
+            this.bitmap = bitmap;
+            this.row = row;
+            this.start = start;
+            this.end = end;
+        }
+    }
+
+    /**
+     * find() of every row, reporting the MATCHED rows only (what Matcher.find() + start() + end() give per haystack,
+     * DFAClassBuilder.java:625-667): 1 bit per row + 8 bytes per matched row come back from the device instead of 8 bytes per
+     * row.  Rows of at most 65 534 chars.
+     */
+    public MatchedRows findCompact(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen, ByteBuffer lengths) {
+        long[] bitmap = new long[(int) ((nRows + 63) / 64)];
+        long[] n = new long[1];
+        int[] rec = new int[2 * (int) nRows];
+        check(Native.findCompactHost(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, bitmap, rec, n), null);
+        int m = (int) n[0];
+        int[] row = new int[m], start = new int[m], end = new int[m];
+        for (int k = 0; k < m; k++) {
+            row[k] = rec[2 * k];
+            start[k] = rec[2 * k + 1] & 0xFFFF;
+            end[k] = rec[2 * k + 1] >>> 16;
+        }
+        return new MatchedRows(bitmap, row, start, end);
+    }
+
     /**
      * find() over an array of haystacks: the strings are flattened to one char buffer + offsets (no per-string
      * Matcher objects, SURVEY.md s8 a9) and cross the boundary once.  Returns the match bitmap.

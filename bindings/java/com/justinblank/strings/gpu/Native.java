@@ -59,6 +59,13 @@ final class Native {
     static native int findAllCsrHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
                                      java.nio.ByteBuffer lengths, long[] offsets, int[] start, int[] end, long[] total);
 
+    /**
+     * needle_find_compact_host: find() with the MATCHED rows only, in row order -- records[2 * k] = row, records[2 * k + 1] =
+     * start | end << 16 (needle_match_rec as two ints); nMatched long[1] = the number of matched rows (may exceed the room).
+     */
+    static native int findCompactHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
+                                      java.nio.ByteBuffer lengths, long[] bitmap, int[] records, long[] nMatched);
+
     /** needle_pattern_serialize / needle_pattern_deserialize: the precompiled-pattern blob (Precompile's analogue). */
     static native byte[] serialize(long handle);
 

@@ -165,6 +165,23 @@ NATIVE(jint, findAllCsrHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint 
     return rc;
 }
 
+/* needle_find_compact_host: bitmap long[ceil(n / 64)]; records int[2 * cap] = needle_match_rec[cap]; nMatched long[1]. */
+NATIVE(jint, findCompactHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jlongArray bitmap, jintArray records, jlongArray nMatched) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    if (!bitmap || !nMatched || (*env)->GetArrayLength(env, bitmap) < (n + 63) / 64 || (*env)->GetArrayLength(env, nMatched) < 1) return NEEDLE_ERR_INVALID;
+    const jsize cap = records ? (*env)->GetArrayLength(env, records) / 2 : 0;
+    jlong *bm = (*env)->GetLongArrayElements(env, bitmap, NULL);
+    jint *rec = cap ? (*env)->GetIntArrayElements(env, records, NULL) : NULL;
+    uint64_t m = 0;
+    int rc = needle_find_compact_host((const needle_pattern *)(intptr_t)h, &v, (uint64_t *)bm, (needle_match_rec *)rec, (uint64_t)cap, &m);
+    jlong jm = (jlong)m;
+    (*env)->SetLongArrayRegion(env, nMatched, 0, 1, &jm);
+    (*env)->ReleaseLongArrayElements(env, bitmap, bm, 0);
+    if (rec) (*env)->ReleaseIntArrayElements(env, records, rec, 0);
+    return rc;
+}
+
 NATIVE(jint, packedHost)(JNIEnv *env, jclass c, jlong h, jint op, jcharArray data, jlongArray offsets, jlongArray bitmap, jintArray start, jintArray end) {
     needle_packed_view v;
     memset(&v, 0, sizeof(v));

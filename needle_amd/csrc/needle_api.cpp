@@ -898,6 +898,12 @@ int needle_pattern_program_info(const needle_pattern *p, int which, int char_wid
     o->records = (int32_t)pr.hdr.sp_records;
     o->chains = (int32_t)pr.hdr.sp_chains;
     if (pr.hdr.mode == MODE_HYBRID) o->hot_rows = (int32_t)(pr.hdr.hot_bytes / (pr.hdr.n_cols * 2u));
+    o->window = (int32_t)pr.hdr.win_on;
+    if (pr.hdr.win_on) {
+        const uint32_t e = pr.hdr.mode == MODE_SPARSE ? 4u : (pr.hdr.mode == MODE_TABLE16 || pr.hdr.mode == MODE_HYBRID) ? 2u : 1u;
+        o->window_lo = (int32_t)(pr.hdr.win_lo_e / e);
+        o->window_hi = (int32_t)(pr.hdr.win_hi_e / e);
+    }
     return NEEDLE_OK;
 }
 

@@ -31,11 +31,17 @@ bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb
             return true;
         }
     }
-    if (h.mode == MODE_PACK && char_width == 1 && p + 12u * 8192u <= cap) {
-        *waves = 16;
-        *chb = 128;
-        *tiles_in_f_rows = 1;
-        return true;
+    if (h.mode == MODE_PACK && char_width == 1) {
+        // (find() programs carry the packed backward automaton behind F, ~1.3 KB: one wave fewer keeps the 128-byte tiles --
+        // whole lines, `nt` loads -- where the generic ladder below would fall to 64-byte tiles.  NEEDLE_PACK_WAVES=16: old rule)
+        static const int min_waves = getenv("NEEDLE_PACK_WAVES") ? atoi(getenv("NEEDLE_PACK_WAVES")) : 14;
+        for (int w = 16; w >= min_waves && w >= 5; --w)
+            if (p + (size_t)(w - 4) * 8192u <= cap) {
+                *waves = w;
+                *chb = 128;
+                *tiles_in_f_rows = 1;
+                return true;
+            }
     }
     static const int cand[8][2] = {{16, 128}, {12, 128}, {16, 64}, {14, 64}, {12, 64}, {10, 64}, {8, 64}, {4, 64}};
     for (const auto &c : cand) {

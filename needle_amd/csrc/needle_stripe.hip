@@ -443,6 +443,10 @@ __global__ __launch_bounds__(256) void spec_fix_kernel(SpecArgs a) {
                     break;
                 }
                 if (!find && qt >= accept_lo) break; // containedIn: decided
+                // find / matches: the true run died (e.g. the stripe was entered in an accepting state and the match is over) --
+                // the sink is absorbing and the speculative run never is in it at a live char, so the two would not meet before
+                // the stripe's end: 4096 one-lane chars for nothing (Sherlock over 1 GiB of long rows: 1.04 of find()'s 1.35 ms)
+                if (find && qt == 0u) break;
             }
             if (met) { // from char i on the two runs are one
                 end_state = a.spec_end_state[v];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_fa (scripts/profile_find_all.sh) -> profiles/r02_find_all.md + the per-workload kernel-stats tables."""
+"""gpurun_out/prof_fa (scripts/profile_find_all.sh) -> profiles/r03_find_all.md + the per-workload kernel-stats tables."""
 import csv
 import json
 import os
@@ -9,7 +9,7 @@ import shutil
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_fa")
 out = []
-out.append("# needle::find_all_kernel, round 2 (`scripts/profile_find_all.sh`: `rocprofv3 --kernel-trace --stats -- python scripts/find_all_probe.py <workload> 10000000 32`)\n")
+out.append("# needle::find_all_kernel, round 3 (`scripts/profile_find_all.sh`: `rocprofv3 --kernel-trace --stats -- python scripts/find_all_probe.py <workload> 10000000 32`)\n")
 out.append("Every non-overlapping match of every row (the reference's repeated `Matcher.find()`), 10⁷ × 256-char rows resident in HBM, 32 result slots per row, "
            "outputs preallocated.  `probe ms` = host-timed call + synchronise (best of 4); `kernel µs` = rocprofv3 average of the kernel; "
            "`rounds ms` = the round-per-match form on the same rows (`NEEDLE_FIND_ALL_ROUNDS=1`: one scan of the batch and one stream synchronisation per round).\n")
@@ -24,7 +24,7 @@ for w in ("c3", "c2", "c5", "c3s"):
         if "find_all_kernel" in r["Name"]:
             k_avg += float(r["AverageNs"]) / 1e3
             calls = int(r["Calls"]) if calls is None else calls
-    shutil.copy(stats, os.path.join(root, "profiles", "r02_find_all_%s_kernel_stats.csv" % w))
+    shutil.copy(stats, os.path.join(root, "profiles", "r03_find_all_%s_kernel_stats.csv" % w))
     out.append("| %s | %d | %d | %.3f | %.1f (%d) | %.1f | %.0f | %.2f | %.1fx | %.2f | %.2f |" % (
         w, one["matches"], one["max_per_row"], one["ms"], k_avg, calls, one["matches"] / (k_avg * 1e-6) / 1e9,
         one["rows"] * 256 * (2 if w == "c5" else 1) / (k_avg * 1e-6) / 1e9, rnd["ms"], rnd["ms"] / one["ms"], one.get("count_ms", 0), one.get("csr_ms", 0)))
@@ -65,5 +65,5 @@ out.append("| HBM bytes per launch / (rows + 4 B per row + 8 B per match) | %.2f
 out.append("\nThe walk kernel is VALU-issue bound, not HBM bound: an iteration walks a whole 16-byte piece for every lane under the cursor guard and a tile takes as many "
            "iterations as its busiest lane (DESIGN.md s3).  At the end of every 64-row group the text of its matches (the 32 bytes before each end) is read again -- FETCH_SIZE says mostly from HBM: the lines have left the L2 by then.  The written bytes are several "
            "times the results (4-byte stores into per-row slots, filed as the matches are found: partial lines leave the L2 before a row's next match arrives).")
-open(os.path.join(root, "profiles", "r02_find_all.md"), "w").write("\n".join(out) + "\n")
+open(os.path.join(root, "profiles", "r03_find_all.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc_<workload>_<tag>/ (scripts/pmc.sh) -> profiles/r02_pmc.md; gpurun_out/prof_aux (scripts/profile_aux.sh)
--> profiles/r02_aux_kernels.md + the kernel-stats tables."""
+"""gpurun_out/pmc_<workload>_<tag>/ (scripts/pmc.sh) -> profiles/r03_pmc.md; gpurun_out/prof_aux (scripts/profile_aux.sh)
+-> profiles/r03_aux_kernels.md + the kernel-stats tables."""
 import collections
 import csv
 import glob
@@ -22,11 +22,13 @@ def summ(d):
     return out
 
 
-sets = [("c3 find, round-1 kernel (before)", "pmc_c3_r2before"),
-        ("c3 find, round 2: survivor pool, LDS-window + popcount-compressed backward walk", "pmc_c3_r2after"),
-        ("c3s find (sparse-match variant): hot rows in LDS + HBM table", "pmc_c3s_r2after"),
-        ("c5 find, first step of round 2 (F in the pages, u32 page table)", "pmc_c5_r2a"),
-        ("c5 find, round 2: ptab64 + constant pages, accept-flag log, packed backward", "pmc_c5_r2after")]
+RND = "03"
+sets = [("c3s find: hot rows in LDS + HBM table (round 2's mode; NEEDLE_SPARSE=0 NEEDLE_WINDOW=0)", "pmc_c3s_r3hybrid"),
+        ("c3s find: compressed automaton in LDS, column-map lookups (NEEDLE_WINDOW=0)", "pmc_c3s_r3sparse"),
+        ("c3s find: compressed automaton in LDS + window addressing (shipped)", "pmc_c3s_r3sparsewin"),
+        ("c3 find: LDS table u16, column-map lookups (NEEDLE_WINDOW=0)", "pmc_c3_r3cmap"),
+        ("c3 find: LDS table u16 + window addressing (shipped)", "pmc_c3_r3window"),
+        ("c5 find (packed functions, unchanged kernel)", "pmc_c5_r3")]
 keys = ["kernel_us", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
         "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
 rows = [(n, summ(d)) for n, d in sets]
@@ -44,8 +46,8 @@ def cell(r, f):
         return "—"
 
 
-with open(os.path.join(root, "profiles", "r02_pmc.md"), "w") as f:
-    f.write("# PMC summaries, round 2 (`rocprofv3 --kernel-trace --pmc ...`, one counter group per pass: `scripts/pmc.sh`; this table: `scripts/summarize_pmc.py`)\n\n")
+with open(os.path.join(root, "profiles", "r%s_pmc.md" % RND), "w") as f:
+    f.write("# PMC summaries, round 3 (`rocprofv3 --kernel-trace --pmc ...`, one counter group per pass: `scripts/pmc.sh`; this table: `scripts/summarize_pmc.py`)\n\n")
     f.write("Per launch of `needle::scan_kernel` on the 10M x 256 batch, mean over the launches of a 3-step bench run.  `GRBM_GUI_ACTIVE` is summed "
             "over the 8 XCDs (÷ 8 = kernel cycles); SQ wave / wait counters are in quad-cycles; `SQ_LDS_IDX_ACTIVE` / `SQ_LDS_BANK_CONFLICT` in LDS "
             "cycles summed over all CUs.  Runs under the profiler are 3-8 % slower than the bench line.\n\n")
@@ -64,12 +66,12 @@ with open(os.path.join(root, "profiles", "r02_pmc.md"), "w") as f:
 aux = os.path.join(root, "gpurun_out", "prof_aux")
 if os.path.isdir(aux):
     for d, name in (("short16", "short_rows_16B"), ("short64", "short_rows_64B"), ("long", "long_rows_1000x1MiB")):
-        shutil.copyfile(os.path.join(aux, d, "t_kernel_stats.csv"), os.path.join(root, "profiles", "r02_%s_kernel_stats.csv" % name))
-    with open(os.path.join(root, "profiles", "r02_aux_kernels.md"), "w") as f:
-        f.write("# Short-row and stripe kernels, round 2\n\n`scripts/profile_aux.sh`: `rocprofv3 --kernel-trace --stats -- python scripts/short_rows_rate.py 16|64` and "
+        shutil.copyfile(os.path.join(aux, d, "t_kernel_stats.csv"), os.path.join(root, "profiles", "r%s_%s_kernel_stats.csv" % (RND, name)))
+    with open(os.path.join(root, "profiles", "r%s_aux_kernels.md" % RND), "w") as f:
+        f.write("# Short-row and stripe kernels, round 3\n\n`scripts/profile_aux.sh`: `rocprofv3 --kernel-trace --stats -- python scripts/short_rows_rate.py 16|64` and "
                 "`... scripts/long_rows_rate.py 1000 1` ('[0-9]+'; 2.56 GB of rows of 16 / 64 bytes; 1000 rows of 1 MiB).  Rates printed by the scripts under the profiler:\n\n```\n")
         for d in ("short16", "short64", "long"):
             f.write("".join(line for line in open(os.path.join(aux, d + ".log")) if "amdgpu.ids" not in line))
-        f.write("```\n\nKernel tables (rocprofv3's `*_kernel_stats.csv`, verbatim): `r02_short_rows_16B_kernel_stats.csv`, `r02_short_rows_64B_kernel_stats.csv` "
-                "(`needle::short_kernel<OP, CW, MODE>`), `r02_long_rows_1000x1MiB_kernel_stats.csv` (`needle::stripe_kernel<CW, FIND, NS>`, `stripe_prefix_kernel`).\n")
-print(open(os.path.join(root, "profiles", "r02_pmc.md")).read())
+        f.write("```\n\nKernel tables (rocprofv3's `*_kernel_stats.csv`, verbatim): `r03_short_rows_16B_kernel_stats.csv`, `r03_short_rows_64B_kernel_stats.csv` "
+                "(`needle::short_kernel<OP, CW, MODE>`), `r03_long_rows_1000x1MiB_kernel_stats.csv` (`needle::stripe_kernel<CW, FIND, NS>`, `stripe_prefix_kernel`).\n")
+print(open(os.path.join(root, "profiles", "r%s_pmc.md" % RND)).read())
