@@ -861,30 +861,46 @@ namespace needle {
 
 MatchLengths match_length_automaton(const RefTables &t) {
     MatchLengths out;
-    const RefDfa &F = t.dfa[W_FORWARDS], &M = t.dfa[W_MATCHES];
+    const RefDfa &F = t.dfa[W_FORWARDS], &B = t.dfa[W_BACKWARDS];
     const int N = t.stride;
-    if (F.n_states < 1 || M.n_states < 1 || F.accepting[0] || M.accepting[0]) return out; // (empty matches: the immediate form)
-    // the alphabet: what the two automata can tell apart -- (class, beyond F's maxChar, beyond M's maxChar) of some code unit
+    if (F.n_states < 1 || B.n_states < 1 || F.accepting[0] || B.accepting[0] || t.dfa[W_MATCHES].accepting[0]) return out; // (empty matches: the immediate form)
+    static const bool dbg = getenv("NEEDLE_ML_DEBUG") != nullptr;
+    // the alphabet: what the two automata can tell apart -- (class, beyond F's maxChar, beyond B's maxChar) of some code unit
     std::vector<std::array<int, 3>> syms;
     {
         std::map<std::array<int, 3>, int> seen;
         for (int c = 0; c < 65536; ++c) {
-            const std::array<int, 3> k = {(int)t.class_map[c], c > F.max_char ? 1 : 0, c > M.max_char ? 1 : 0};
+            const std::array<int, 3> k = {(int)t.class_map[c], c > F.max_char ? 1 : 0, c > B.max_char ? 1 : 0};
             if (seen.emplace(k, 0).second) syms.push_back(k);
         }
     }
     const int S = (int)syms.size();
     auto stepF = [&](int f, const std::array<int, 3> &y) { return y[1] ? -1 : (int)F.table[(size_t)f * N + y[0]]; };
-    auto stepM = [&](int m, const std::array<int, 3> &y) { return y[2] ? -1 : (int)M.table[(size_t)m * N + y[0]]; };
-    // 1. product of the search automaton with the runs of the anchored automaton started at every position since the search
-    // began: a run = (state of M, chars read).  The longest accepting run is what indexBackwards would find.
-    typedef std::vector<uint32_t> Runs; // sorted (m << 8 | age)
-    std::map<std::pair<int, Runs>, int> index;
-    std::vector<std::pair<int, Runs>> prod;
+    auto stepB = [&](int b, const std::array<int, 3> &y) { return y[2] ? -1 : (int)B.table[(size_t)b * N + y[0]]; };
+    // 1. What would indexBackwards report if the search ended HERE?  The reversed automaton B reads the text right to left
+    // from the end, remembering the leftmost index at which it was accepting, until it dies (DFAClassBuilder.java:549-583; NOT
+    // simply the longest match: B is built with the reference's priority pruning, so `bc|abc` reports "bc" inside "abc").  Scanning
+    // left to right, keep for EVERY state q of B the answer "B started in q at the current end: the largest number of chars
+    // after which it was accepting" -- V[q] -- because one more char c turns it into V'[q] = V[B(q, c)] + 1 (or 1 when
+    // B(q, c) accepts and nothing longer does).  The product of the search automaton with those vectors (sparse: few states of
+    // B lead anywhere on a given text) is finite when match lengths are bounded; its accepting states report V[B's start].
+    std::vector<std::vector<std::vector<int>>> pred(S, std::vector<std::vector<int>>(B.n_states)); // pred[y][q1]: q with B(q, y) = q1
+    for (int y = 0; y < S; ++y)
+        for (int q = 0; q < B.n_states; ++q) {
+            const int q1 = stepB(q, syms[y]);
+            if (q1 >= 0) pred[y][q1].push_back(q);
+        }
+    std::vector<int> b_acc;
+    for (int q = 0; q < B.n_states; ++q)
+        if (B.accepting[q]) b_acc.push_back(q);
+    typedef std::vector<uint32_t> Vec; // sorted (q << 8 | length)
+    std::map<std::pair<int, Vec>, int> index;
+    std::vector<std::pair<int, Vec>> prod;
     std::vector<int> trans; // prod x S
     std::vector<int> outL;  // match length of an accepting product state, 0 otherwise
     const size_t kMaxProd = 60000;
-    auto intern = [&](int f, Runs &&r) -> int {
+    uint64_t work = 0;
+    auto intern = [&](int f, Vec &&r) -> int {
         auto key = std::make_pair(f, std::move(r));
         auto it = index.find(key);
         if (it != index.end()) return it->second;
@@ -892,37 +908,50 @@ MatchLengths match_length_automaton(const RefTables &t) {
         index.emplace(key, id);
         int L = 0;
         if (F.accepting[f]) {
-            for (uint32_t x : key.second)
-                if (M.accepting[x >> 8]) L = std::max(L, (int)(x & 255u));
-            if (L == 0) L = -1; // the search automaton accepts but no anchored run does: the two disagree -- give up
+            // V[B's start state 0]: entries are sorted by q, so it is the first one if present
+            if (!key.second.empty() && (key.second[0] >> 8) == 0u) L = (int)(key.second[0] & 255u);
+            if (L == 0) L = -1; // the search automaton accepts but the reversed one finds no start: the two disagree -- give up
         }
         outL.push_back(L);
         prod.push_back(std::move(key));
         return id;
     };
-    intern(0, Runs());
+    intern(0, Vec());
+    std::vector<int> scratch(B.n_states, 0);
     for (size_t i = 0; i < prod.size(); ++i) {
-        if (prod.size() > kMaxProd) { if (getenv("NEEDLE_ML_DEBUG")) fprintf(stderr, "[ml] product too big\n"); return out; }
-        if (outL[i] < 0) { if (getenv("NEEDLE_ML_DEBUG")) fprintf(stderr, "[ml] F accepts (state %d) without an accepting anchored run\n", prod[i].first); return out; }
+        if (prod.size() > kMaxProd || work > 400ull * 1000 * 1000) { if (dbg) fprintf(stderr, "[ml] product too big\n"); return out; }
+        if (outL[i] < 0) { if (dbg) fprintf(stderr, "[ml] F accepts (state %d) but the reversed automaton finds no start\n", prod[i].first); return out; }
         trans.resize((i + 1) * S, -1);
         for (int y = 0; y < S; ++y) {
             const int f = prod[i].first;
             const int f2 = stepF(f, syms[y]);
             if (f2 < 0) continue;
-            Runs r;
-            r.reserve(prod[i].second.size() + 1);
-            bool too_old = false;
+            Vec r;
+            bool too_long = false;
+            // scratch[q] = V'[q] (0 = undefined)
+            std::vector<int> touched;
+            for (int q1 : b_acc)
+                for (int q : pred[y][q1]) {
+                    if (!scratch[q]) touched.push_back(q);
+                    scratch[q] = 1;
+                }
             for (uint32_t x : prod[i].second) {
-                const int m2 = stepM((int)(x >> 8), syms[y]);
-                if (m2 < 0) continue;
-                const uint32_t age = (x & 255u) + 1u;
-                if (age > 250u) too_old = true;
-                r.push_back(((uint32_t)m2 << 8) | age);
+                const int q1 = (int)(x >> 8), len = (int)(x & 255u) + 1;
+                if (len > 250) too_long = true;
+                for (int q : pred[y][q1]) {
+                    if (!scratch[q]) touched.push_back(q);
+                    scratch[q] = len; // (longer than the 1 an accepting B(q, c) alone gives)
+                }
+                work += pred[y][q1].size() + 1;
             }
-            const int m1 = stepM(0, syms[y]);
-            if (m1 >= 0) r.push_back(((uint32_t)m1 << 8) | 1u);
-            if (too_old || r.size() > 64) { if (getenv("NEEDLE_ML_DEBUG")) fprintf(stderr, "[ml] unbounded runs\n"); return out; } // unbounded match lengths (`[0-9]+`, `a.*b`): keep indexBackwards
-            std::sort(r.begin(), r.end());
+            std::sort(touched.begin(), touched.end());
+            r.reserve(touched.size());
+            for (int q : touched) {
+                r.push_back(((uint32_t)q << 8) | (uint32_t)scratch[q]);
+                scratch[q] = 0;
+            }
+            work += touched.size();
+            if (too_long || r.size() > 8192) { if (dbg) fprintf(stderr, "[ml] unbounded match lengths\n"); return out; } // `[0-9]+`, `a.*b`: keep indexBackwards
             const int id = intern(f2, std::move(r)); // (may reallocate prod: indices only from here on)
             trans[i * S + y] = id;
         }
@@ -999,7 +1028,7 @@ MatchLengths match_length_automaton(const RefTables &t) {
     }
     const int n_ref = 1 + K + (int)pst.size() - 1;
     out.dfa.n_states = n_ref;
-    out.dfa.max_char = std::min(F.max_char, M.max_char); // chars beyond it take the OVER column: out.over[]
+    out.dfa.max_char = std::min(F.max_char, B.max_char); // chars beyond it take the OVER column: out.over[]
     out.over.assign(n_ref, (int16_t)-1);
     out.dfa.table.assign((size_t)n_ref * N, (int16_t)-1);
     out.dfa.accepting.assign(n_ref, 0);

@@ -49,9 +49,9 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
 // ---- find-all without backward walks (needle_find_all.hip, "lengths" form) -----------------------------------------
 // The reference finds a match's start by walking the reversed automaton back from its end (indexBackwards,
 // DFAClassBuilder.java:529-586) unless the WHOLE pattern has one length (Factorization.canOnlyHaveOneLength, :640-646).
-// Generalised here per STATE: the forward search automaton is refined (a product with the runs of the anchored automaton
-// started at every position, Moore-minimised with the match length as output) until every accepting state stands for ONE
-// match length, and then made to REMEMBER the length of its last match until it dies -- dead states "D_L" instead of the
+// Generalised here per STATE: the forward search automaton is refined (a product with "what the reversed automaton would
+// report from here", kept for every one of its states; Moore-minimised with the match length as output) until every
+// accepting state stands for ONE match length, and then made to REMEMBER the length of its last match until it dies -- dead states "D_L" instead of the
 // sink.  A find() that ends in state s then reports start = end - pend[s]: no backward walk, no second look at the text.
 // Possible for keyword unions and other patterns whose accepting runs have bounded, state-determined lengths; anything
 // else (an accepting state reachable with two match lengths and no finite refinement, e.g. `[0-9]+`) keeps indexBackwards.

@@ -62,8 +62,11 @@ out.append("| VALU instructions per char-wave | %.1f (scan kernel, C3 find: 3.8)
 out.append("| LDS instructions per char-wave | %.2f |" % (pmc["SQ_INSTS_LDS"] / cw))
 out.append("| HBM bytes per launch / (rows + 4 B per row + 8 B per match) | %.2f |" % (
     (traffic["FETCH_SIZE"] * 2048 + traffic["WRITE_SIZE"] * 1024) / (1e7 * 260 + 8 * 46586444)))
-out.append("\nThe walk kernel is VALU-issue bound, not HBM bound: an iteration walks a whole 16-byte piece for every lane under the cursor guard and a tile takes as many "
-           "iterations as its busiest lane (DESIGN.md s3).  At the end of every 64-row group the text of its matches (the 32 bytes before each end) is read again -- FETCH_SIZE says mostly from HBM: the lines have left the L2 by then.  The written bytes are several "
-           "times the results (4-byte stores into per-row slots, filed as the matches are found: partial lines leave the L2 before a row's next match arrives).")
+out.append("\nRound 3: for the dictionary (a keyword union) the program is the refined \"lengths\" automaton (DESIGN.md s3): the state a search ends in says how long "
+           "its match was, start = end - pend[state] -- no starts phase, no backward walks, and FETCH_SIZE is the batch exactly once (round 2: 6.2 GB).  The walk kernel is "
+           "VALU-issue bound, not HBM bound: an iteration walks a whole 16-byte piece for every lane under the cursor guard and a tile takes as many iterations as its "
+           "busiest lane.  The written bytes are several times the results: every match is two 4-byte stores into the per-row slot blocks of two arrays, filed as the "
+           "matches are found -- the partial sectors leave the L2 before the row's next match arrives.  c2 / c5 / c3s: patterns with unbounded match lengths, or a refined "
+           "automaton that does not fit the LDS as a plain table (c3s), keep indexBackwards at the end of every 64-row group.")
 open(os.path.join(root, "profiles", "r03_find_all.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

@@ -37,7 +37,11 @@ def _find_all_by_lengths(ml, class_map, _unused_max_char, text):
         cursor = last
 
 
-KEYWORDS = ["abc|bcd|cdefg|a|xyzzy|zzy", "Sherlock|Holmes|Watson|Irene|Adler|John|Baker", "(ab|a|bcdef|g)", "aab|ab|b", "ab?c|abc?d",
+# (the last rows: alternatives whose ORDER decides what indexBackwards reports -- the reversed automaton is pruned by priority, so
+# `bc|abc` finds "bc" inside "abc" -- and cases a GPU fuzz campaign caught when the analysis modelled "the longest match" instead)
+KEYWORDS = ["bc|abc", "zzy|xyzzy", "abc|bc", r"(\D|(.|b)([a-cx-z]|1))c", r"A|(\w)?.([a-cx-z]|(B|[x-z0]))", r"[^0-9a-f]|c[a\d]",
+            r"(y|((\x41|[a-zA-Z])[^0-9a-f]|(.|a)中|a))",
+            "abc|bcd|cdefg|a|xyzzy|zzy", "Sherlock|Holmes|Watson|Irene|Adler|John|Baker", "(ab|a|bcdef|g)", "aab|ab|b", "ab?c|abc?d",
             "http://|https://|ftp|tp:", "[ab]c|a[bc]d|[abc]{4}", "(foo|foobar|bar|barbaz|baz)", "a.c|ab"]
 
 
@@ -50,7 +54,7 @@ def test_lengths_automaton_equals_repeated_find(regex, oracle_lib):
     assert ml is not None, regex
     t = p.tables()
     cm, mc = t["class_map"], t["dfas"]["forwards"]["max_char"]
-    alphabet = sorted(set(ord(c) for c in regex if c.isalnum() or c in ":/. ")) + [ord(" "), ord("~"), 200]
+    alphabet = sorted(set(ord(c) for c in regex if ord(c) < 256 and (c.isalnum() or c in ":/. "))) + [ord(c) for c in " ~_\n019xyzAB"] + [200]
     rng = np.random.default_rng(7)
     for trial in range(400):
         n = int(rng.integers(0, 40))
@@ -78,3 +82,33 @@ def test_lengths_automaton_on_the_bench_dictionary(oracle_lib):
 def test_unbounded_or_empty_matches_are_refused(regex):
     from needle_amd.pattern import DFACompiler
     assert DFACompiler.compile(regex, "t", 0).match_length_automaton() is None
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_lengths_automaton_on_random_regexes(seed, oracle_lib):
+    """Seeded random regexes (the generator of tests/test_compile_vs_python_restatement.py) x flag sets: wherever the analysis
+    offers a refined automaton, walking it reports exactly the oracle's repeated find() on random haystacks."""
+    import random
+    from needle_amd.pattern import DFACompiler, PatternException
+    from test_compile_vs_python_restatement import FLAG_SETS, random_regex
+    rng = random.Random(7000 + seed)
+    nrng = np.random.default_rng(seed)
+    alphabet = [ord(c) for c in "abcxyz019 AB_\n."] + [0xE9, 0x416, 0x4E2D, 0xFFFF]
+    offered = 0
+    for _ in range(60):
+        regex, flags = random_regex(rng), rng.choice(FLAG_SETS)
+        try:
+            p = DFACompiler.compile(regex, "t", flags)
+            o, _ = oracle_for(regex, flags)
+        except (PatternException, ValueError):
+            continue
+        ml = p.match_length_automaton()
+        if ml is None:
+            continue
+        offered += 1
+        t = p.tables()
+        for trial in range(150):
+            n = int(nrng.integers(0, 40))
+            text = nrng.choice(alphabet, size=n).astype(np.uint16)
+            assert _find_all_by_lengths(ml, t["class_map"], 0, text.tolist()) == o.find_all(text), (regex, flags, text.tolist())
+    assert offered >= 5
