@@ -15,7 +15,9 @@ ALPHABET = [ord(c) for c in "abcxyz019 AB_\n."] + [0xE9, 0x416, 0x4E2D, 0xFFFF]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(4))
+# (5009, 5038, 5054: seeds on which round 3's find-all "lengths" form first disagreed with the reference -- order-sensitive
+# alternations, where indexBackwards does not report the longest match)
+@pytest.mark.parametrize("seed", list(range(4)) + [5009, 5038, 5054])
 def test_random_regexes_on_random_haystacks(seed):
     import torch
     from needle_amd.pattern import PatternException, unpack_bitmap
