@@ -28,6 +28,8 @@ hipError_t launch_spec_init(const SpecArgs &a, hipStream_t stream);
 hipError_t launch_spec_fix(const SpecArgs &a, hipStream_t stream);
 hipError_t launch_spec_reduce(const SpecArgs &a, hipStream_t stream);
 hipError_t launch_backward_rows(int char_width, const StripeArgs &a, hipStream_t stream);
+bool dict_kernel_applies(int char_width, const ScanArgs &a);                      // needle_dict.hip: two row sets per wave
+hipError_t launch_dict(int op, const ScanArgs &a, int n_cus, hipStream_t stream);
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
 } // namespace needle
@@ -416,6 +418,37 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     skip_backward = skip_backward || dbg_no_backward;
 #endif
     if (skip_backward && op == OP_FIND) a.fixed_len = 0, a.bprog = nullptr;
+    // Big automata on full 8-bit rows: two 64-row sets per wave (needle_dict.hip) over the whole 128-row pairs of the batch, the
+    // ordinary kernel on what is left; find()'s starts by indexBackwards afterwards, one lane per matched row.
+    // NEEDLE_DICT: 0 off, 1 on for the compressed automaton (default), 2 also for plain uint16 LDS tables.
+    static const int dict_env = getenv("NEEDLE_DICT") ? atoi(getenv("NEEDLE_DICT")) : 1;
+    if (dict_env > 0 && (a.hdr.mode == MODE_SPARSE || dict_env > 1) && dict_kernel_applies((int)v->char_width, a)) {
+        HIP_TRY(launch_dict(op, a, n_cus, (hipStream_t)stream));
+        const uint64_t done_rows = (a.n_rows >> 7) << 7;
+        if (op == OP_FIND && a.fixed_len < 0 && done_rows) {
+            StripeArgs ba;
+            memset(&ba, 0, sizeof(ba));
+            ba.rows = a.rows;
+            ba.n_rows = done_rows;
+            ba.stride_bytes = a.stride_bytes;
+            ba.prog = fp->d_blob;
+            ba.hdr = fp->prog.hdr;
+            ba.bitmap = d_bitmap;
+            ba.start = d_start;
+            ba.end = d_end;
+            ba.fixed_len = -1;
+            ba.op = OP_FIND;
+            ba.bprog = bp->d_blob;
+            ba.bhdr = bp->prog.hdr;
+            HIP_TRY(launch_backward_rows((int)v->char_width, ba, (hipStream_t)stream));
+        }
+        if (done_rows == a.n_rows) return NEEDLE_OK;
+        a.rows += done_rows * a.stride_bytes; // the last n_rows % 128 rows
+        a.n_rows -= done_rows;
+        a.total_bytes = a.n_rows * a.stride_bytes;
+        a.bitmap += done_rows >> 6;
+        if (a.start) a.start += done_rows, a.end += done_rows;
+    }
     HIP_TRY(launch_scan(op, (int)v->char_width, a, n_cus, (hipStream_t)stream));
     return NEEDLE_OK;
 }
