@@ -420,8 +420,9 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     if (skip_backward && op == OP_FIND) a.fixed_len = 0, a.bprog = nullptr;
     // Big automata on full 8-bit rows: two 64-row sets per wave (needle_dict.hip) over the whole 128-row pairs of the batch, the
     // ordinary kernel on what is left; find()'s starts by indexBackwards afterwards, one lane per matched row.
-    // NEEDLE_DICT: 0 off, 1 on for the compressed automaton (default), 2 also for plain uint16 LDS tables.
-    static const int dict_env = getenv("NEEDLE_DICT") ? atoi(getenv("NEEDLE_DICT")) : 1;
+    // NEEDLE_DICT: 0 off (default: measured, it is no faster -- DESIGN.md s4), 1 on for the compressed automaton, 2 also for
+    // plain uint16 LDS tables.
+    static const int dict_env = getenv("NEEDLE_DICT") ? atoi(getenv("NEEDLE_DICT")) : 0;
     if (dict_env > 0 && (a.hdr.mode == MODE_SPARSE || dict_env > 1) && dict_kernel_applies((int)v->char_width, a)) {
         HIP_TRY(launch_dict(op, a, n_cus, (hipStream_t)stream));
         const uint64_t done_rows = (a.n_rows >> 7) << 7;

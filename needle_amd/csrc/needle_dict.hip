@@ -133,9 +133,15 @@ __global__ __launch_bounds__(kDictWaves * 64) void dict_kernel(const ScanArgs a)
                     *(lds_u32x4 *)(uintptr_t)(tile0 + (uint32_t)s * kDictSetTile + 1024u + st_addr) = R[s][t][1];
                 }
                 asm volatile("" ::: "memory");
-                if (have_next) {
-                    fetch_quarter(ng, nl, 0, t);
-                    fetch_quarter(ng, nl, 1, t);
+                // the next line is requested WHOLE, its four quarters back to back, once the last quarter of this one is staged
+                // (asking for each quarter as its registers come free would spread a line's four requests over a tile walk each --
+                // long enough for the line to leave the vector L1 and the L2 in between: up to four fetches of every line)
+                if (t == 3 && have_next) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        fetch_quarter(ng, nl, 0, tt);
+                        fetch_quarter(ng, nl, 1, tt);
+                    }
                 }
                 asm volatile("" ::: "memory");
                 const uint32_t idx0 = line * 128u + (uint32_t)t * kDictTileB;

@@ -52,3 +52,14 @@ def test_survivor_pool_matches_oracle(defer, lo, hi, mode):
     r = subprocess.run([sys.executable, "-c", CODE, str(lo), str(hi), str(mode)], env=env, capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
     assert "POOL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lo,hi,mode,dict_mode", [(6, 8, 6, "1"), (3, 5, 2, "2")])
+def test_two_sets_per_wave_kernel_matches_oracle(lo, hi, mode, dict_mode):
+    """needle_dict.hip (opt-in, NEEDLE_DICT): two 64-row sets per wave, 32-byte tiles, find()'s starts by a separate backward
+    pass -- the 60 000 x 256 full-row batch of the child takes it (the ragged / short / odd-stride batches the ordinary kernel)."""
+    env = dict(os.environ, NEEDLE_DICT=dict_mode)
+    r = subprocess.run([sys.executable, "-c", CODE, str(lo), str(hi), str(mode)], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert "POOL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
