@@ -51,7 +51,7 @@ class PatternInfo(ctypes.Structure):
 
 class ProgramInfo(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ("mode", "n_states", "lds_bytes", "blob_bytes", "waves", "tile_bytes",
-                                              "dense_rows", "records", "chains", "hot_rows", "window", "window_lo", "window_hi")]
+                                              "dense_rows", "records", "chains", "hot_rows", "window", "window_lo", "window_hi", "lengths_form")]
 
 
 _lib = None

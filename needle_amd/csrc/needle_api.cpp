@@ -108,6 +108,7 @@ struct needle_pattern {
     //          3 HBM-table layout forced (column maps + uint16 table in one blob: the speculative-stripe fix-up walks it)
     //          4 / 5 as 0 / 2 without the pair table (the one-pass find-all kernel)
     //          6 the find-all "lengths" automaton (W_FORWARDS only; absent when the pattern does not allow it)
+    //          7 the same for find() in the scan kernels
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
     int ml_state = 0;       // 0: not analysed yet, 1: find-all can report starts as end - length (ml), -1: it cannot
@@ -138,7 +139,8 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        if (variant == 6) { // find-all, "lengths" form: the refined forward automaton + pend[] (needle_lower.h)
+        if (variant == 6 || variant == 7) { // "lengths" form: the refined forward automaton + pend[] (needle_lower.h);
+                                            // 6: the find-all kernel's plain layout, 7: the scan kernels' (window addressing)
             if (p->ml_state == 0) {
                 p->ml = match_length_automaton(p->t);
                 p->ml_state = p->ml.ok ? 1 : -1;
@@ -147,7 +149,7 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
                 *out = nullptr;
                 return NEEDLE_OK;
             }
-            dp.prog = lower_match_lengths(p->t, p->ml, cw, max_prog_lds());
+            dp.prog = lower_match_lengths(p->t, p->ml, cw, max_prog_lds(), variant == 6);
             if (dp.prog.blob.empty()) { // (does not fit the LDS as a plain table: the ordinary program with backward walks)
                 p->cache.emplace(key, DevProgram());
                 *out = nullptr;
@@ -233,6 +235,13 @@ static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v
     (void)scratch_free(sa.fn, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "launch_long_rows");
     return NEEDLE_OK;
+}
+
+// NEEDLE_FIND_LENGTHS: 0 = find() always by forward + backward walks, 1 (default) = the "lengths" automaton where the ordinary
+// program is a plain LDS table, 2 = also instead of the pair table (measured slower: DESIGN.md s4)
+static bool find_lengths_for(uint32_t mode) {
+    static const int level = getenv("NEEDLE_FIND_LENGTHS") ? atoi(getenv("NEEDLE_FIND_LENGTHS")) : 1;
+    return level > 0 && (mode == MODE_TABLE8 || mode == MODE_TABLE16 || (level > 1 && mode == MODE_PAIR));
 }
 
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
@@ -387,6 +396,16 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // rows of tens of megabytes and more
     if (v->row_stride * v->char_width >= (1ull << 26))
         return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more are only supported on the stripe paths (automata of at most 5 states, or ones that re-synchronise; not with NEEDLE_LONG_ROWS=0, per-row cursors or empty-matching patterns)");
+    // find() whose pattern allows it: the "lengths" automaton -- the state the walk stops in remembers how long the match was,
+    // start = end - pend[state], no indexBackwards, no text snapshots (needle_lower.h).  Taken where the ordinary program is a
+    // plain LDS table (the modes pend[] can be indexed in).  NEEDLE_FIND_LENGTHS=0: off (A/B, tests).
+    bool lengths_form = false;
+    if (need_backward && !d_end_state && !no_backward && find_lengths_for(fp->prog.hdr.mode)) {
+        const DevProgram *lp = nullptr;
+        rc = get_program(p, W_FORWARDS, (int)v->char_width, 7, &lp, nullptr);
+        if (rc) return rc;
+        if (lp) fp = lp, lengths_form = true;
+    }
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = (const uint8_t *)v->rows;
@@ -401,7 +420,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     a.fixed_len = -1;
     if (op == OP_FIND) {
         a.fixed_len = p->t.fixed_len;
-        if (a.fixed_len < 0) {
+        if (a.fixed_len < 0 && !lengths_form) {
             rc = get_program(p, W_BACKWARDS, (int)v->char_width, 1, &bp, nullptr);
             if (rc) return rc;
             a.bprog = bp->d_blob;
@@ -423,7 +442,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // NEEDLE_DICT: 0 off (default: measured, it is no faster -- DESIGN.md s4), 1 on for the compressed automaton, 2 also for
     // plain uint16 LDS tables.
     static const int dict_env = getenv("NEEDLE_DICT") ? atoi(getenv("NEEDLE_DICT")) : 0;
-    if (dict_env > 0 && (a.hdr.mode == MODE_SPARSE || dict_env > 1) && dict_kernel_applies((int)v->char_width, a)) {
+    if (dict_env > 0 && !lengths_form && (a.hdr.mode == MODE_SPARSE || dict_env > 1) && dict_kernel_applies((int)v->char_width, a)) {
         HIP_TRY(launch_dict(op, a, n_cus, (hipStream_t)stream));
         const uint64_t done_rows = (a.n_rows >> 7) << 7;
         if (op == OP_FIND && a.fixed_len < 0 && done_rows) {
@@ -921,7 +940,15 @@ int needle_pattern_program_info(const needle_pattern *p, int which, int char_wid
     if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
     if (which < 0 || which > 2 || (char_width != 1 && char_width != 2)) return fail(NEEDLE_ERR_INVALID, "which / char_width out of range");
     memset(o, 0, sizeof(*o));
-    const Program pr = lower(p->t, (Which)which, char_width, max_prog_lds(), false, with_backward != 0 && which == W_FORWARDS && p->t.fixed_len < 0);
+    const bool backward = with_backward != 0 && which == W_FORWARDS && p->t.fixed_len < 0;
+    Program pr = lower(p->t, (Which)which, char_width, max_prog_lds(), false, backward);
+    if (backward && find_lengths_for(pr.hdr.mode)) { // (as run_dev chooses)
+        const MatchLengths ml = match_length_automaton(p->t);
+        if (ml.ok) {
+            Program lp = lower_match_lengths(p->t, ml, char_width, max_prog_lds(), false);
+            if (!lp.blob.empty()) pr = std::move(lp), o->lengths_form = 1;
+        }
+    }
     o->mode = (int32_t)pr.hdr.mode;
     o->n_states = (int32_t)pr.hdr.n_states;
     o->lds_bytes = (int32_t)pr.hdr.lds_bytes;

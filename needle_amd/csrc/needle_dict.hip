@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kDictWaves * 64) void dict_kernel(const ScanArgs a)
     wk.ncols_e = a.hdr.n_cols * ELEM;
     wk.pad_e = wk.pre_e = wk.pad_b = wk.pre_b = 0;
     wk.win_on = a.hdr.win_on, wk.win_lo = a.hdr.win_lo_e, wk.win_hi = a.hdr.win_hi_e;
-    wk.sp_chains = a.hdr.sp_chains, wk.sp_pad_ident = 0;
+    wk.sp_chains = a.hdr.sp_chains, wk.sp_pad_ident = 0, wk.dead_hi = 0;
     wk.table_off = a.hdr.off_table, wk.lane4 = 0, wk.gtable = nullptr, wk.hot_last = 0;
     const uint32_t accept_lo = a.hdr.accept_lo, start_state = a.hdr.start;
 

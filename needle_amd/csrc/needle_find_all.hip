@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
     wk.pad_b = wk.pre_b = 0;
     wk.table_off = a.hdr.off_table;
     wk.win_on = 0, wk.win_lo = 0, wk.win_hi = 0; // (the find-all programs are lowered without window addressing)
-    wk.sp_chains = 0, wk.sp_pad_ident = 0;
+    wk.sp_chains = 0, wk.sp_pad_ident = 0, wk.dead_hi = 0;
     wk.lane4 = (uint32_t)lane * 4u; // packed mode on 8-bit rows: all 64 lane copies of F are there (no tiles in the F rows)
     wk.gtable = (const uint16_t *)(a.prog + (MODE == MODE_HYBRID ? a.hdr.off_gtable : a.hdr.off_table));
     wk.hot_last = a.hdr.hot_bytes - 2u;

@@ -379,18 +379,22 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
 } // namespace
 
 Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
-              bool with_backward_maps, bool no_pair) {
-    const RefDfa &d = t.dfa[which];
+              bool with_backward_maps, bool no_pair, const MatchLengths *ml) {
+    // ml (W_FORWARDS only): the refined "lengths" automaton stands in for the reference's search automaton (needle_lower.h)
+    const RefDfa &d = ml ? ml->dfa : t.dfa[which];
     const int N = t.stride;
     const int n_ref = d.n_states;
     const int n_dev = n_ref + 1;
     const int n_cols = N + 3, OVER = N, PAD = N + 1, PRE = N + 2;
 
-    // device numbering: 0 sink | non-accepting | accepting
+    // device numbering: 0 sink | [lengths form: the dead-with-a-match-pending states D_L, so that "the search is over" is
+    // state <= fa_dead_n] | non-accepting | accepting
     std::vector<int> dev(n_ref);
     int next_id = 1;
+    if (ml)
+        for (int s = 1; s <= ml->n_dead; ++s) dev[s] = next_id++;
     for (int s = 0; s < n_ref; ++s)
-        if (!d.accepting[s]) dev[s] = next_id++;
+        if (!d.accepting[s] && !(ml && s >= 1 && s <= ml->n_dead)) dev[s] = next_id++;
     const int accept_lo = next_id;
     for (int s = 0; s < n_ref; ++s)
         if (d.accepting[s]) dev[s] = next_id++;
@@ -412,6 +416,15 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         row[OVER] = (uint16_t)dead;
         row[PAD] = (which == W_MATCHES || contained) ? (uint16_t)dev[s] : (uint16_t)0;
         row[PRE] = (uint16_t)dev[s];
+        if (ml) {
+            // a char beyond the refined automaton's maxChar has a target of its own per state; the end of the row (PAD) ends the
+            // search like any dying transition: with a match pending it leads to D_L, not to the sink
+            row[OVER] = (uint16_t)(ml->over[s] < 0 ? 0 : dev[ml->over[s]]);
+            int dl = 0;
+            for (int k = 1; k <= ml->n_dead; ++k)
+                if (ml->pend[s] && ml->pend[k] == ml->pend[s]) dl = dev[k];
+            row[PAD] = (uint16_t)dl;
+        }
     }
 
     Program p;
@@ -458,7 +471,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     // when [state][col][col] fits, one lookup advances TWO chars.  NEEDLE_PAIR_MAX_BYTES=0 turns it off (A/B, tests).
     static const size_t pair_budget = getenv("NEEDLE_PAIR_MAX_BYTES") ? (size_t)atol(getenv("NEEDLE_PAIR_MAX_BYTES")) : (size_t)(96u << 10);
     const size_t pair_bytes = (size_t)n_dev * n_cols * n_cols * 2;
-    if (!no_pair && mode == MODE_TABLE8 && char_width == 1 && pair_bytes <= pair_budget && pair_bytes + 4096 <= lds_table_budget) mode = MODE_PAIR;
+    if (!no_pair && !ml && mode == MODE_TABLE8 && char_width == 1 && pair_bytes <= pair_budget && pair_bytes + 4096 <= lds_table_budget) mode = MODE_PAIR;
 
     // Window addressing for the table modes (needle_device.h; not for the plain layouts other kernels walk: global_walk, the
     // HBM-table variant with no LDS budget, the find-all programs).  NEEDLE_WINDOW=0 turns it off (A/B, tests).
@@ -688,7 +701,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         if (char_width == 2 && (uint32_t)n_cols * elem > 255u && !win.ok) mode = MODE_GLOBAL; // pages hold column * elem in a byte
         build(mode);
         bool sparse_done = false;
-        if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget && !no_pair) {
+        if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget && !no_pair && !ml) {
             // Too big for a dense table in LDS.  First choice: the compressed whole-automaton form (MODE_SPARSE, above).
             // NEEDLE_SPARSE=0 turns it off (A/B, tests of the hot-rows mode); NEEDLE_SPARSE_ROOM: LDS bytes the program may take
             // (default: what leaves room for 16 waves x 64-byte tiles).
@@ -851,6 +864,22 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     }
     while (p.blob.size() % 16) p.blob.push_back(0);
     p.hdr.mode = mode;
+    if (ml) {
+        // pend[] by DEVICE state rides in the LDS part; only the plain table modes number states the way it is indexed
+        if (mode != MODE_TABLE8 && mode != MODE_TABLE16) {
+            p.blob.clear();
+            p.hdr.mode = MODE_GLOBAL;
+            return p;
+        }
+        std::vector<uint8_t> pend_dev(n_dev, 0);
+        for (int s = 0; s < n_ref; ++s) pend_dev[dev[s]] = ml->pend[s];
+        p.hdr.fa_len_off = (uint32_t)p.blob.size();
+        p.blob.insert(p.blob.end(), pend_dev.begin(), pend_dev.end());
+        while (p.blob.size() % 16) p.blob.push_back(0);
+        p.hdr.lds_bytes = (uint32_t)p.blob.size();
+        p.hdr.fa_dead_lo = 1;
+        p.hdr.fa_dead_n = (uint32_t)ml->n_dead;
+    }
     return p;
 }
 
@@ -1051,57 +1080,9 @@ MatchLengths match_length_automaton(const RefTables &t) {
     return out;
 }
 
-Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget) {
-    RefTables t2 = t;
-    t2.dfa[W_FORWARDS] = ml.dfa;
-    Program p = lower(t2, W_FORWARDS, char_width, lds_table_budget, false, false, true);
-    if (p.hdr.mode != MODE_TABLE8 && p.hdr.mode != MODE_TABLE16) { // (the other modes number or store states their own way)
-        p.blob.clear();
-        p.hdr.mode = MODE_GLOBAL;
-        return p;
-    }
-    // device ids as lower() hands them out: 0 sink | non-accepting in ref order | accepting in ref order
-    const int n_ref = ml.dfa.n_states, n_cols = (int)p.hdr.n_cols, N = t.stride;
-    std::vector<int> dev(n_ref);
-    int next_id = 1;
-    for (int s = 0; s < n_ref; ++s)
-        if (!ml.dfa.accepting[s]) dev[s] = next_id++;
-    for (int s = 0; s < n_ref; ++s)
-        if (ml.dfa.accepting[s]) dev[s] = next_id++;
-    const uint32_t elem = p.hdr.mode == MODE_TABLE16 ? 2u : 1u;
-    auto put = [&](int s_dev, int col, int v) {
-        const size_t o = p.hdr.off_table + ((size_t)s_dev * n_cols + col) * elem;
-        p.blob[o] = (uint8_t)(v & 255);
-        if (elem == 2) p.blob[o + 1] = (uint8_t)(v >> 8);
-    };
-    // the end of the row (PAD) ends the search like any dying transition: with a match pending it leads to D_L, not to the
-    // sink; OVER (a char beyond the refined automaton's maxChar = the smaller of the two automata's) has a target of its own
-    // per state (lower() sends both to the sink for the index walks)
-    std::vector<uint8_t> pend_dev(n_ref + 1, 0);
-    auto dead_ref = [&](int L) { // ref id of D_L
-        for (int k = 1; k <= ml.n_dead; ++k)
-            if (ml.pend[k] == L) return k;
-        return -1;
-    };
-    for (int s = 0; s < n_ref; ++s) {
-        pend_dev[dev[s]] = ml.pend[s];
-        const int L = ml.pend[s];
-        put(dev[s], N, ml.over[s] < 0 ? 0 : dev[ml.over[s]]); // OVER: beyond the refined automaton's maxChar
-        put(dev[s], N + 1, L ? dev[dead_ref(L)] : 0);         // PAD: the row's end
-    }
-    while (p.blob.size() % 16) p.blob.push_back(0);
-    p.hdr.fa_len_off = (uint32_t)p.blob.size();
-    p.blob.insert(p.blob.end(), pend_dev.begin(), pend_dev.end());
-    while (p.blob.size() % 16) p.blob.push_back(0);
-    p.hdr.lds_bytes = (uint32_t)p.blob.size();
-    p.hdr.fa_dead_lo = (uint32_t)dev[1];
-    p.hdr.fa_dead_n = (uint32_t)ml.n_dead;
-    for (int k = 1; k <= ml.n_dead; ++k)
-        if (dev[k] != dev[1] + (k - 1)) { // (ref states 1 .. K are non-accepting and consecutive: so are their device ids)
-            p.blob.clear();
-            p.hdr.mode = MODE_GLOBAL;
-        }
-    return p;
+Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget, bool plain) {
+    // plain: the find-all kernel's form (no pair table, no window addressing, no compressed automaton); else the scan kernel's
+    return lower(t, W_FORWARDS, char_width, lds_table_budget, false, false, plain, &ml);
 }
 
 } // namespace needle

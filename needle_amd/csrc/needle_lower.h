@@ -43,8 +43,9 @@ bool validate_tables(const RefTables &t, std::string &err);
 // read from global memory (used for the backward automaton of find()).
 // `with_backward_maps` (W_FORWARDS only): append the backward automaton's char -> column maps to the blob.
 // `no_pair`: never the two-chars-per-lookup table (the find-all kernel walks from per-lane char positions).
+struct MatchLengths;
 Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
-              bool with_backward_maps = false, bool no_pair = false);
+              bool with_backward_maps = false, bool no_pair = false, const MatchLengths *ml = nullptr);
 
 // ---- find-all without backward walks (needle_find_all.hip, "lengths" form) -----------------------------------------
 // The reference finds a match's start by walking the reversed automaton back from its end (indexBackwards,
@@ -63,8 +64,9 @@ struct MatchLengths {
     int n_dead = 0;
 };
 MatchLengths match_length_automaton(const RefTables &t);
-// The device program of that automaton (table modes only; mode == MODE_GLOBAL with an empty blob when it does not fit the
-// LDS): hdr.fa_len_off = LDS offset of pend[] by DEVICE state, hdr.fa_dead_lo / fa_dead_n = device ids of the D_L states.
-Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget);
+// The device program of that automaton (plain table modes only; mode == MODE_GLOBAL with an empty blob when it does not fit
+// the LDS as one): hdr.fa_len_off = LDS offset of pend[] by DEVICE state, hdr.fa_dead_lo (= 1) / fa_dead_n = device ids of the
+// D_L states -- "the search is over" is state <= fa_dead_n.  plain: for the find-all kernel (no window addressing).
+Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget, bool plain = true);
 
 } // namespace needle

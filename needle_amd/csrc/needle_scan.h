@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     wk.win_on = a.hdr.win_on;
     wk.win_lo = a.hdr.win_lo_e;
     wk.win_hi = a.hdr.win_hi_e;
+    wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_n : 0u; // (fa_dead_lo == 1: the D_L states follow the sink)
     wk.sp_chains = a.hdr.sp_chains;
     wk.sp_pad_ident = a.hdr.sp_pad_ident;
     // (window addressing: column offsets are not rebased -- wraps are fine in 32-bit address math; the compressed form carries
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         }
         }
         if (OP == OP_FIND) {
-            if (a.fixed_len < 0) { // wave-uniform
+            if (a.fixed_len < 0 && !a.hdr.fa_len_off) { // wave-uniform (a "lengths" program needs no text for its starts)
                 if (last_rel >= 0) {
                     const uint32_t pi = ((uint32_t)(last_rel - 1) * CW) >> 4; // tile piece holding the accepting char
                     snapA = tile_piece<CHB>(tile, lane, (int)pi);
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         // wave-uniform early exit: every lane has an absorbing verdict (sink, or accepted for containedIn)
         bool live;
         if (OP == OP_CONTAINED_IN) live = st < accept_lo;
-        else live = st != 0;
+        else live = st > wk.dead_hi;
         if (GUARD) live = live && (idx0 + CHB / CW < len);
         return __ballot(live);
     };
@@ -315,6 +316,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         const int32_t e = res ? last : -1;
         if (a.fixed_len >= 0) {
             s = res ? last - a.fixed_len : -1; // :640-646
+        } else if (a.hdr.fa_len_off) {
+            // the "lengths" automaton (needle_lower.h): the state the walk stopped in -- a dead-with-a-match-pending state D_L,
+            // or at the row's end any state -- remembers how long its last match was: :640-646 generalised per state, no
+            // indexBackwards
+            s = res ? last - (int32_t)lds_u8(a.hdr.fa_len_off + st) : -1;
         } else {
             // indexBackwards(end - 1, 0), :536-583.  Column map in LDS, row bytes (L2-hot) fetched 8 at a time,
             // backward table walked out of HBM/L2.

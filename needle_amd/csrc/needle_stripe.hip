@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
     __syncthreads();
     Walk wk;
     wk.ncols_e = 0, wk.pad_e = a.hdr.pad_f, wk.pre_e = a.hdr.pre_f, wk.table_off = 0, wk.gtable = nullptr;
-    wk.win_on = 0, wk.win_lo = 0, wk.win_hi = 0, wk.sp_chains = 0, wk.sp_pad_ident = 0;
+    wk.win_on = 0, wk.win_lo = 0, wk.win_hi = 0, wk.sp_chains = 0, wk.sp_pad_ident = 0, wk.dead_hi = 0;
     wk.lane4 = (uint32_t)(lane & 31) * 4u;
     constexpr int CPL = 64 / CW; // chars per lane and stripe
     const uint32_t accept_lo = a.hdr.accept_off;
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
     wk.table_off = a.hdr.off_table - a.hdr.win_lo_e; // (window addressing, needle_device.h)
     wk.win_on = a.hdr.win_on, wk.win_lo = a.hdr.win_lo_e, wk.win_hi = a.hdr.win_hi_e;
     wk.sp_chains = 0, wk.sp_pad_ident = 0;
+    wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_n : 0u;
     wk.lane4 = (uint32_t)(lane & 31) * 4u;
     wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
     const uint32_t accept_lo = MODE == MODE_PACK ? a.hdr.accept_off : a.hdr.accept_lo;
@@ -679,6 +680,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
             const int32_t e = res ? last : -1;
             if (a.fixed_len >= 0) {
                 s = res ? last - a.fixed_len : -1; // :640-646
+            } else if (a.hdr.fa_len_off) { // the "lengths" automaton: the end state remembers the match length (needle_scan.h)
+                s = res ? last - (int32_t)lds_u8(a.hdr.fa_len_off + st) : -1;
             } else if (a.short_window) {
                 // indexBackwards(end - 1, FROM), :536-583, on the row's text parked in this lane's LDS slot (it is in
                 // registers, which cannot be indexed per lane): one ds_read per char instead of a load from L2, and the packed /

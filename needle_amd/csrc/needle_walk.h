@@ -143,6 +143,8 @@ struct Walk {
     const uint16_t *gtable; // MODE_GLOBAL / MODE_HYBRID: the whole table in HBM
     uint32_t hot_last;      // MODE_HYBRID: byte offset of the last table entry held in LDS (hot_bytes - 2)
     uint32_t win_on, win_lo, win_hi; // window addressing (needle_device.h): clamp bounds of char * element size
+    uint32_t dead_hi;       // find(): states 0 .. dead_hi end the search (0: the sink alone; the "lengths" programs add their
+                            // dead-with-a-match-pending states D_L, needle_lower.h)
     uint32_t sp_chains;     // MODE_SPARSE: some state has more than one exception record (wave-uniform)
     uint32_t sp_pad_ident;  // MODE_SPARSE: PAD is the identity (matches / containedIn) rather than the way to the sink
 };
@@ -365,7 +367,7 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
     // conflicts it would cause disappear.  (Packed mode is conflict-free by construction: no masking.)
     bool lane_live = true;
     if (MODE != MODE_PACK && NEEDLE_MASK_DONE_LANES)
-        lane_live = (OP == OP_CONTAINED_IN) ? (st - 1u < accept_lo - 1u) : (st != 0u);
+        lane_live = (OP == OP_CONTAINED_IN) ? (st - 1u < accept_lo - 1u) : (st > wk.dead_hi);
     if (lane_live) {
     // all state-independent lookups of the piece first (they pipeline in the LDS) ...
     uint32_t col[CPP];

@@ -69,3 +69,20 @@ def test_small_automata(regex, mode):
         assert d["waves"] == 15 and p.program_info("contained_in")["waves"] == 16
     else:
         assert d["waves"] >= 12
+
+
+def test_find_takes_the_lengths_form_on_lds_tables():
+    """find() on an LDS-table automaton whose pattern allows it (bounded match length, not nullable) is lowered as the
+    "lengths" automaton (needle_lower.h: start = end - the length the stop state remembers; DFAClassBuilder.java:640-656
+    generalised per state) -- no backward program; NEEDLE_FIND_LENGTHS=0 brings the indexBackwards form back; the
+    compressed form (mode 6) and unbounded patterns keep it."""
+    i = _info(3, 5, 1000)
+    assert i["forwards"]["mode"] == 2 and i["forwards"]["lengths_form"] == 1
+    assert i["contained_in"]["lengths_form"] == 0
+    off = _info(3, 5, 1000, NEEDLE_FIND_LENGTHS="0")
+    assert off["forwards"]["mode"] == 2 and off["forwards"]["lengths_form"] == 0
+    assert off["forwards"]["n_states"] <= i["forwards"]["n_states"]
+    assert _info(6, 8, 1000)["forwards"]["lengths_form"] == 0
+    from needle_amd.pattern import DFACompiler
+    assert DFACompiler.compile("[0-9]+x", "t", 0).program_info("forwards", 1)["lengths_form"] == 0  # unbounded
+    assert DFACompiler.compile("(ab|a|bcdef|g)x", "t", 0).program_info("forwards", 1)["lengths_form"] in (0, 1)
