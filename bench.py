@@ -551,6 +551,15 @@ def measure(workload, args, ctx, headline):
                            "slots": slots, "more": bool(more), "GB/s": fa_bytes / dt / 1e9, "algorithmic_bytes": fa_bytes,
                            "kernel": "needle::find_all_kernel",
                            "note": "every non-overlapping match per row (repeated Matcher.find()), one pass; bytes = rows + 4 B count per row + 8 B per match"}
+        # the same with each match as one dword (needle_find_all_packed16_dev: start | end << 16): one result line per row
+        t = time.perf_counter()
+        for _ in range(k2):
+            pattern.find_all_dense_packed16(rows, slots, out=(fc, fs))
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t) / k2
+        assert int(fc.sum().item()) == n_matches and ((fs >> 16) & 0xFFFF)[:, 0][fc > 0].eq(fe[:, 0][fc > 0]).all()
+        out["find_all"]["packed16"] = {"ms_per_step": dtp * 1e3, "matches_per_s": n_matches / dtp,
+                                       "algorithmic_bytes": n_rows * (256 * cw + 4) + 4 * n_matches}
         del fc, fs, fe
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(workload, pattern, rows, op_name, 10.0 if headline else 4.0)

@@ -1143,7 +1143,8 @@ static int find_all_rounds(const needle_pattern *p, const needle_batch_view *v, 
 // One pass over the batch: every row is fetched once, each lane restarts its search where its last match ended
 // (needle_find_all.hip).  Dense slots (offsets == nullptr), compact filing at caller-computed offsets, or counting only.
 static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
-                             int32_t *d_end, const uint64_t *d_offsets, bool count_only, int *more, hipStream_t stream) {
+                             int32_t *d_end, const uint64_t *d_offsets, bool count_only, int *more, hipStream_t stream,
+                             uint32_t *d_packed = nullptr) {
     const uint64_t stride_bytes = v->row_stride * v->char_width;
     if (stride_bytes >= (1ull << 26)) return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more: only needle_find_all_dev (round per match) takes them");
     const DevProgram *fp = nullptr, *bp = nullptr;
@@ -1193,6 +1194,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     fa.counts = d_counts;
     fa.starts = d_start;
     fa.ends = d_end;
+    fa.packed = d_packed;
     int32_t *d_more = nullptr;
     HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
     auto done = [&](int code) {
@@ -1226,6 +1228,20 @@ int needle_find_all_dev(const needle_pattern *cp, const needle_batch_view *v, ui
     static const bool rounds = getenv("NEEDLE_FIND_ALL_ROUNDS") && atoi(getenv("NEEDLE_FIND_ALL_ROUNDS")) != 0;
     if (rounds || v->row_stride * v->char_width >= (1ull << 26)) return find_all_rounds(p, v, slots, d_counts, d_start, d_end, more, stream);
     return find_all_one_pass(p, v, slots, d_counts, d_start, d_end, nullptr, false, more, stream);
+}
+
+// needle_find_all_dev with each match as ONE dword (start | end << 16): half the result bytes, one store per match.
+int needle_find_all_packed16_dev(const needle_pattern *cp, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts,
+                                 uint32_t *d_start_end16, int *more, void *stream_) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, true);
+    if (rc) return rc;
+    if (more) *more = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_counts || (slots && !d_start_end16)) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    if (v->row_stride > 65535u) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit start / end: rows of at most 65535 chars");
+    return find_all_one_pass(p, v, slots, d_counts, nullptr, nullptr, nullptr, false, more, (hipStream_t)stream_, d_start_end16);
 }
 
 int needle_count_matches_dev(const needle_pattern *cp, const needle_batch_view *v, uint32_t *d_counts, void *stream_) {

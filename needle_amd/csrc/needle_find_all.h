@@ -15,6 +15,8 @@ struct FindAllArgs {
     uint32_t *counts;  // [n_rows]
     int32_t *starts;   // [n_rows][slots]
     int32_t *ends;     // [n_rows][slots]
+    uint32_t *packed;  // != nullptr: [n_rows][slots] (or the compact filing) of start | end << 16 instead of starts / ends
+                       // (rows of at most 65 535 chars): one store per match, half the result lines
     int32_t *more;     // set to 1 when some row has a match beyond its last slot
     const uint64_t *offsets; // != nullptr: compact (CSR) filing -- match k of row r at offsets[r] + k, room for
                              // offsets[r + 1] - offsets[r] matches; slots is not used

@@ -242,8 +242,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 if (hit && !file) *fa.more = 1;
                 done = done || (hit && !file);
                 if (file && !fa.count_only) {
-                    fa.starts[out0 + count] = en - mlen;
-                    fa.ends[out0 + count] = en;
+                    if (fa.packed) {
+                        fa.packed[out0 + count] = (uint32_t)(en - mlen) | ((uint32_t)en << 16);
+                    } else {
+                        fa.starts[out0 + count] = en - mlen;
+                        fa.ends[out0 + count] = en;
+                    }
                 }
                 count += file ? 1u : 0u;
                 cursor = file ? en : cursor;
@@ -257,7 +261,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 const bool file = hit && count < cap;
                 if (hit && !file) *fa.more = 1;
                 done = done || (hit && !file);
-                if (file && !fa.count_only) fa.ends[out0 + count] = en; // (counting: nothing is filed)
+                if (file && !fa.count_only) { // (counting: nothing is filed)
+                    if (fa.packed) fa.packed[out0 + count] = (uint32_t)en << 16; // (the start joins it in starts_phase)
+                    else fa.ends[out0 + count] = en;
+                }
                 count += file ? 1u : 0u;
                 cursor = file ? en : cursor;
                 st = file ? start_state : st;
@@ -272,8 +279,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 if (valid) {
                     if (count < cap) {
                         if (!fa.count_only) {
-                            fa.starts[out0 + count] = s;
-                            fa.ends[out0 + count] = en;
+                            if (fa.packed) {
+                                fa.packed[out0 + count] = (uint32_t)s | ((uint32_t)en << 16);
+                            } else {
+                                fa.starts[out0 + count] = s;
+                                fa.ends[out0 + count] = en;
+                            }
                         }
                         ++count;
                         // the row goes on only while the cursor advances (needle_hip.h)
@@ -329,8 +340,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             const uint8_t *o_rowp = a.rows + ((grp << 6) + owner) * a.stride_bytes;
             int32_t en = 1, bound = 0;
             if (act) {
-                en = __hip_atomic_load(&fa.ends[o_out0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (k) bound = __hip_atomic_load(&fa.ends[o_out0 + k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fa.packed) {
+                    en = (int32_t)(__hip_atomic_load(&fa.packed[o_out0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
+                    if (k) bound = (int32_t)(__hip_atomic_load(&fa.packed[o_out0 + k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
+                } else {
+                    en = __hip_atomic_load(&fa.ends[o_out0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (k) bound = __hip_atomic_load(&fa.ends[o_out0 + k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             const uint32_t pa = ((uint32_t)(en - 1) * CW) >> 4; // window: the piece holding char en - 1 and the one before it
             const uint32_t pb = pa ? pa - 1u : 0u;
@@ -344,7 +360,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             const uint32_t win_b0 = pa ? pb * 16u : 0u;
             const uint32_t w_addr = pa ? tile.row_addr : tile.row_addr + 16u;
             const int32_t st_k = fa.defer == 2u ? bound : backward_walk<CW>(a, act, en, bound, w_addr, win_b0, pa ? 32u : 16u, 0u, o_rowp); // (2: measurement aid)
-            if (act) fa.starts[o_out0 + k] = st_k;
+            if (act) {
+                if (fa.packed) fa.packed[o_out0 + k] = (uint32_t)st_k | ((uint32_t)en << 16);
+                else fa.starts[o_out0 + k] = st_k;
+            }
         }
     };
     auto end_group = [&](uint64_t grp) __attribute__((always_inline)) {

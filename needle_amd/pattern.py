@@ -346,6 +346,27 @@ class Pattern:
                                          en.data_ptr(), ctypes.byref(more), s))
         return counts, st, en, bool(more.value)
 
+    def find_all_dense_packed16(self, rows, max_per_row, lengths=None, stream=None, out=None, want_more=True):
+        """needle_find_all_packed16_dev: as find_all_dense on device rows of at most 65 535 chars, each match one dword
+        (start | end << 16).  -> (counts int32[n], start_end16 int32[n, max_per_row] (bit pattern of the uint32), more: bool or
+        None when want_more is False -- the call is then asynchronous on the stream)."""
+        import torch
+        L = _lib.lib()
+        v, n = self._dev_view(rows, lengths), rows.shape[0]
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            if out is not None:
+                counts, se = out
+                assert counts.shape == (n,) and se.shape == (n, max_per_row)
+                assert all(t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() for t in out)
+            else:
+                counts = torch.zeros(n, dtype=torch.int32, device=rows.device)
+                se = torch.full((n, max_per_row), -1, dtype=torch.int32, device=rows.device)
+            more = ctypes.c_int(0)
+            _check(L.needle_find_all_packed16_dev(self._h, ctypes.byref(v), int(max_per_row), counts.data_ptr(), se.data_ptr(),
+                                                  ctypes.byref(more) if want_more else None, s))
+        return counts, se, (bool(more.value) if want_more else None)
+
     def _dev_view(self, rows, lengths):
         import torch
         assert isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dim() == 2 and rows.is_contiguous()

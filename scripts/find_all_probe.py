@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time needle_find_all_dev on a bench workload's rows (every non-overlapping match of every row):
+"""Time needle_find_all_dev (FIND_ALL_PROBE_PACKED=1: needle_find_all_packed16_dev) on a bench workload's rows (every non-overlapping match of every row):
 python scripts/find_all_probe.py <c2|c3|c3s|c5> [rows] [slots] [check]
 NEEDLE_FIND_ALL_ROUNDS=1: the round-per-match form; NEEDLE_FIND_ALL_DEFER=0: backward walks at once.
 check: compare a sample of rows with the oracle's repeated find()."""
@@ -30,12 +30,19 @@ while time.perf_counter() - tp < 0.15:
         scratch.copy_(rows)
     torch.cuda.synchronize()
 del scratch
+packed = bool(os.environ.get("FIND_ALL_PROBE_PACKED"))  # needle_find_all_packed16_dev: one dword per match
+out["form"] = "packed16" if packed else "start/end int32"
 for rep in range(4):
     t0 = time.perf_counter()
-    counts, st, en, more = pattern.find_all_dense(rows, slots, out=(counts, st, en))
+    if packed:
+        counts, st, more = pattern.find_all_dense_packed16(rows, slots, out=(counts, st))
+    else:
+        counts, st, en, more = pattern.find_all_dense(rows, slots, out=(counts, st, en))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     best = dt if best is None or (rep and dt < best) else best
+if packed:
+    st, en = st & 0xFFFF, (st >> 16) & 0xFFFF
 out["ms"] = round(best * 1e3, 3)
 total = int(counts.sum().item())
 out["matches"] = total

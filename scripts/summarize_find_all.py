@@ -28,6 +28,18 @@ for w in ("c3", "c2", "c5", "c3s"):
     out.append("| %s | %d | %d | %.3f | %.1f (%d) | %.1f | %.0f | %.2f | %.1fx | %.2f | %.2f |" % (
         w, one["matches"], one["max_per_row"], one["ms"], k_avg, calls, one["matches"] / (k_avg * 1e-6) / 1e9,
         one["rows"] * 256 * (2 if w == "c5" else 1) / (k_avg * 1e-6) / 1e9, rnd["ms"], rnd["ms"] / one["ms"], one.get("count_ms", 0), one.get("csr_ms", 0)))
+# the dictionary with one dword per match (needle_find_all_packed16_dev)
+pk = json.loads(open(os.path.join(src, "c3_packed.json")).read().strip().splitlines()[-1])
+pk_k = sum(float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(src, "c3_packed", "t_kernel_stats.csv"))) if "find_all_kernel" in r["Name"])
+shutil.copy(os.path.join(src, "c3_packed", "t_kernel_stats.csv"), os.path.join(root, "profiles", "r03_find_all_c3_packed16_kernel_stats.csv"))
+pk_t = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    pk_t[c] = float(open(os.path.join(src, "packed_%s.txt" % c)).read().split()[1])
+pk_bytes = pk_t["FETCH_SIZE"] * 2048 + pk_t["WRITE_SIZE"] * 1024
+out.append("\n`needle_find_all_packed16_dev` (each match one dword, start | end << 16; the same kernel, one store per match) on c3: probe %.3f ms, kernel %.1f µs, "
+           "%d matches (%d of 300 sampled rows differ from the oracle's repeated find()); FETCH_SIZE %.2f GB + WRITE_SIZE %.2f GB = **%.2f GB per launch** "
+           "= %.2f x (rows + 4 B per row + 4 B per match).\n" % (pk["ms"], pk_k, pk["matches"], pk.get("bad", -1), pk_t["FETCH_SIZE"] * 2048 / 1e9, pk_t["WRITE_SIZE"] * 1024 / 1e9,
+                                                               pk_bytes / 1e9, pk_bytes / (1e7 * 260 + 4 * pk["matches"])))
 pmc = {}
 for line in open(os.path.join(src, "pmc_c3.txt")):
     m = re.match(r"(\w+)\s+([0-9.e+]+)$", line.strip())
@@ -65,8 +77,9 @@ out.append("| HBM bytes per launch / (rows + 4 B per row + 8 B per match) | %.2f
 out.append("\nRound 3: for the dictionary (a keyword union) the program is the refined \"lengths\" automaton (DESIGN.md s3): the state a search ends in says how long "
            "its match was, start = end - pend[state] -- no starts phase, no backward walks, and FETCH_SIZE is the batch exactly once (round 2: 6.2 GB).  The walk kernel is "
            "VALU-issue bound, not HBM bound: an iteration walks a whole 16-byte piece for every lane under the cursor guard and a tile takes as many iterations as its "
-           "busiest lane.  The written bytes are several times the results: every match is two 4-byte stores into the per-row slot blocks of two arrays, filed as the "
-           "matches are found -- the partial sectors leave the L2 before the row's next match arrives.  c2 / c5 / c3s: patterns with unbounded match lengths, or a refined "
+           "busiest lane.  The written bytes are several times the results, and exactly the slot arrays: with 32 slots a row's block is one 128-byte line in each of the two "
+           "arrays, almost every row has a match, and a line leaves the L2 whole -- 2 x 128 B x 10^7 rows = 2.56 GB whatever the order of the stores (each line is "
+           "written once: staging the stores in LDS would not change the count).  The packed form above halves it -- one array, one line per row.  c2 / c5 / c3s: patterns with unbounded match lengths, or a refined "
            "automaton that does not fit the LDS as a plain table (c3s), keep indexBackwards at the end of every 64-row group.")
 open(os.path.join(root, "profiles", "r03_find_all.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

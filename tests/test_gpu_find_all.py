@@ -230,3 +230,35 @@ def test_csr_host_dense_matches_bounded_results():
     env = dict(os.environ, NEEDLE_HOST_RESULT_BYTES="8192")
     r = subprocess.run([sys.executable, "-c", DENSE_HOST], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert "DENSE-HOST-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("regex", ["Sherlock|Holmes|Watson|ab|abc|bc", "[0-9]+", "(ab|a|bcdef|g)+", "a*", "a.c"])
+@pytest.mark.parametrize("cw", [1, 2])
+def test_packed16_form_equals_the_two_array_form(regex, cw):
+    """needle_find_all_packed16_dev (one dword per match: start | end << 16) files what needle_find_all_dev files -- the
+    lengths-automaton walk, the deferred starts phase (the end travels in the high half until the backward walk adds the
+    start) and the immediate form of nullable patterns; full and ragged rows, too few slots included."""
+    import torch
+    from needle_amd.pattern import DFACompiler
+    p = DFACompiler.compile(regex, "t", 0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    lut = torch.tensor([ord(c) for c in "abcdefg019 SherlockHmsWtn"], dtype=torch.uint8, device="cuda")
+    n = 20011
+    rows = lut[torch.randint(0, len(lut), (n, 112), device="cuda", generator=g)]
+    if cw == 2:
+        rows = rows.to(torch.int16)
+    lens = torch.randint(0, 113, (n,), device="cuda", generator=g).to(torch.int32)
+    for l in (None, lens):
+        for slots in (40, 3):
+            c0, s0, e0, m0 = p.find_all_dense(rows, slots, l)
+            c1, se, m1 = p.find_all_dense_packed16(rows, slots, l)
+            assert m0 == m1 and (c0 == c1).all()
+            assert int(c0.sum()) > n // 10
+            filed = torch.arange(slots, device="cuda")[None, :] < c0[:, None]
+            assert ((se & 0xFFFF)[filed] == s0[filed]).all() and (((se >> 16) & 0xFFFF)[filed] == e0[filed]).all()
+            assert (se[~filed] == -1).all()  # slots beyond the count stay untouched
+    wide = torch.zeros((2, 65536 + 16), dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception):
+        p.find_all_dense_packed16(wide, 4)
