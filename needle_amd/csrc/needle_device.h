@@ -93,6 +93,10 @@ struct ProgHeader {
     // find-all "lengths" form (needle_lower.h, MatchLengths): pend[] by device state in LDS; the dead-with-a-pending-match
     // states are the device ids fa_dead_lo .. fa_dead_lo + fa_dead_n - 1
     uint32_t fa_len_off, fa_dead_lo, fa_dead_n;
+    // find-all programs of that form also carry "skip" states: S_k (device id fa_skip_lo + k - 1) goes to S_(k-1) on EVERY
+    // column and S_1 to the start state -- a search restarted k chars into a 16-byte piece enters the piece in S_k and needs
+    // no per-char cursor guard (0: none)
+    uint32_t fa_skip_lo;
     uint32_t off_bpack;  // != 0: the backward automaton has <= 5 states and rides along as packed functions: 8-bit rows
                          // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)
                          // followed by its F area.  The backward walk then needs no state-dependent lookup.

@@ -42,7 +42,9 @@ namespace needle {
 // returns the flags of the piece's chars, char i at bit i.
 // CUT (the "lengths" form on the piece a ragged row ends in): chars from in_row on take the PAD column, which there leads
 // to the dead state that remembers the pending match -- the state the piece ends in is then the one the ROW ends in.
-template <int CW, int MODE, bool CUT = false>
+// SKIPST (programs with skip states, needle_device.h fa_skip_lo): no cursor guard at all -- a search restarted inside the piece
+// enters it in the skip state that swallows the chars before its cursor.
+template <int CW, int MODE, bool CUT = false, bool SKIPST = false>
 __device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t (&w)[4], uint32_t skip_rel, uint32_t accept_lo,
                                                   uint32_t &st, uint32_t in_row = 0) {
     constexpr int CPP = 16 / CW;
@@ -53,8 +55,10 @@ __device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t
 #pragma unroll
         for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < in_row) ? col[i] : wk.pad_e;
     }
+    if (!SKIPST) {
 #pragma unroll
-    for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < skip_rel) ? wk.pre_e : col[i];
+        for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < skip_rel) ? wk.pre_e : col[i];
+    }
     uint32_t h = 0;
     const uint32_t acc_m1 = accept_lo - 1u;
 #pragma unroll
@@ -69,7 +73,8 @@ __device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t
     return h >> (32 - CPP);
 }
 
-template <int CW, int MODE, int CHB>
+// LM: the "lengths" form (fa.lmode) of a program with skip states
+template <int CW, int MODE, int CHB, bool LM>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const FindAllArgs fa) {
     using G = Geom<CHB>;
     const ScanArgs &a = fa.s;
@@ -208,9 +213,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             const uint32_t skip_rel = (uint32_t)cursor > p0 ? (uint32_t)cursor - p0 : 0u; // < CPP: the cursor's piece, or none
             const uint32_t st_old = st;
             uint32_t st_new = st;
-            uint32_t acc = walk_piece_fa<CW, MODE>(wk, w, skip_rel, accept_lo, st_new);
+            uint32_t acc = walk_piece_fa<CW, MODE, false, LM>(wk, w, skip_rel, accept_lo, st_new);
             const uint32_t in_row = len > p0 ? len - p0 : 0u; // chars of the piece inside the row (all, if >= CPP)
-            acc &= ~((1u << skip_rel) - 1u);                   // an accepting start state does not count before the cursor
+            if (!LM) acc &= ~((1u << skip_rel) - 1u);          // an accepting start state does not count before the cursor
             acc &= in_row < (uint32_t)CPP ? (1u << in_row) - 1u : 0xFFFFFFFFu;
             acc = active ? acc : 0u;
             last = acc ? (int32_t)(p0 + 32u - (uint32_t)__builtin_clz(acc)) : last;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             const bool hit = ended && last >= 0;
             const int32_t en = last;
             if (ended && !hit) done = true; // no further match in this row
-            if (fa.lmode) {
+            if (LM || fa.lmode) {
                 // The "lengths" automaton (needle_lower.h): the state the search ended in remembers how long its last match
                 // was -- start = end - pend[state], no indexBackwards (DFAClassBuilder.java:640-646 generalised per state).
                 // A ragged row that ends INSIDE this piece was walked past its end above (harmless for the flags, which are
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                     const bool cut = hit && in_row < (uint32_t)CPP;
                     if (__ballot(cut) != 0ull) {
                         uint32_t st_fix = st_old;
-                        (void)walk_piece_fa<CW, MODE, true>(wk, w, skip_rel, accept_lo, st_fix, in_row);
+                        (void)walk_piece_fa<CW, MODE, true, LM>(wk, w, skip_rel, accept_lo, st_fix, in_row);
                         st_end = cut ? st_fix : st_end;
                     }
                 }
@@ -251,9 +256,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 }
                 count += file ? 1u : 0u;
                 cursor = file ? en : cursor;
-                st = file ? start_state : st;
+                const uint32_t pi_en = ((uint32_t)en * CW) >> 4;
+                uint32_t st_again = start_state;
+                if (LM) { // en - pi_en * CPP chars of the piece lie before the new cursor: S_k swallows them
+                    const uint32_t rel = (uint32_t)en - pi_en * (uint32_t)CPP;
+                    st_again = rel ? a.hdr.fa_skip_lo + rel - 1u : start_state;
+                }
+                st = file ? st_again : st;
                 last = file ? -1 : last;
-                pi = file ? (((uint32_t)en * CW) >> 4) : pi;
+                pi = file ? pi_en : pi;
             } else if (fa.defer) {
                 // not nullable, start by indexBackwards: the match is not empty and ends beyond its cursor -- the row goes on.
                 // Written as selects, not branches: this block runs in most iterations (some lane of 64 has just resolved)
@@ -433,9 +444,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-template <int CW, int MODE, int CHB>
+template <int CW, int MODE, int CHB, bool LM = false>
 static hipError_t launch_fa(const FindAllArgs &fa, int grid, int waves, size_t lds, hipStream_t stream) {
-    auto k = find_all_kernel<CW, MODE, CHB>;
+    auto k = find_all_kernel<CW, MODE, CHB, LM>;
     static thread_local uint64_t configured = 0;
     if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(waves * 64), lds, stream, fa);
@@ -443,6 +454,10 @@ static hipError_t launch_fa(const FindAllArgs &fa, int grid, int waves, size_t l
 }
 template <int CW, int MODE>
 static hipError_t launch_fa_h(const FindAllArgs &fa, int chb, int grid, int waves, size_t lds, hipStream_t s) {
+    if constexpr (MODE == MODE_TABLE8 || MODE == MODE_TABLE16) {
+        if (fa.lmode && fa.s.hdr.fa_skip_lo)
+            return chb == 128 ? launch_fa<CW, MODE, 128, true>(fa, grid, waves, lds, s) : launch_fa<CW, MODE, 64, true>(fa, grid, waves, lds, s);
+    }
     return chb == 128 ? launch_fa<CW, MODE, 128>(fa, grid, waves, lds, s) : launch_fa<CW, MODE, 64>(fa, grid, waves, lds, s);
 }
 template <int CW>

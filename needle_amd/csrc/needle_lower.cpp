@@ -384,7 +384,9 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     const RefDfa &d = ml ? ml->dfa : t.dfa[which];
     const int N = t.stride;
     const int n_ref = d.n_states;
-    const int n_dev = n_ref + 1;
+    // (the find-all form of the lengths automaton -- ml && no_pair -- carries skip states: needle_device.h fa_skip_lo)
+    const int n_skip = (ml && no_pair) ? 16 / char_width - 1 : 0;
+    const int n_dev = n_ref + 1 + n_skip;
     const int n_cols = N + 3, OVER = N, PAD = N + 1, PRE = N + 2;
 
     // device numbering: 0 sink | [lengths form: the dead-with-a-match-pending states D_L, so that "the search is over" is
@@ -393,6 +395,8 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     int next_id = 1;
     if (ml)
         for (int s = 1; s <= ml->n_dead; ++s) dev[s] = next_id++;
+    const int skip_lo = next_id;
+    next_id += n_skip;
     for (int s = 0; s < n_ref; ++s)
         if (!d.accepting[s] && !(ml && s >= 1 && s <= ml->n_dead)) dev[s] = next_id++;
     const int accept_lo = next_id;
@@ -425,6 +429,11 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                 if (ml->pend[s] && ml->pend[k] == ml->pend[s]) dl = dev[k];
             row[PAD] = (uint16_t)dl;
         }
+    }
+
+    for (int k = 1; k <= n_skip; ++k) { // S_k -> S_(k-1) on every column, S_1 -> the start state
+        uint16_t *row = &next[(size_t)(skip_lo + k - 1) * n_cols];
+        for (int c = 0; c < n_cols; ++c) row[c] = (uint16_t)(k == 1 ? dev[0] : skip_lo + k - 2);
     }
 
     Program p;
@@ -879,6 +888,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         p.hdr.lds_bytes = (uint32_t)p.blob.size();
         p.hdr.fa_dead_lo = 1;
         p.hdr.fa_dead_n = (uint32_t)ml->n_dead;
+        p.hdr.fa_skip_lo = n_skip ? (uint32_t)skip_lo : 0u;
     }
     return p;
 }

@@ -26,8 +26,9 @@ RND = "03"
 sets = [("c3s find: hot rows in LDS + HBM table (round 2's mode; NEEDLE_SPARSE=0 NEEDLE_WINDOW=0)", "pmc_c3s_r3hybrid"),
         ("c3s find: compressed automaton in LDS, column-map lookups (NEEDLE_WINDOW=0)", "pmc_c3s_r3sparse"),
         ("c3s find: compressed automaton in LDS + window addressing (shipped)", "pmc_c3s_r3sparsewin"),
-        ("c3 find: LDS table u16, column-map lookups (NEEDLE_WINDOW=0)", "pmc_c3_r3cmap"),
-        ("c3 find: LDS table u16 + window addressing (shipped)", "pmc_c3_r3window"),
+        ("c3 find: LDS table u16, column-map lookups, backward walks (NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS=0)", "pmc_c3_r3cmap"),
+        ("c3 find: LDS table u16 + window addressing, backward walks (NEEDLE_FIND_LENGTHS=0)", "pmc_c3_r3window"),
+        ("c3 find: + the lengths automaton, no backward walk (shipped)", "pmc_c3_r3lengths"),
         ("c5 find (packed functions, unchanged kernel)", "pmc_c5_r3")]
 keys = ["kernel_us", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
         "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
