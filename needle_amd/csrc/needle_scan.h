@@ -37,7 +37,10 @@
 
 namespace needle {
 
-template <int OP, int CW, int MODE, bool GUARD, int CHB>
+// LEN (OP_FIND on a "lengths" program, needle_lower.h): start = end - pend[stop state] -- the instantiation carries no text
+// snapshots and no backward walk at all (in the ragged-row kernels those cost registers the walk then spills: C3 find on
+// ragged rows 0.66 -> 0.53 ms)
+template <int OP, int CW, int MODE, bool GUARD, int CHB, bool LEN = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArgs a) {
     using G = Geom<CHB>;
     // The survivor pool is compiled into the kernels of the big-table automata (64-byte tiles: the shape the launcher
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         }
         }
         if (OP == OP_FIND) {
-            if (a.fixed_len < 0 && !a.hdr.fa_len_off) { // wave-uniform (a "lengths" program needs no text for its starts)
+            if (a.fixed_len < 0 && !LEN && !a.hdr.fa_len_off) { // wave-uniform (a "lengths" program needs no text for its starts)
                 if (last_rel >= 0) {
                     const uint32_t pi = ((uint32_t)(last_rel - 1) * CW) >> 4; // tile piece holding the accepting char
                     snapA = tile_piece<CHB>(tile, lane, (int)pi);
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         const int32_t e = res ? last : -1;
         if (a.fixed_len >= 0) {
             s = res ? last - a.fixed_len : -1; // :640-646
-        } else if (a.hdr.fa_len_off) {
+        } else if (LEN || a.hdr.fa_len_off) {
             // the "lengths" automaton (needle_lower.h): the state the walk stopped in -- a dead-with-a-match-pending state D_L,
             // or at the row's end any state -- remembers how long its last match was: :640-646 generalised per state, no
             // indexBackwards
@@ -583,23 +586,26 @@ struct LaunchShape {
     size_t lds;
 };
 
-template <int OP, int CW, int MODE, bool GUARD, int CHB>
+template <int OP, int CW, int MODE, bool GUARD, int CHB, bool LEN>
 static hipError_t launch_one(const ScanArgs &a, LaunchShape sh, hipStream_t stream) {
-    auto k = scan_kernel<OP, CW, MODE, GUARD, CHB>;
+    auto k = scan_kernel<OP, CW, MODE, GUARD, CHB, LEN>;
     static thread_local uint64_t configured = 0;
     if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(sh.grid), dim3(sh.waves * 64), sh.lds, stream, a);
     return hipGetLastError();
 }
 
-template <int OP, int CW, int MODE, bool GUARD>
+template <int OP, int CW, int MODE, bool GUARD, bool LEN>
 static hipError_t launch_h(const ScanArgs &a, LaunchShape sh, hipStream_t s) {
-    return sh.chb == 128 ? launch_one<OP, CW, MODE, GUARD, 128>(a, sh, s) : launch_one<OP, CW, MODE, GUARD, 64>(a, sh, s);
+    return sh.chb == 128 ? launch_one<OP, CW, MODE, GUARD, 128, LEN>(a, sh, s) : launch_one<OP, CW, MODE, GUARD, 64, LEN>(a, sh, s);
 }
 
-template <int OP, int CW, int MODE>
+template <int OP, int CW, int MODE, bool LEN = false>
 static hipError_t launch_g(const ScanArgs &a, bool guard, LaunchShape sh, hipStream_t s) {
-    return guard ? launch_h<OP, CW, MODE, true>(a, sh, s) : launch_h<OP, CW, MODE, false>(a, sh, s);
+    if constexpr (OP == OP_FIND && !LEN && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16)) {
+        if (a.hdr.fa_len_off) return launch_g<OP, CW, MODE, true>(a, guard, sh, s); // (the only modes such programs have)
+    }
+    return guard ? launch_h<OP, CW, MODE, true, LEN>(a, sh, s) : launch_h<OP, CW, MODE, false, LEN>(a, sh, s);
 }
 
 template <int OP, int CW>

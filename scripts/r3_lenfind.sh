@@ -15,4 +15,4 @@ for rep in 1 2; do
   done
 done
 for k in 1 0; do echo "ragged NEEDLE_FIND_LENGTHS=$k"; NEEDLE_FIND_LENGTHS=$k timeout 300 python scripts/quick_ragged_keywords.py 2>&1 | grep -v amdgpu | tail -6; done
-for k in 1 0; do echo "short NEEDLE_FIND_LENGTHS=$k"; NEEDLE_FIND_LENGTHS=$k timeout 300 python scripts/short_rows_rate.py 2>&1 | grep -v amdgpu | tail -8; done
+for k in 1 0; do echo "short NEEDLE_FIND_LENGTHS=$k"; NEEDLE_FIND_LENGTHS=$k timeout 300 python scripts/short_rows_rate.py 32 "$(python -c "import sys; sys.path.insert(0, \".\"); from needle_amd import workload as W; print(\"|\".join(W.keywords(300)))")" 2>&1 | grep -v amdgpu | tail -8; done
