@@ -230,7 +230,16 @@ static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v
             sa.bhdr = bp->prog.hdr;
         }
     }
-    HIP_TRY(scratch_malloc((void **)&sa.fn, (size_t)sa.n_rows * sa.spr * 4, (hipStream_t)stream));
+    // find(): pass 1 also marks the stripes that pass through an accepting state, and only the last such stripe of a row is walked
+    // again for lastMatch (needle_stripe.hip).  NEEDLE_STRIPE_CAND=0: every stripe is (A/B, tests).
+    static const bool cand_on = !(getenv("NEEDLE_STRIPE_CAND") && atoi(getenv("NEEDLE_STRIPE_CAND")) == 0);
+    const size_t fn_bytes = ((size_t)sa.n_rows * sa.spr * 4 + 15) & ~(size_t)15;
+    const bool cand = op == OP_FIND && cand_on;
+    HIP_TRY(scratch_malloc((void **)&sa.fn, fn_bytes * (cand ? 2 : 1) + (cand ? (size_t)sa.n_rows * 4 : 0), (hipStream_t)stream));
+    if (cand) {
+        sa.cand = (uint32_t *)((uint8_t *)sa.fn + fn_bytes);
+        sa.cand_stripe = (int32_t *)((uint8_t *)sa.fn + 2 * fn_bytes);
+    }
     hipError_t e = launch_long_rows((int)v->char_width, sa, n_cus, (hipStream_t)stream);
     (void)scratch_free(sa.fn, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "launch_long_rows");

@@ -171,6 +171,10 @@ struct StripeArgs {
     uint32_t *fn;            // [n_rows][spr]: pass 1 writes each stripe's function, the prefix pass replaces it by the
                              // stripe's ENTRY state (5 * device state id)
     uint64_t *bitmap;        // prefix pass: verdicts (matches / containedIn), or "matched" for find (set by the last pass)
+    uint32_t *cand;          // find (nullptr: off): [n_rows][spr], pass 1: bit k set <=> entered in its k-th tracked state the stripe
+                             // passes through an accepting state
+    int32_t *cand_stripe;    // find: [n_rows], prefix pass: the LAST stripe whose true entry state has that bit set (-1: none) --
+                             // the only stripe of the row pass 2 walks again
     int32_t *end;            // find: lastMatch per row (pass 2, atomicMax); initialised by the prefix pass
     int32_t *start;          // find: written by the backward pass
     const uint8_t *bprog;    // find: backward program (global-walk layout) and header

@@ -79,7 +79,11 @@ hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_r
 //   pass 2  stripe_kernel<CW, true>  (find): lane entry state = stripe entry state through the exclusive lane scan,
 //           then the lane walks its bytes again tracking the last accepting position; lanes after the automaton died
 //           enter in the sink and accept nothing, so lastMatch (DFAClassBuilder.java:438-468) is simply the MAX of the
-//           accepting positions: atomicMax per row
+//           accepting positions: atomicMax per row.  Round 3: only ONE stripe per row is walked again.  Pass 1 also notes, per
+//           stripe and tracked entry state, whether the stripe passes through an accepting state at all (one v_or per char
+//           and state: accepting states are the odd field offsets) -- the prefix pass, which knows every stripe's true entry
+//           state, picks the row's last such stripe, and lastMatch lies in it.  (Before: every stripe of every row was read
+//           and walked twice -- find() on rows without an early match cost 2.3 x containedIn().)
 //   start   backward_row_kernel: indexBackwards from lastMatch - 1, one lane per row
 // ------------------------------------------------------------------------------------------------
 // Field offsets of the packed functions (ProgHeader::pack_off): the sink at 0, the other states' fields wherever the
@@ -109,7 +113,7 @@ __device__ __forceinline__ uint32_t compose_fn(const Fields &fl, uint32_t a, uin
 
 // NS = device states incl. the sink (2..5).  The sink maps to itself under every char, so only states 1 .. NS-1 are
 // tracked: NS - 1 v_bfe_u32 per char.
-template <int CW, bool FIND, int NS>
+template <int CW, bool FIND, int NS, bool CAND = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const StripeArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -125,8 +129,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
     const uint32_t accept_lo = a.hdr.accept_off;
     const Fields fl = fields_of(a.hdr);
     const uint32_t kIdentFn = fl.ident;
-    const uint64_t total = a.n_rows * a.spr;
-    for (uint64_t v = (uint64_t)blockIdx.x * kWavesPerBlock + wave; v < total; v += (uint64_t)gridDim.x * kWavesPerBlock) {
+    const bool one_per_row = FIND && a.cand_stripe != nullptr; // (pass 2: the row's candidate stripe only)
+    const uint64_t total = one_per_row ? a.n_rows : a.n_rows * a.spr;
+    for (uint64_t it = (uint64_t)blockIdx.x * kWavesPerBlock + wave; it < total; it += (uint64_t)gridDim.x * kWavesPerBlock) {
+        uint64_t v = it;
+        if (one_per_row) {
+            const int32_t cs = a.cand_stripe[it];
+            if (cs < 0) continue;
+            v = it * a.spr + (uint32_t)cs;
+        }
         const uint64_t row = v / a.spr;
         const uint32_t s = (uint32_t)(v - row * a.spr);
         const uint32_t len = a.lengths ? a.lengths[row] : a.row_len;
@@ -135,7 +146,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
         uint32_t entry = 0; // FIND: 5 * state in which the row's automaton reaches this stripe
         if (FIND) entry = a.fn[v];
         if ((uint64_t)s * (kStripeBytes / CW) >= len || (FIND && entry == 0)) { // stripe past the row's end / automaton dead
-            if (!FIND && lane == 0) a.fn[v] = kIdentFn;
+            if (!FIND && lane == 0) {
+                a.fn[v] = kIdentFn;
+                if (CAND) a.cand[v] = 0u;
+            }
             continue;
         }
         u32x4 d[4] = {};
@@ -172,16 +186,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
                 for (int i = 0; i < 16 / CW; ++i) per_char(j * (16 / CW) + i, f[i]);
             }
         };
+        uint32_t seen[NS]; // CAND: OR of the states the walk from entry state i went through (bit 0: some of them accept)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) seen[i] = 0;
         if (full) {
             walk_all([&](int, uint32_t f) __attribute__((always_inline)) {
 #pragma unroll
-                for (int i = 1; i < NS; ++i) g[i] = __builtin_amdgcn_ubfe(f, g[i], 5);
+                for (int i = 1; i < NS; ++i) {
+                    g[i] = __builtin_amdgcn_ubfe(f, g[i], 5);
+                    if (CAND) seen[i] |= g[i];
+                }
             });
         } else {
             walk_all([&](int c, uint32_t f) __attribute__((always_inline)) {
-                f = (uint32_t)c < n_valid ? f : kIdentFn;
+                const bool in_row = (uint32_t)c < n_valid;
+                f = in_row ? f : kIdentFn;
 #pragma unroll
-                for (int i = 1; i < NS; ++i) g[i] = __builtin_amdgcn_ubfe(f, g[i], 5);
+                for (int i = 1; i < NS; ++i) {
+                    g[i] = __builtin_amdgcn_ubfe(f, g[i], 5);
+                    if (CAND) seen[i] |= in_row ? g[i] : 0u;
+                }
             });
         }
         uint32_t fn = 0;
@@ -194,12 +218,24 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
             const uint32_t left = (uint32_t)__shfl_up((int)incl, dlt);
             if (lane >= dlt) incl = compose_fn(fl, left, incl);
         }
-        if (!FIND) {
-            if (lane == 63) a.fn[v] = incl;
-            continue;
-        }
         uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
         if (lane == 0) excl = kIdentFn;
+        if (!FIND) {
+            if (lane == 63) a.fn[v] = incl;
+            if (CAND) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int i = 1; i < NS; ++i) {
+                    const uint32_t e = __builtin_amdgcn_ubfe(excl, fl.off[i], 5); // this lane's entry state when the stripe is entered in state i
+                    uint32_t sv = 0;
+#pragma unroll
+                    for (int k = 1; k < NS; ++k) sv = e == fl.off[k] ? seen[k] : sv; // (the sink: nothing seen)
+                    if (__ballot((sv & 1u) != 0u) != 0ull) bits |= 1u << i;
+                }
+                if (lane == 0) a.cand[v] = bits;
+            }
+            continue;
+        }
         uint32_t st = __builtin_amdgcn_ubfe(excl, entry, 5);
         int32_t last_rel = -1;
         if (full) {
@@ -229,6 +265,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
 // row walking 262144 stripes of a 1 GiB row one dependent load at a time took 25 ms.)
 __global__ __launch_bounds__(1024) void stripe_prefix_kernel(const StripeArgs a) {
     __shared__ uint32_t wave_total[16];
+    __shared__ int32_t wave_cand[16];
     const uint32_t accept_lo = a.hdr.accept_off;
     const Fields fl = fields_of(a.hdr);
     const uint32_t kIdentFn = fl.ident;
@@ -254,10 +291,32 @@ __global__ __launch_bounds__(1024) void stripe_prefix_kernel(const StripeArgs a)
         if (lane == 0) excl = kIdentFn;
         excl = compose_fn(fl, before, excl);
         uint32_t q = __builtin_amdgcn_ubfe(excl, a.hdr.start_off, 5);
+        int32_t last_cand = -1;
         for (uint32_t s = s0; s < s1; ++s) {
             const uint32_t f = fn[s];
             fn[s] = q;
+            if (a.cand) { // (find) entered in q, does stripe s pass through an accepting state?
+                const uint32_t c = a.cand[row * a.spr + s];
+                uint32_t k = 0;
+#pragma unroll
+                for (int i = 1; i < 5; ++i) k = (i < fl.n && q == fl.off[i]) ? (uint32_t)i : k;
+                if (k && ((c >> k) & 1u)) last_cand = (int32_t)s;
+            }
             q = __builtin_amdgcn_ubfe(f, q, 5);
+        }
+        if (a.cand) { // the row's last candidate stripe: maximum over the workgroup
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int32_t t = __shfl_xor(last_cand, o);
+                last_cand = t > last_cand ? t : last_cand;
+            }
+            if (lane == 0) wave_cand[wave] = last_cand;
+            __syncthreads();
+            if (tid == 0) {
+                int32_t best = -1;
+                for (int w = 0; w < n_waves; ++w) best = wave_cand[w] > best ? wave_cand[w] : best;
+                a.cand_stripe[row] = best;
+            }
         }
         if (tid == (int)blockDim.x - 1) { // its chunk is the last one (possibly empty): q is the row's final state
             if (a.op == OP_FIND) a.end[row] = a.hdr.root_accepting ? 0 : -1; // :356 lastMatch before the first char
@@ -312,21 +371,21 @@ hipError_t launch_backward_rows(int char_width, const StripeArgs &a, hipStream_t
     return hipGetLastError();
 }
 
-template <int CW, bool FIND, int NS>
+template <int CW, bool FIND, int NS, bool CAND>
 static hipError_t launch_stripe(const StripeArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
-    auto k = stripe_kernel<CW, FIND, NS>;
+    auto k = stripe_kernel<CW, FIND, NS, CAND>;
     static thread_local uint64_t configured = 0;
     if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(kWavesPerBlock * 64), lds, stream, a);
     return hipGetLastError();
 }
-template <int CW, bool FIND>
+template <int CW, bool FIND, bool CAND = false>
 static hipError_t launch_stripe_n(const StripeArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     switch (a.hdr.n_states) {
-    case 0: case 1: case 2: return launch_stripe<CW, FIND, 2>(a, grid, lds, stream);
-    case 3: return launch_stripe<CW, FIND, 3>(a, grid, lds, stream);
-    case 4: return launch_stripe<CW, FIND, 4>(a, grid, lds, stream);
-    default: return launch_stripe<CW, FIND, 5>(a, grid, lds, stream); // packed mode has at most 5 states
+    case 0: case 1: case 2: return launch_stripe<CW, FIND, 2, CAND>(a, grid, lds, stream);
+    case 3: return launch_stripe<CW, FIND, 3, CAND>(a, grid, lds, stream);
+    case 4: return launch_stripe<CW, FIND, 4, CAND>(a, grid, lds, stream);
+    default: return launch_stripe<CW, FIND, 5, CAND>(a, grid, lds, stream); // packed mode has at most 5 states
     }
 }
 
@@ -337,7 +396,9 @@ hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipS
     const size_t lds = (a.hdr.lds_bytes + 15u) & ~15u;
     const dim3 grid((unsigned)blocks);
     const unsigned pblocks = (unsigned)((a.n_rows + 255) / 256);
-    hipError_t e = char_width == 1 ? launch_stripe_n<1, false>(a, grid, lds, stream) : launch_stripe_n<2, false>(a, grid, lds, stream);
+    const bool cand = a.op == OP_FIND && a.cand != nullptr;
+    hipError_t e = cand ? (char_width == 1 ? launch_stripe_n<1, false, true>(a, grid, lds, stream) : launch_stripe_n<2, false, true>(a, grid, lds, stream))
+                        : (char_width == 1 ? launch_stripe_n<1, false>(a, grid, lds, stream) : launch_stripe_n<2, false>(a, grid, lds, stream));
     if (e != hipSuccess) return e;
     {
         if (a.op != OP_FIND) { // verdict bits are OR-ed in
@@ -350,7 +411,12 @@ hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipS
         hipLaunchKernelGGL(stripe_prefix_kernel, dim3((unsigned)(a.n_rows < max_blocks ? a.n_rows : max_blocks)), dim3(threads), 0, stream, a);
     }
     if (a.op == OP_FIND) {
-        e = char_width == 1 ? launch_stripe_n<1, true>(a, grid, lds, stream) : launch_stripe_n<2, true>(a, grid, lds, stream);
+        dim3 grid2 = grid;
+        if (cand) { // one stripe per row
+            const uint64_t b2 = (a.n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+            grid2 = dim3((unsigned)(b2 < (uint64_t)n_cus ? b2 : (uint64_t)n_cus));
+        }
+        e = char_width == 1 ? launch_stripe_n<1, true>(a, grid2, lds, stream) : launch_stripe_n<2, true>(a, grid2, lds, stream);
         if (e != hipSuccess) return e;
         if (char_width == 1) hipLaunchKernelGGL(backward_row_kernel<1>, dim3(pblocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(backward_row_kernel<2>, dim3(pblocks), dim3(256), 0, stream, a);

@@ -207,3 +207,25 @@ def test_an_automaton_that_never_resynchronises_falls_back_to_the_lane_walk():
     rows[3, 7] = ord("q")
     rows[3, 4096 * 3 - 2:4096 * 3 + 6] = [ord(c) for c in "z#abcdef"]  # straddles a stripe boundary
     check(p, o, rows, None)
+
+
+@pytest.mark.gpu
+def test_stripe_find_without_candidate_stripes_in_a_child():
+    """find() on the function-composition stripe path walks, a second time, only each row's LAST stripe that passes through an
+    accepting state from its true entry state (the default; the tests above).  NEEDLE_STRIPE_CAND=0 -- every stripe walked
+    again, round 2's form -- must give the same (oracle-checked) results; the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import test_gpu_long_rows as T
+for case in T.CASES:
+    if case[0] != "a.c":
+        T.test_long_rows_take_the_stripe_path_and_match_the_oracle.__wrapped__(*case) if hasattr(T.test_long_rows_take_the_stripe_path_and_match_the_oracle, "__wrapped__") else T.test_long_rows_take_the_stripe_path_and_match_the_oracle(*case)
+print("STRIPE-ALL-OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, NEEDLE_STRIPE_CAND="0"), capture_output=True, text=True, timeout=900)
+    assert "STRIPE-ALL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
