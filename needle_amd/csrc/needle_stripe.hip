@@ -852,8 +852,15 @@ static hipError_t launch_short_c(const ScanArgs &a, int cw, int grid, size_t lds
 hipError_t launch_short_rows(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream) {
     const uint64_t n_groups = (a.n_rows + 63) >> 6;
     uint64_t blocks = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks > (uint64_t)n_cus) blocks = (uint64_t)n_cus;
     const size_t lds = (a.hdr.lds_bytes + 15u) & ~15u;
+    // matches() / containedIn() on rows of 16 and 32 bytes: the kernels need at most 64 VGPRs and no LDS beyond the program, so
+    // TWO workgroups share a CU when two copies of the program fit its LDS -- 32 waves instead of 16 hide the memory latency of
+    // rows this short (a wave has only 64 x stride bytes in flight): 16-byte rows 3.75 -> 4.9 TB/s, 32-byte rows 5.0 -> 5.3; rows
+    // of 48 and 64 bytes lose 5 % that way and keep one.  find() has no room for a second copy beside its text slots.
+    // NEEDLE_SHORT_WGS=1: one workgroup per CU everywhere (A/B).
+    static const int wgs_env = getenv("NEEDLE_SHORT_WGS") ? atoi(getenv("NEEDLE_SHORT_WGS")) : 2;
+    const uint64_t per_cu = (op != OP_FIND && wgs_env >= 2 && a.stride_bytes <= 32 && 2 * lds <= 160u * 1024u) ? 2 : 1;
+    if (blocks > (uint64_t)n_cus * per_cu) blocks = (uint64_t)n_cus * per_cu;
     switch (op) {
     case OP_MATCHES: return launch_short_c<OP_MATCHES>(a, char_width, (int)blocks, lds, stream);
     case OP_CONTAINED_IN: return launch_short_c<OP_CONTAINED_IN>(a, char_width, (int)blocks, lds, stream);
