@@ -111,6 +111,17 @@ public final class GpuPattern implements Pattern, AutoCloseable {
         return more[0] != 0;
     }
 
+    /**
+     * {@link #findAllBatch} with each match as one int, {@code start | end << 16} (rows of at most 65 535 chars): half the result
+     * bytes on the device and over PCIe (needle_find_all_packed16_host).
+     */
+    public boolean findAllBatchPacked(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen, ByteBuffer lengths,
+                                      int maxPerRow, int[] counts, int[] startEnd) {
+        int[] more = new int[1];
+        check(Native.findAllPacked16Host(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, maxPerRow, counts, startEnd, more), null);
+        return more[0] != 0;
+    }
+
     /** Result of {@link #findAllCompact}: row r's matches are start/end[offsets[r] .. offsets[r + 1]). */
     public static final class Matches {
         public final long[] offsets;

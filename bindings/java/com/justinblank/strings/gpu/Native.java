@@ -55,6 +55,10 @@ final class Native {
     static native int findAllHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
                                   java.nio.ByteBuffer lengths, int maxPerRow, int[] counts, int[] start, int[] end, int[] more);
 
+    /** needle_find_all_packed16_host: counts int[nRows]; startEnd int[nRows * maxPerRow], each match start | end << 16. */
+    static native int findAllPacked16Host(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
+                                          java.nio.ByteBuffer lengths, int maxPerRow, int[] counts, int[] startEnd, int[] more);
+
     /** needle_find_all_csr_host: offsets long[nRows + 1]; start / end int[capacity] (null: count only); total long[1]. */
     static native int findAllCsrHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
                                      java.nio.ByteBuffer lengths, long[] offsets, int[] start, int[] end, long[] total);

@@ -143,6 +143,20 @@ NATIVE(jint, findAllHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw,
     return rc;
 }
 
+NATIVE(jint, findAllPacked16Host)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jint maxPerRow, jintArray counts, jintArray startEnd, jintArray more) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    jint *cn = (*env)->GetIntArrayElements(env, counts, NULL);
+    jint *se = (*env)->GetIntArrayElements(env, startEnd, NULL);
+    int m = 0;
+    int rc = needle_find_all_packed16_host((const needle_pattern *)(intptr_t)h, &v, (uint32_t)maxPerRow, (uint32_t *)cn, (uint32_t *)se, &m);
+    jint mm = m;
+    (*env)->SetIntArrayRegion(env, more, 0, 1, &mm);
+    (*env)->ReleaseIntArrayElements(env, counts, cn, 0);
+    (*env)->ReleaseIntArrayElements(env, startEnd, se, 0);
+    return rc;
+}
+
 /* needle_find_all_csr_host: offsets long[nRows + 1]; start / end int[capacity] (may be null with capacity 0: count only);
  * total long[1]. */
 NATIVE(jint, findAllCsrHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jlongArray offsets, jintArray start, jintArray end, jlongArray total) {

@@ -1275,8 +1275,9 @@ int needle_find_all_csr_dev(const needle_pattern *cp, const needle_batch_view *v
     return find_all_one_pass(p, v, 0, nullptr, d_start, d_end, d_offsets, false, more, (hipStream_t)stream_);
 }
 
+// start_end16 != nullptr: the one-dword-per-match form (needle_find_all_packed16_dev) -- start / end are not used
 static int find_all_host_one(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
-                             int32_t *end, int *more) {
+                             int32_t *end, int *more, uint32_t *start_end16 = nullptr) {
     const size_t cw = v->char_width, n = (size_t)v->n_rows;
     const size_t src_stride = (size_t)v->row_stride * cw;
     size_t dst_stride = (src_stride + 15) & ~(size_t)15;
@@ -1284,7 +1285,7 @@ static int find_all_host_one(const needle_pattern *p, const needle_batch_view *v
     uint8_t *d = nullptr; // rows | lengths | counts | start | end
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_len = up16(n * dst_stride), o_cnt = o_len + up16(n * 4), o_s = o_cnt + up16(n * 4);
-    const size_t o_e = o_s + up16(n * slots * 4), total = o_e + up16(n * slots * 4);
+    const size_t o_e = o_s + up16(n * slots * 4), total = o_e + (start_end16 ? 0 : up16(n * slots * 4));
     HIP_TRY(hipMalloc((void **)&d, total));
     auto done = [&](int code) {
         (void)hipFree(d);
@@ -1304,11 +1305,12 @@ static int find_all_host_one(const needle_pattern *p, const needle_batch_view *v
     dv.rows = d;
     dv.lengths = v->lengths ? (const uint32_t *)(d + o_len) : nullptr;
     dv.row_stride = dst_stride / cw;
-    int rc = needle_find_all_dev(p, &dv, slots, (uint32_t *)(d + o_cnt), (int32_t *)(d + o_s), (int32_t *)(d + o_e), more, nullptr);
+    int rc = start_end16 ? needle_find_all_packed16_dev(p, &dv, slots, (uint32_t *)(d + o_cnt), (uint32_t *)(d + o_s), more, nullptr)
+                         : needle_find_all_dev(p, &dv, slots, (uint32_t *)(d + o_cnt), (int32_t *)(d + o_s), (int32_t *)(d + o_e), more, nullptr);
     if (rc) return done(rc);
     e = hipMemcpy(counts, d + o_cnt, n * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && slots) e = hipMemcpy(start, d + o_s, n * slots * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && slots) e = hipMemcpy(end, d + o_e, n * slots * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && slots) e = hipMemcpy(start_end16 ? (void *)start_end16 : (void *)start, d + o_s, n * slots * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && slots && !start_end16) e = hipMemcpy(end, d + o_e, n * slots * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return done(hip_fail(e, "find_all_host download"));
     return done(NEEDLE_OK);
 }
@@ -1415,15 +1417,15 @@ int needle_find_all_csr_host(const needle_pattern *p, const needle_batch_view *v
     *total = offsets[v->n_rows];
     return NEEDLE_OK;
 }
-int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
-                         int32_t *end, int *more) {
+static int find_all_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
+                         int32_t *end, int *more, uint32_t *start_end16) {
     if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
     int rc = check_view(v, false);
     if (rc) return rc;
     if ((rc = check_host_lengths(v))) return rc;
     if (more) *more = 0;
     if (v->n_rows == 0) return NEEDLE_OK;
-    if (!counts || (slots && (!start || !end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    if (!counts || (slots && !start_end16 && (!start || !end))) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
     static const uint64_t kHostChunkBytes = getenv("NEEDLE_HOST_CHUNK_BYTES") ? (uint64_t)atoll(getenv("NEEDLE_HOST_CHUNK_BYTES")) : (2ull << 30);
     const uint64_t row_bytes = std::max<uint64_t>(16, (v->row_stride * v->char_width + 15) & ~(uint64_t)15) + 8 + 8ull * slots;
     const uint64_t per = std::max<uint64_t>(64, (kHostChunkBytes / row_bytes) & ~(uint64_t)63);
@@ -1433,11 +1435,23 @@ int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, ui
         c.rows = (const uint8_t *)v->rows + r0 * v->row_stride * v->char_width;
         c.lengths = v->lengths ? v->lengths + r0 : nullptr;
         int m = 0;
-        rc = find_all_host_one(p, &c, slots, counts + r0, start ? start + r0 * slots : nullptr, end ? end + r0 * slots : nullptr, &m);
+        rc = find_all_host_one(p, &c, slots, counts + r0, start ? start + r0 * slots : nullptr, end ? end + r0 * slots : nullptr, &m,
+                               start_end16 ? start_end16 + r0 * slots : nullptr);
         if (rc) return rc;
         if (m && more) *more = 1;
     }
     return NEEDLE_OK;
+}
+int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts, int32_t *start,
+                         int32_t *end, int *more) {
+    return find_all_host(p, v, slots, counts, start, end, more, nullptr);
+}
+int needle_find_all_packed16_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts,
+                                  uint32_t *start_end16, int *more) {
+    if (slots && !start_end16) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    if (v && v->row_stride > 65535u) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit start / end: rows of at most 65535 chars");
+    static uint32_t none = 0; // (slots == 0: counting only; a non-null marker keeps the packed form)
+    return find_all_host(p, v, slots, counts, nullptr, nullptr, more, start_end16 ? start_end16 : &none);
 }
 int needle_matches_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm) {
     return run_host(p, OP_MATCHES, v, bm, nullptr, nullptr);

@@ -350,8 +350,24 @@ class Pattern:
         """needle_find_all_packed16_dev: as find_all_dense on device rows of at most 65 535 chars, each match one dword
         (start | end << 16).  -> (counts int32[n], start_end16 int32[n, max_per_row] (bit pattern of the uint32), more: bool or
         None when want_more is False -- the call is then asynchronous on the stream)."""
-        import torch
         L = _lib.lib()
+        if isinstance(rows, np.ndarray):  # host buffers: needle_find_all_packed16_host
+            rows = np.ascontiguousarray(rows)
+            if rows.dtype == np.int16:
+                rows = rows.view(np.uint16)
+            assert rows.ndim == 2 and rows.dtype in (np.uint8, np.uint16)
+            n, stride = rows.shape
+            v = BatchView()
+            v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.ctypes.data, rows.dtype.itemsize, n, stride, stride
+            if lengths is not None:
+                lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+                v.lengths = lengths.ctypes.data
+            counts = np.zeros(n, dtype=np.uint32)
+            se = np.full((n, max_per_row), 0xFFFFFFFF, dtype=np.uint32)
+            more = ctypes.c_int(0)
+            _check(L.needle_find_all_packed16_host(self._h, ctypes.byref(v), int(max_per_row), counts.ctypes.data, se.ctypes.data, ctypes.byref(more)))
+            return counts, se, bool(more.value)
+        import torch
         v, n = self._dev_view(rows, lengths), rows.shape[0]
         with torch.cuda.device(rows.device):
             s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream

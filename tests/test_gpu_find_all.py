@@ -259,6 +259,12 @@ def test_packed16_form_equals_the_two_array_form(regex, cw):
             filed = torch.arange(slots, device="cuda")[None, :] < c0[:, None]
             assert ((se & 0xFFFF)[filed] == s0[filed]).all() and (((se >> 16) & 0xFFFF)[filed] == e0[filed]).all()
             assert (se[~filed] == -1).all()  # slots beyond the count stay untouched
+    # host buffers: needle_find_all_packed16_host (unfiled slots come back as 0xFFFFFFFF)
+    h = rows.cpu().numpy()
+    hl = lens.cpu().numpy().astype(np.uint32)
+    hc, hse, hm = p.find_all_dense_packed16(h[:3000], 40, hl[:3000])
+    c1, se, m1 = p.find_all_dense_packed16(rows[:3000].contiguous(), 40, lens[:3000].contiguous())
+    assert hm == m1 and (hc == c1.cpu().numpy().astype(np.uint32)).all() and (hse.view(np.int32) == se.cpu().numpy()).all()
     wide = torch.zeros((2, 65536 + 16), dtype=torch.uint8, device="cuda")
     with pytest.raises(Exception):
         p.find_all_dense_packed16(wide, 4)
