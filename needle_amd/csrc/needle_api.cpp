@@ -250,7 +250,8 @@ static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v
 // program is a plain LDS table, 2 = also instead of the pair table (measured slower: DESIGN.md s4)
 static bool find_lengths_for(uint32_t mode) {
     static const int level = getenv("NEEDLE_FIND_LENGTHS") ? atoi(getenv("NEEDLE_FIND_LENGTHS")) : 1;
-    return level > 0 && (mode == MODE_TABLE8 || mode == MODE_TABLE16 || (level > 1 && mode == MODE_PAIR));
+    static const bool sparse_too = !(getenv("NEEDLE_FIND_LENGTHS_SPARSE") && atoi(getenv("NEEDLE_FIND_LENGTHS_SPARSE")) == 0);
+    return level > 0 && (mode == MODE_TABLE8 || mode == MODE_TABLE16 || (sparse_too && mode == MODE_SPARSE) || (level > 1 && mode == MODE_PAIR));
 }
 
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,

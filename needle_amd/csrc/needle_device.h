@@ -93,6 +93,11 @@ struct ProgHeader {
     // find-all "lengths" form (needle_lower.h, MatchLengths): pend[] by device state in LDS; the dead-with-a-pending-match
     // states are the device ids fa_dead_lo .. fa_dead_lo + fa_dead_n - 1
     uint32_t fa_len_off, fa_dead_lo, fa_dead_n;
+    // the scan kernels' test for "this lane's search is over": state value <= fa_dead_hi (plain tables: = fa_dead_n; the compressed
+    // form: the value of D_K, whose rows are the first dense rows).  Compressed lengths programs: sp_end_col4 = key of the END
+    // records (row end -> the D_L of the pending length; the states with a match pending carry one, last in their chain),
+    // sp_dead_row0 = address field of D_1's row, sp_len_cols = cells per row
+    uint32_t fa_dead_hi, sp_end_col4, sp_dead_row0, sp_len_cols;
     // find-all programs of that form also carry "skip" states: S_k (device id fa_skip_lo + k - 1) goes to S_(k-1) on EVERY
     // column and S_1 to the start state -- a search restarted k chars into a 16-byte piece enters the piece in S_k and needs
     // no per-char cursor guard (0: none)

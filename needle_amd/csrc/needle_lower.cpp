@@ -154,6 +154,9 @@ namespace {
 struct SparseImage {
     std::vector<uint8_t> img; // relative to the table base
     uint32_t rec_base = 0, accept_rec = 0, rows_base = 0, start = 0, accept_lo = 0, chains = 0, dense = 0, records = 0;
+    // lengths programs (n_dead > 0): the dead-with-a-match-pending states D_1 .. D_K own the first dense rows, so that "the search
+    // is over" is value <= dead_hi; dead_row0 = the address field (row address / 4) of D_1's row, D_k's = dead_row0 + (k - 1) * NC
+    uint32_t dead_hi = 0, dead_row0 = 0, end_key = 0;
 };
 
 constexpr int kSparseMaxChain = 3; // states that need more exceptions than this against every candidate row become dense
@@ -161,7 +164,12 @@ constexpr int kSparseMaxChain = 3; // states that need more exceptions than this
 // next_full: device-numbered table [n_dev][n_cols_full] (0 = sink | non-accepting | accepting from accept_lo_dev on); only
 // the columns listed in `cols` take part, renumbered 0 .. cols.size() - 1 in that order.  room: bytes the image may take.
 bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_full, const std::vector<int> &cols, int col_bias, int start_dev,
-                  int accept_lo_dev, size_t room, SparseImage &out) {
+                  int accept_lo_dev, size_t room, SparseImage &out, int n_dead = 0, const std::vector<uint16_t> *end_tgt = nullptr) {
+    // end_tgt (lengths programs): per state, where the END of the row leads -- the D_L of its pending length, or 0.  END is no
+    // column of the dense rows (a cell per row for the few states that have a match pending would not fit: C3-sparse has 76 bytes
+    // to spare): the states with a target keep a record of their own for it, keyed NC * 4 (one past the last column), which
+    // only finish_rows' record-chain walk (needle_scan.h, sparse_end) ever asks for; they are never dense.
+    auto pending = [&](int s) { return end_tgt && s > n_dead && (*end_tgt)[s] != 0; };
     // col_bias (window addressing): the walk's column offsets are (col_bias + j) * 4, not rebased -- every row sits col_bias
     // cells further up than its address says, and the record keys carry the bias
     const int NC = (int)cols.size();
@@ -216,10 +224,14 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
     auto evaluate = [&](int D) -> size_t {
         std::fill(is_dense.begin(), is_dense.end(), 0);
         is_dense[0] = 1;
-        for (int i = 0; i < D; ++i) is_dense[order[i]] = 1;
-        size_t n_rec = 0, n_dense = (size_t)D;
-        for (int i = D; i < S; ++i) {
+        size_t n_rec = 0, n_dense = 0;
+        for (int i = 0; i < D; ++i)
+            if (!pending(order[i])) is_dense[order[i]] = 1, ++n_dense;
+        for (int d = 1; d <= n_dead; ++d) // (lengths programs: the D_L states keep rows of their own)
+            if (!is_dense[d]) is_dense[d] = 1, ++n_dense;
+        for (int i = 0; i < S; ++i) {
             const int s = order[i];
+            if (is_dense[s]) continue;
             int best = 0, best_n = diff(s, 0, NC); // the sink's row (all cells 0) is always a candidate
             auto consider = [&](int d) {
                 if (!is_dense[d] || d == best) return;
@@ -234,9 +246,10 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
                 x = nx;
             }
             consider(start_dev);
+            for (int d = 1; d <= n_dead; ++d) consider(d); // (a state every char of which ends the match: D_L's own row)
             if (best_n > 1 && work < work_cap) // the heuristic candidates are poor: look at every dense row
                 for (int j = 0; j < D && best_n > 1; ++j) consider(order[j]);
-            if (best_n > kSparseMaxChain) { // no row is close: the state keeps a dense row of its own
+            if (best_n > kSparseMaxChain && !pending(s)) { // no row is close: the state keeps a dense row of its own
                 is_dense[s] = 2;
                 ++n_dense;
                 continue;
@@ -245,6 +258,7 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
             exc[s].clear();
             for (int c = 0; c < NC; ++c)
                 if (cell(s, c) != cell(best, c)) exc[s].push_back(c);
+            if (pending(s)) exc[s].push_back(NC); // the END record, last in the chain
             n_rec += exc[s].size();
         }
         return ((row_bytes + 7) & ~(size_t)7) + (2 + n_rec) * 8 + n_dense * row_bytes + 8;
@@ -268,7 +282,7 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
     for (int want = kSparseMaxChain; want >= 2; --want)
         for (int i = D; i < S; ++i) {
             const int s = order[i];
-            if (is_dense[s] || (int)exc[s].size() != want) continue;
+            if (is_dense[s] || (int)exc[s].size() != want || pending(s)) continue;
             const size_t nb = bytes + row_bytes - 8 * exc[s].size();
             if (nb > room) continue;
             is_dense[s] = 2;
@@ -305,8 +319,13 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
     uint32_t n_dense = 0;
     {
         uint32_t r = rows_base;
+        for (int d = 1; d <= n_dead; ++d) { // D_1 .. D_K first, one row apart whether reachable or not
+            row_at[d] = r;
+            r += (uint32_t)row_bytes;
+            if (is_dense[d]) ++n_dense;
+        }
         for (int i = 0; i < S; ++i)
-            if (is_dense[order[i]]) { row_at[order[i]] = r; r += (uint32_t)row_bytes; ++n_dense; }
+            if (is_dense[order[i]] && !(order[i] >= 1 && order[i] <= n_dead)) { row_at[order[i]] = r; r += (uint32_t)row_bytes; ++n_dense; }
         if (r / 4 > 0xFFFFu || r > room + bias4 + 8) return false;
         out.img.assign(r, 0);
     }
@@ -330,7 +349,7 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
                 const uint32_t a = rec_at[s] + 8u * (uint32_t)k;
                 const uint32_t nxt = k + 1 < exc[s].size() ? a + 8u : 0u;
                 put32(a, ((uint32_t)exc[s][k] * 4u + bias4) | (nxt << 16));
-                put32(a + 4, value(cell(s, exc[s][k])));
+                put32(a + 4, value(exc[s][k] == NC ? (int)(*end_tgt)[s] : cell(s, exc[s][k])));
             }
         }
     }
@@ -338,6 +357,13 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
     out.accept_rec = dummy_acc;
     out.rows_base = rows_base;
     out.start = value(start_dev);
+    out.end_key = (uint32_t)NC * 4u + bias4;
+    if (n_dead) {
+        for (int d = 1; d <= n_dead; ++d)
+            if (d >= accept_lo_dev || (pos[d] >= 0 && !is_dense[d])) return false;
+        out.dead_row0 = (row_at[1] - bias4) >> 2;
+        out.dead_hi = (dummy_nonacc << 16) | ((row_at[n_dead] - bias4) >> 2);
+    }
     out.accept_lo = dummy_acc << 16;
     out.chains = chains;
     out.dense = n_dense;
@@ -369,7 +395,23 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
                 nx = hit ? b1 : nx;
             }
             if (nx != value(cell(s, c))) {
-                if (dbg) fprintf(stderr, "[sparse] verification failed: state %d column %d\n", s, c);
+                if (dbg) fprintf(stderr, "[sparse] verification failed: state %d column %d: got %08x want %08x (target %d, dense %d/%d, exc %zu, dflt %d, sv %08x)\n", s, c, nx,
+                                 value(cell(s, c)), cell(s, c), (int)is_dense[s], (int)is_dense[cell(s, c)], exc[s].size(), dflt[s], sv);
+                return false;
+            }
+        }
+        if (end_tgt && s > n_dead) { // END: the record chain alone (needle_scan.h, sparse_end); no record = the sink
+            uint32_t b0 = rd32(sv >> 16), b1 = rd32((sv >> 16) + 4), r = 0;
+            int guard = 0;
+            for (;;) {
+                if ((b0 & 0xFFFFu) == out.end_key) { r = b1; break; }
+                if (b0 <= 0xFFFFu || guard++ > 16) break;
+                const uint32_t nr = b0 >> 16;
+                b0 = rd32(nr);
+                b1 = rd32(nr + 4);
+            }
+            if (r != value((int)(*end_tgt)[s])) {
+                if (dbg) fprintf(stderr, "[sparse] verification failed: state %d END\n", s);
                 return false;
             }
         }
@@ -710,7 +752,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         if (char_width == 2 && (uint32_t)n_cols * elem > 255u && !win.ok) mode = MODE_GLOBAL; // pages hold column * elem in a byte
         build(mode);
         bool sparse_done = false;
-        if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget && !no_pair && !ml) {
+        if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget && !no_pair) { // (ml: the scan kernels' lengths form too)
             // Too big for a dense table in LDS.  First choice: the compressed whole-automaton form (MODE_SPARSE, above).
             // NEEDLE_SPARSE=0 turns it off (A/B, tests of the hot-rows mode); NEEDLE_SPARSE_ROOM: LDS bytes the program may take
             // (default: what leaves room for 16 waves x 64-byte tiles).
@@ -724,6 +766,13 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                 else for (uint8_t c : cm.pages) used[c] = 1;
                 for (int k = 0; k < n_cols; ++k)
                     if (used[k]) { col_id[k] = (int)cols.size(); cols.push_back(k); }
+            }
+            // lengths programs: the row's end is a column of its own (END = the PAD column, which lower() pointed at the D_L of every
+            // state's pending length): the walk takes it once, after the row's last char, and lands in the state that names the length
+            std::vector<uint16_t> end_tgt; // lengths programs: where the row's END leads from each state (the PAD column lower() patched)
+            if (ml) {
+                end_tgt.resize(n_dev);
+                for (int st = 0; st < n_dev; ++st) end_tgt[st] = next[(size_t)st * n_cols + PAD];
             }
             const int NC = (int)cols.size();
             const bool cols_ok = char_width == 1 || NC * 4 <= 256 || win.ok; // UTF-16: the pages hold column * 4 in a byte
@@ -758,10 +807,16 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                         for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Table + i] = (uint8_t)(col_id[cm.pages[i]] * 4);
                         while (p.blob.size() % 16) p.blob.push_back(0);
                     }
-                    const size_t fixed = p.blob.size() + (with_backward_maps ? (char_width == 1 ? 256 : 256 + bm.pages.size()) + 64 : 0) + 64;
+                    const size_t fixed = p.blob.size() + (with_backward_maps ? (char_width == 1 ? 256 : 256 + bm.pages.size()) + 64 : 0) + 64 +
+                                         (ml ? (size_t)ml->n_dead * (size_t)NC + 48 : 0); // (+ pend[] of the lengths form)
                     if (room <= fixed) continue;
-                    built = w ? build_sparse(*tab, n_dev, n_cols, win.cols, win.cl, dev[0], accept_lo, room - fixed, im)
-                              : build_sparse(*tab, n_dev, n_cols, cols, 0, dev[0], accept_lo, room - fixed, im);
+                    const int nd = ml ? ml->n_dead : 0;
+                    built = w ? build_sparse(*tab, n_dev, n_cols, win.cols, win.cl, dev[0], accept_lo, room - fixed, im, nd, ml ? &end_tgt : nullptr)
+                              : build_sparse(*tab, n_dev, n_cols, cols, 0, dev[0], accept_lo, room - fixed, im, nd, ml ? &end_tgt : nullptr);
+                    if (built && ml) {
+                        p.hdr.sp_end_col4 = im.end_key;
+                        p.hdr.sp_len_cols = (uint32_t)(w ? win.cols.size() : cols.size());
+                    }
                     if (built && w) {
                         set_window_header(4);
                         p.hdr.n_cols = n_cols; // (PAD / PRE are no columns in this mode; n_cols stays the reference's)
@@ -781,7 +836,10 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
                     p.hdr.sp_accept_rec = im.accept_rec;
                     p.hdr.sp_rows_base = im.rows_base;
                     p.hdr.sp_chains = im.chains;
-                    p.hdr.sp_pad_ident = (which == W_MATCHES || contained) ? 1u : 0u;
+                    p.hdr.sp_pad_ident = (which == W_MATCHES || contained || ml) ? 1u : 0u; // (lengths programs: the state freezes at the
+                                                                                                // row's end; finish_rows asks its END record)
+                    p.hdr.sp_dead_row0 = im.dead_row0;
+                    p.hdr.fa_dead_hi = im.dead_hi;
                     p.hdr.sp_dense = im.dense;
                     p.hdr.sp_records = im.records;
                     sparse_done = true;
@@ -875,11 +933,25 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     p.hdr.mode = mode;
     if (ml) {
         // pend[] by DEVICE state rides in the LDS part; only the plain table modes number states the way it is indexed
+        if (mode == MODE_SPARSE) {
+            // the compressed form: only the D_L states are ever asked (a live stop state takes the END column first) -- pend[] is
+            // indexed by their rows' address fields, sp_len_cols apart from sp_dead_row0 on
+            std::vector<uint8_t> pend_rows((size_t)ml->n_dead * p.hdr.sp_len_cols + 16, 0);
+            for (int k = 1; k <= ml->n_dead; ++k) pend_rows[(size_t)(k - 1) * p.hdr.sp_len_cols] = ml->pend[k];
+            p.hdr.fa_len_off = (uint32_t)p.blob.size();
+            p.blob.insert(p.blob.end(), pend_rows.begin(), pend_rows.end());
+            while (p.blob.size() % 16) p.blob.push_back(0);
+            p.hdr.lds_bytes = (uint32_t)p.blob.size();
+            p.hdr.fa_dead_lo = 1;
+            p.hdr.fa_dead_n = (uint32_t)ml->n_dead;
+            return p;
+        }
         if (mode != MODE_TABLE8 && mode != MODE_TABLE16) {
             p.blob.clear();
             p.hdr.mode = MODE_GLOBAL;
             return p;
         }
+        p.hdr.fa_dead_hi = (uint32_t)ml->n_dead;
         std::vector<uint8_t> pend_dev(n_dev, 0);
         for (int s = 0; s < n_ref; ++s) pend_dev[dev[s]] = ml->pend[s];
         p.hdr.fa_len_off = (uint32_t)p.blob.size();

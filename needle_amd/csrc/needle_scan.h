@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     wk.win_on = a.hdr.win_on;
     wk.win_lo = a.hdr.win_lo_e;
     wk.win_hi = a.hdr.win_hi_e;
-    wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_n : 0u; // (fa_dead_lo == 1: the D_L states follow the sink)
+    wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_hi : 0u; // (the D_L states follow the sink: needle_device.h)
     wk.sp_chains = a.hdr.sp_chains;
     wk.sp_pad_ident = a.hdr.sp_pad_ident;
     // (window addressing: column offsets are not rebased -- wraps are fine in 32-bit address math; the compressed form carries
@@ -323,7 +323,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             // the "lengths" automaton (needle_lower.h): the state the walk stopped in -- a dead-with-a-match-pending state D_L,
             // or at the row's end any state -- remembers how long its last match was: :640-646 generalised per state, no
             // indexBackwards
-            s = res ? last - (int32_t)lds_u8(a.hdr.fa_len_off + st) : -1;
+            uint32_t pidx = st;
+            if (MODE == MODE_SPARSE) { // a live stop state (the row ended) asks its END record for the D_L of its pending length
+                const uint32_t st_end = sparse_end<CW>(wk, st, st > wk.dead_hi, a.hdr.sp_end_col4);
+                pidx = (st_end & 0xFFFFu) - a.hdr.sp_dead_row0;
+            }
+            s = res ? last - (int32_t)lds_u8(a.hdr.fa_len_off + pidx) : -1;
         } else {
             // indexBackwards(end - 1, 0), :536-583.  Column map in LDS, row bytes (L2-hot) fetched 8 at a time,
             // backward table walked out of HBM/L2.
@@ -602,7 +607,7 @@ static hipError_t launch_h(const ScanArgs &a, LaunchShape sh, hipStream_t s) {
 
 template <int OP, int CW, int MODE, bool LEN = false>
 static hipError_t launch_g(const ScanArgs &a, bool guard, LaunchShape sh, hipStream_t s) {
-    if constexpr (OP == OP_FIND && !LEN && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16)) {
+    if constexpr (OP == OP_FIND && !LEN && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16 || MODE == MODE_SPARSE)) {
         if (a.hdr.fa_len_off) return launch_g<OP, CW, MODE, true>(a, guard, sh, s); // (the only modes such programs have)
     }
     return guard ? launch_h<OP, CW, MODE, true, LEN>(a, sh, s) : launch_h<OP, CW, MODE, false, LEN>(a, sh, s);

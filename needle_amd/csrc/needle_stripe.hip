@@ -685,7 +685,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
     wk.table_off = a.hdr.off_table - a.hdr.win_lo_e; // (window addressing, needle_device.h)
     wk.win_on = a.hdr.win_on, wk.win_lo = a.hdr.win_lo_e, wk.win_hi = a.hdr.win_hi_e;
     wk.sp_chains = 0, wk.sp_pad_ident = 0;
-    wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_n : 0u;
+    wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_hi : 0u;
     wk.lane4 = (uint32_t)(lane & 31) * 4u;
     wk.gtable = (const uint16_t *)(a.prog + a.hdr.off_table);
     const uint32_t accept_lo = MODE == MODE_PACK ? a.hdr.accept_off : a.hdr.accept_lo;

@@ -244,6 +244,25 @@ __device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t 
     return MODE == MODE_TABLE8 ? lds_u8(addr) : lds_u16(addr);
 }
 
+// Compressed lengths programs (needle_device.h): where the END of the row leads from state st -- the target of the END record in
+// the state's chain, the sink if it has none.  Lanes not in `live` keep their state.
+template <int CW>
+__device__ __forceinline__ uint32_t sparse_end(const Walk &wk, uint32_t st, bool live, uint32_t end_key) {
+    const uint32_t tb = CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off;
+    uint32_t r = live ? 0u : st, rec = st >> 16;
+    bool more = live;
+    while (__ballot(more) != 0ull) {
+        if (more) {
+            const u32x2 b = lds_u32x2(rec + tb);
+            const bool hit = (b[0] & 0xFFFFu) == end_key;
+            r = hit ? b[1] : r;
+            more = !hit && b[0] > 0xFFFFu;
+            rec = b[0] >> 16;
+        }
+    }
+    return r;
+}
+
 // Everything of a 16-byte piece's walk that does not depend on the automaton state: per char its F (packed mode) or
 // its column * element size (table modes).  GUARD: chars at p0 + i >= rem take the PAD column, chars at p0 + i < skip PRE.
 template <int MODE, int CW, bool GUARD>
@@ -420,6 +439,7 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
         if (OP == OP_FIND) {
             bool acc = st >= accept_lo;
             if (GUARD) acc = acc && ((uint32_t)i >= skip_rel); // an accepting start state must not count before the cursor
+            if (GUARD && MODE == MODE_SPARSE) acc = acc && (p0 + i < rem); // (lengths programs: the state FREEZES at the row's end)
             lr = acc ? (uint32_t)(i + 1) : lr;
         }
     }

@@ -40,7 +40,7 @@ def test_sparse_match_dictionary_is_lds_resident_as_compressed_automaton():
         assert d["lds_bytes"] + 16 * 64 * 64 <= 160 * 1024 and d["blob_bytes"] == d["lds_bytes"]
         assert 400 <= d["dense_rows"] <= 900 and 2000 <= d["records"] <= 5000
         assert d["window"] == 1 and d["window_lo"] == ord("a") - 1 and d["window_hi"] == ord("z") + 1
-    assert i["forwards"]["chains"] == 1
+    assert i["forwards"]["chains"] == 1 and i["forwards"]["lengths_form"] == 1
 
 
 def test_fallback_ladder():
@@ -82,7 +82,10 @@ def test_find_takes_the_lengths_form_on_lds_tables():
     off = _info(3, 5, 1000, NEEDLE_FIND_LENGTHS="0")
     assert off["forwards"]["mode"] == 2 and off["forwards"]["lengths_form"] == 0
     assert off["forwards"]["n_states"] <= i["forwards"]["n_states"]
-    assert _info(6, 8, 1000)["forwards"]["lengths_form"] == 0
+    # the compressed form carries the lengths automaton too (4487 states; END records instead of an END column): round 3
+    big = _info(6, 8, 1000)["forwards"]
+    assert big["mode"] == 6 and big["lengths_form"] == 1 and big["lds_bytes"] + 16 * 64 * 64 <= 160 * 1024
+    assert _info(6, 8, 1000, NEEDLE_FIND_LENGTHS_SPARSE="0")["forwards"]["lengths_form"] == 0
     from needle_amd.pattern import DFACompiler
     assert DFACompiler.compile("[0-9]+x", "t", 0).program_info("forwards", 1)["lengths_form"] == 0  # unbounded
     assert DFACompiler.compile("(ab|a|bcdef|g)x", "t", 0).program_info("forwards", 1)["lengths_form"] in (0, 1)
