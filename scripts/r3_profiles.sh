@@ -11,8 +11,9 @@ G1="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SMEM"
 G2="SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY"
 G3="SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 NEEDLE_SPARSE=0 NEEDLE_WINDOW=0 scripts/pmc.sh c3s r3hybrid "$G1" "$G2" "$G3" > gpurun_out/pmc_c3s_r3hybrid.log 2>&1
-NEEDLE_WINDOW=0 scripts/pmc.sh c3s r3sparse "$G1" "$G2" "$G3" > gpurun_out/pmc_c3s_r3sparse.log 2>&1
-scripts/pmc.sh c3s r3sparsewin "$G1" "$G2" "$G3" > gpurun_out/pmc_c3s_r3sparsewin.log 2>&1
+NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS_SPARSE=0 scripts/pmc.sh c3s r3sparse "$G1" "$G2" "$G3" > gpurun_out/pmc_c3s_r3sparse.log 2>&1
+NEEDLE_FIND_LENGTHS_SPARSE=0 scripts/pmc.sh c3s r3sparsewin "$G1" "$G2" "$G3" > gpurun_out/pmc_c3s_r3sparsewin.log 2>&1
+scripts/pmc.sh c3s r3sparselen "$G1" "$G2" "$G3" > gpurun_out/pmc_c3s_r3sparselen.log 2>&1
 NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS=0 scripts/pmc.sh c3 r3cmap "$G1" "$G2" "$G3" > gpurun_out/pmc_c3_r3cmap.log 2>&1
 NEEDLE_FIND_LENGTHS=0 scripts/pmc.sh c3 r3window "$G1" "$G2" "$G3" > gpurun_out/pmc_c3_r3window.log 2>&1
 scripts/pmc.sh c3 r3lengths "$G1" "$G2" "$G3" > gpurun_out/pmc_c3_r3lengths.log 2>&1

@@ -24,8 +24,9 @@ def summ(d):
 
 RND = "03"
 sets = [("c3s find: hot rows in LDS + HBM table (round 2's mode; NEEDLE_SPARSE=0 NEEDLE_WINDOW=0)", "pmc_c3s_r3hybrid"),
-        ("c3s find: compressed automaton in LDS, column-map lookups (NEEDLE_WINDOW=0)", "pmc_c3s_r3sparse"),
-        ("c3s find: compressed automaton in LDS + window addressing (shipped)", "pmc_c3s_r3sparsewin"),
+        ("c3s find: compressed automaton in LDS, column-map lookups, backward walks (NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS_SPARSE=0)", "pmc_c3s_r3sparse"),
+        ("c3s find: compressed automaton in LDS + window addressing, backward walks (NEEDLE_FIND_LENGTHS_SPARSE=0)", "pmc_c3s_r3sparsewin"),
+        ("c3s find: + the lengths automaton in the compressed form, no backward walk (shipped)", "pmc_c3s_r3sparselen"),
         ("c3 find: LDS table u16, column-map lookups, backward walks (NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS=0)", "pmc_c3_r3cmap"),
         ("c3 find: LDS table u16 + window addressing, backward walks (NEEDLE_FIND_LENGTHS=0)", "pmc_c3_r3window"),
         ("c3 find: + the lengths automaton, no backward walk (shipped)", "pmc_c3_r3lengths"),
