@@ -1,0 +1,73 @@
+"""Random DICTIONARIES against the oracle: keyword unions big enough for the compressed automaton (mode 6) and its lengths program, with
+keywords that are prefixes / suffixes / infixes of one another (states with a match pending that live on: END records, D_L rows as
+default rows), planted at row ends and cut by ragged lengths.  python scripts/dictionary_fuzz.py <seed0> <n>
+(child processes: NEEDLE_MAX_PROG_LDS is read once per process)"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CODE = r'''
+import sys, random, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from needle_amd.pattern import DFACompiler, unpack_bitmap
+from test_compile_matches_txt import oracle_for
+seed = int(sys.argv[1])
+rng = random.Random(seed)
+alpha = "abcdefghijklmnopqrstuvwxyz"[:rng.choice([8, 14, 26, 26])]
+n_kw = rng.choice([150, 400, 900])
+lo, hi = rng.choice([(3, 6), (5, 8), (6, 9), (2, 9)])
+words = set()
+while len(words) < n_kw:
+    w = "".join(rng.choice(alpha) for _ in range(rng.randint(lo, hi)))
+    words.add(w)
+    r = rng.random()
+    if r < 0.15 and len(w) > lo: words.add(w[:rng.randint(max(2, lo - 1), len(w) - 1)])      # a proper prefix
+    elif r < 0.25 and len(w) > 3: words.add(w[rng.randint(1, len(w) - 2):])                    # a proper suffix
+    elif r < 0.30: words.add(w + "".join(rng.choice(alpha) for _ in range(rng.randint(1, 3))))  # an extension
+words = sorted(words)
+rng.shuffle(words)
+rx = "|".join(words)
+p = DFACompiler.compile(rx, "t", 0)
+o, _ = oracle_for(rx, 0)
+pi = p.program_info("forwards", 1)
+n, width = 20011, rng.choice([64, 112, 256])
+nr = np.random.default_rng(seed)
+noise = np.array([ord(c) for c in alpha + " "], dtype=np.uint8)
+rows = nr.choice(noise, (n, width))
+for r in range(0, n, 3):  # plant: anywhere, at the very end, cut by the end
+    w = np.frombuffer(words[nr.integers(len(words))].encode(), dtype=np.uint8)
+    k = r % 9
+    if k == 0: rows[r, width - len(w):] = w
+    elif k == 3 and len(w) > 1: rows[r, width - len(w) + 1:] = w[:-1]
+    else:
+        at = int(nr.integers(0, width - len(w) + 1)); rows[r, at:at + len(w)] = w
+lens = nr.integers(0, width + 1, n).astype(np.uint32)
+t = torch.from_numpy(rows).cuda()
+tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+for l, dl in ((None, None), (lens, tl)):
+    fw, fs, fe = p.find_batch(t, dl)
+    of, ofs, ofe = o.batch_find(rows, l, threads=8)
+    assert (unpack_bitmap(fw, n) == of).all(), ("find bitmap", seed)
+    assert (fs.cpu().numpy() == ofs).all() and (fe.cpu().numpy() == ofe).all(), ("find start/end", seed)
+    cur = torch.where(torch.from_numpy(of).cuda(), fe, torch.full_like(fe, -1))
+    nw, ns, ne = p.find_next_batch(t, cur, dl)
+    nw, ns, ne = unpack_bitmap(nw, n), ns.cpu().numpy(), ne.cpu().numpy()
+    for i in range(0, n, 53):
+        a = o.find_all(rows[i] if l is None else rows[i, :l[i]])
+        if len(a) >= 2: assert nw[i] and (ns[i], ne[i]) == a[1], ("second find", seed, i)
+        else: assert not nw[i], ("second find", seed, i)
+    assert (unpack_bitmap(p.contained_in_batch(t, dl), n) == o.batch_contained_in(rows, l, threads=8)).all(), ("containedIn", seed)
+print("DICT-OK seed %d: %d keywords over %d letters, %d states, mode %d, lengths form %d, %d of %d rows match" % (
+    seed, len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"], int(of.sum()), n))
+'''
+if __name__ == "__main__":
+    seed0, cnt = int(sys.argv[1]), int(sys.argv[2])
+    bad = 0
+    for seed in range(seed0, seed0 + cnt):
+        env = dict(os.environ)
+        if seed % 4: env["NEEDLE_MAX_PROG_LDS"] = str([12000, 20000, 40000][seed % 3])  # smaller dictionaries into the compressed form too
+        r = subprocess.run([sys.executable, "-c", CODE, str(seed)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
+        line = [x for x in r.stdout.splitlines() if x.startswith("DICT-OK")]
+        if line: print(line[0], "(LDS budget %s)" % env.get("NEEDLE_MAX_PROG_LDS", "default"))
+        else:
+            bad += 1
+            print("FAILED seed", seed, r.stdout[-500:], r.stderr[-1500:])
+    print("dictionary campaign done: %d seeds, %d failures" % (cnt, bad))

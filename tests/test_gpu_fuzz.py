@@ -100,3 +100,27 @@ def test_random_regexes_on_random_haystacks(seed):
         assert (unpack_bitmap(p.matches_batch(tl, tll), 3) == o.batch_matches(long_rows, long_lens, threads=3)).all(), (regex, flags, "long")
         assert (unpack_bitmap(p.contained_in_batch(tl, tll), 3) == o.batch_contained_in(long_rows, long_lens, threads=3)).all(), (regex, flags, "long")
     assert modes  # (which device modes a seed draws varies: packed functions, pair table, uint8 table)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,lds", [(202, "20000"), (205, "20000"), (210, "12000"), (233, "40000"), (235, None)])
+def test_random_dictionaries(seed, lds):
+    """scripts/dictionary_fuzz.py: random keyword unions whose keywords are prefixes / suffixes / extensions of one another, planted
+    anywhere, at the very end of a row and cut by it, full and ragged rows, second find() from the cursor -- against the oracle.
+    The seeds here land in the compressed automaton (mode 6) with its lengths program (END records, D_L rows as default rows)
+    and, the last one, without it."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dictionary_fuzz", os.path.join(root, "scripts", "dictionary_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    env = dict(os.environ)
+    if lds:
+        env["NEEDLE_MAX_PROG_LDS"] = lds
+    r = subprocess.run([sys.executable, "-c", mod.CODE, str(seed)], env=env, capture_output=True, text=True, cwd=root, timeout=900)
+    assert "DICT-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    if seed != 235:
+        assert "mode 6, lengths form 1" in r.stdout, r.stdout[-300:]
