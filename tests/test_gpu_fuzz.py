@@ -103,7 +103,7 @@ def test_random_regexes_on_random_haystacks(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,lds", [(202, "20000"), (205, "20000"), (210, "12000"), (233, "40000"), (235, None)])
+@pytest.mark.parametrize("seed,lds", [(202, "20000"), (205, "20000"), (210, "12000"), (233, "40000"), (235, "20000")])
 def test_random_dictionaries(seed, lds):
     """scripts/dictionary_fuzz.py: random keyword unions whose keywords are prefixes / suffixes / extensions of one another, planted
     anywhere, at the very end of a row and cut by it, full and ragged rows, second find() from the cursor -- against the oracle.
@@ -122,5 +122,4 @@ def test_random_dictionaries(seed, lds):
         env["NEEDLE_MAX_PROG_LDS"] = lds
     r = subprocess.run([sys.executable, "-c", mod.CODE, str(seed)], env=env, capture_output=True, text=True, cwd=root, timeout=900)
     assert "DICT-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
-    if seed != 235:
-        assert "mode 6, lengths form 1" in r.stdout, r.stdout[-300:]
+    assert ("mode 6, lengths form 1" if seed != 235 else "mode 6, lengths form 0") in r.stdout, r.stdout[-300:]  # (235: it does not fit 20 KB)
