@@ -75,5 +75,11 @@ if os.path.isdir(aux):
         for d in ("short16", "short64", "long"):
             f.write("".join(line for line in open(os.path.join(aux, d + ".log")) if "amdgpu.ids" not in line))
         f.write("```\n\nKernel tables (rocprofv3's `*_kernel_stats.csv`, verbatim): `r03_short_rows_16B_kernel_stats.csv`, `r03_short_rows_64B_kernel_stats.csv` "
-                "(`needle::short_kernel<OP, CW, MODE>`), `r03_long_rows_1000x1MiB_kernel_stats.csv` (`needle::stripe_kernel<CW, FIND, NS>`, `stripe_prefix_kernel`).\n")
+                "(`needle::short_kernel<OP, CW, MODE>`), `r03_long_rows_1000x1MiB_kernel_stats.csv` (`needle::stripe_kernel<CW, FIND, NS>`, `stripe_prefix_kernel`).\n\n"
+                "Reading the short-row lines: `containedIn` on 16- and 32-byte rows runs two workgroups per CU since round 3 (3.8 -> 4.8-5.3 TB/s on 16-byte rows), "
+                "`find` cannot (its text slots leave no LDS for a second copy of the program) and writes 8 result bytes per row -- half of what it reads on 16-byte rows.  "
+                "With start := end, i.e. with NO backward walk at all (`scripts/r3_short_bound.sh`, tuning build), `find` takes 1.06 / 0.75 / 0.58 ms on 16 / 32 / 64-byte rows "
+                "against 1.74 / 1.09 / 0.80 ms as shipped: the round-2 review's bar (`find` >= 0.6 x `containedIn`) is out of reach on 16- and 32-byte rows whatever the backward "
+                "walk costs, and met on the stripe path (0.32 vs 0.28 ms: the re-walk takes one candidate stripe per row).  Bounded-length patterns (keyword unions) take the "
+                "lengths automaton and lose the backward walk altogether: 32-byte rows under a 300-keyword dictionary 1.33 -> 0.85 ms (`r03_find_forms_ab.log`).\n")
 print(open(os.path.join(root, "profiles", "r%s_pmc.md" % RND)).read())
