@@ -251,7 +251,8 @@ static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v
 static bool find_lengths_for(uint32_t mode) {
     static const int level = getenv("NEEDLE_FIND_LENGTHS") ? atoi(getenv("NEEDLE_FIND_LENGTHS")) : 1;
     static const bool sparse_too = !(getenv("NEEDLE_FIND_LENGTHS_SPARSE") && atoi(getenv("NEEDLE_FIND_LENGTHS_SPARSE")) == 0);
-    return level > 0 && (mode == MODE_TABLE8 || mode == MODE_TABLE16 || (sparse_too && mode == MODE_SPARSE) || (level > 1 && mode == MODE_PAIR));
+    static const bool pair_too = !(getenv("NEEDLE_FIND_LENGTHS_PAIR") && atoi(getenv("NEEDLE_FIND_LENGTHS_PAIR")) == 0);
+    return level > 0 && (mode == MODE_TABLE8 || mode == MODE_TABLE16 || (sparse_too && mode == MODE_SPARSE) || ((pair_too || level > 1) && mode == MODE_PAIR));
 }
 
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
@@ -414,6 +415,10 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
         const DevProgram *lp = nullptr;
         rc = get_program(p, W_FORWARDS, (int)v->char_width, 7, &lp, nullptr);
         if (rc) return rc;
+        // (a pair-table automaton whose lengths program no longer fits the pair table keeps its two walks: two chars per lookup
+        // beat the saved backward walk -- NEEDLE_FIND_LENGTHS=2 takes the plain table all the same)
+        static const bool force_tables = getenv("NEEDLE_FIND_LENGTHS") && atoi(getenv("NEEDLE_FIND_LENGTHS")) > 1;
+        if (lp && fp->prog.hdr.mode == MODE_PAIR && lp->prog.hdr.mode != MODE_PAIR && !force_tables) lp = nullptr;
         if (lp) fp = lp, lengths_form = true;
     }
     ScanArgs a;
@@ -956,7 +961,9 @@ int needle_pattern_program_info(const needle_pattern *p, int which, int char_wid
         const MatchLengths ml = match_length_automaton(p->t);
         if (ml.ok) {
             Program lp = lower_match_lengths(p->t, ml, char_width, max_prog_lds(), false);
-            if (!lp.blob.empty()) pr = std::move(lp), o->lengths_form = 1;
+            static const bool force_tables = getenv("NEEDLE_FIND_LENGTHS") && atoi(getenv("NEEDLE_FIND_LENGTHS")) > 1;
+            const bool pair_lost = pr.hdr.mode == MODE_PAIR && lp.hdr.mode != MODE_PAIR && !force_tables;
+            if (!lp.blob.empty() && !pair_lost) pr = std::move(lp), o->lengths_form = 1;
         }
     }
     o->mode = (int32_t)pr.hdr.mode;

@@ -522,7 +522,8 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     // when [state][col][col] fits, one lookup advances TWO chars.  NEEDLE_PAIR_MAX_BYTES=0 turns it off (A/B, tests).
     static const size_t pair_budget = getenv("NEEDLE_PAIR_MAX_BYTES") ? (size_t)atol(getenv("NEEDLE_PAIR_MAX_BYTES")) : (size_t)(96u << 10);
     const size_t pair_bytes = (size_t)n_dev * n_cols * n_cols * 2;
-    if (!no_pair && !ml && mode == MODE_TABLE8 && char_width == 1 && pair_bytes <= pair_budget && pair_bytes + 4096 <= lds_table_budget) mode = MODE_PAIR;
+    // (ml: the scan kernels' lengths programs take the pair table too -- D_L states are ordinary absorbing rows of it)
+    if (!no_pair && mode == MODE_TABLE8 && char_width == 1 && pair_bytes <= pair_budget && pair_bytes + 4096 <= lds_table_budget) mode = MODE_PAIR;
 
     // Window addressing for the table modes (needle_device.h; not for the plain layouts other kernels walk: global_walk, the
     // HBM-table variant with no LDS budget, the find-all programs).  NEEDLE_WINDOW=0 turns it off (A/B, tests).
@@ -946,7 +947,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
             p.hdr.fa_dead_n = (uint32_t)ml->n_dead;
             return p;
         }
-        if (mode != MODE_TABLE8 && mode != MODE_TABLE16) {
+        if (mode != MODE_TABLE8 && mode != MODE_TABLE16 && mode != MODE_PAIR) {
             p.blob.clear();
             p.hdr.mode = MODE_GLOBAL;
             return p;

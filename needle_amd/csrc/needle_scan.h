@@ -607,7 +607,7 @@ static hipError_t launch_h(const ScanArgs &a, LaunchShape sh, hipStream_t s) {
 
 template <int OP, int CW, int MODE, bool LEN = false>
 static hipError_t launch_g(const ScanArgs &a, bool guard, LaunchShape sh, hipStream_t s) {
-    if constexpr (OP == OP_FIND && !LEN && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16 || MODE == MODE_SPARSE)) {
+    if constexpr (OP == OP_FIND && !LEN && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16 || MODE == MODE_SPARSE || MODE == MODE_PAIR)) {
         if (a.hdr.fa_len_off) return launch_g<OP, CW, MODE, true>(a, guard, sh, s); // (the only modes such programs have)
     }
     return guard ? launch_h<OP, CW, MODE, true, LEN>(a, sh, s) : launch_h<OP, CW, MODE, false, LEN>(a, sh, s);

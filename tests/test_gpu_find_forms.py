@@ -26,7 +26,7 @@ for rx, mode, plant in cases:
     o, _ = oracle_for(rx, 0)
     for cw in (1, 2):
         pi = p.program_info("forwards", cw)
-        if pi["mode"] in (1, 2, 6):
+        if pi["mode"] in (1, 2, 4, 6):
             assert pi["lengths_form"] == want_form, (rx[:40], pi)
     if mode is not None:
         assert p.program_info("forwards", 1)["mode"] == mode, p.program_info("forwards", 1)

@@ -87,5 +87,7 @@ def test_find_takes_the_lengths_form_on_lds_tables():
     assert big["mode"] == 6 and big["lengths_form"] == 1 and big["lds_bytes"] + 16 * 64 * 64 <= 160 * 1024
     assert _info(6, 8, 1000, NEEDLE_FIND_LENGTHS_SPARSE="0")["forwards"]["lengths_form"] == 0
     from needle_amd.pattern import DFACompiler
+    names = DFACompiler.compile("Sherlock|Holmes|Watson|Irene|Adler|John|Baker", "t", 0).program_info("forwards", 1)
+    assert names["mode"] == 4 and names["lengths_form"] == 1  # the pair table carries the lengths automaton too (40 states)
     assert DFACompiler.compile("[0-9]+x", "t", 0).program_info("forwards", 1)["lengths_form"] == 0  # unbounded
     assert DFACompiler.compile("(ab|a|bcdef|g)x", "t", 0).program_info("forwards", 1)["lengths_form"] in (0, 1)
