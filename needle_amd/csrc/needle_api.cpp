@@ -30,6 +30,11 @@ hipError_t launch_spec_reduce(const SpecArgs &a, hipStream_t stream);
 hipError_t launch_backward_rows(int char_width, const StripeArgs &a, hipStream_t stream);
 bool dict_kernel_applies(int char_width, const ScanArgs &a);                      // needle_dict.hip: two row sets per wave
 hipError_t launch_dict(int op, const ScanArgs &a, int n_cus, hipStream_t stream);
+// needle_ngram.hip: containedIn / find behind the n-gram candidate filter
+bool ngram_shape_ok(const ScanArgs &a);
+size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng);
+hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, int n_cus, hipStream_t stream);
+int ngram_level(); // needle_lower.cpp (NEEDLE_PREFILTER)
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
 } // namespace needle
@@ -98,6 +103,7 @@ static int hip_fail(hipError_t e, const char *what) {
 struct DevProgram {
     Program prog;
     uint8_t *d_blob = nullptr;
+    uint32_t *d_ng = nullptr; // the n-gram filter's bitmap (prog.ng.p.on)
 };
 
 struct needle_pattern {
@@ -114,8 +120,10 @@ struct needle_pattern {
     int ml_state = 0;       // 0: not analysed yet, 1: find-all can report starts as end - length (ml), -1: it cannot
     MatchLengths ml;
     ~needle_pattern() {
-        for (auto &kv : cache)
+        for (auto &kv : cache) {
             if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
+            if (kv.second.d_ng) (void)hipFree(kv.second.d_ng);
+        }
     }
 };
 
@@ -161,6 +169,16 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
         if (hipError_t ce = hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice); ce != hipSuccess) {
             (void)hipFree(dp.d_blob);
             return hip_fail(ce, "hipMemcpy(program blob)");
+        }
+        if (dp.prog.ng.p.on) {
+            const size_t nb = dp.prog.ng.bitmap.size() * 4;
+            hipError_t ce = hipMalloc((void **)&dp.d_ng, nb);
+            if (ce == hipSuccess) ce = hipMemcpy(dp.d_ng, dp.prog.ng.bitmap.data(), nb, hipMemcpyHostToDevice);
+            if (ce != hipSuccess) {
+                (void)hipFree(dp.d_blob);
+                if (dp.d_ng) (void)hipFree(dp.d_ng);
+                return hip_fail(ce, "hipMalloc/hipMemcpy(n-gram bitmap)");
+            }
         }
         it = p->cache.emplace(key, std::move(dp)).first;
     }
@@ -483,6 +501,14 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
         a.total_bytes = a.n_rows * a.stride_bytes;
         a.bitmap += done_rows >> 6;
         if (a.start) a.start += done_rows, a.end += done_rows;
+    }
+    // The n-gram candidate filter (needle_ngram.hip): the automaton only runs where a hashed 4-byte window of the
+    // text can stand ahead of a match.  For programs whose lowering established that this gives the reference's answers
+    // (needle_ngram_host.cpp), on containedIn() and on find() whose start is end - length (lengths programs, one-length patterns).
+    if (fp->d_ng && fp->prog.ng.p.on && ngram_level() > 0 && v->char_width == 1 && op != OP_MATCHES && !skip_backward &&
+        (op == OP_CONTAINED_IN || lengths_form || a.fixed_len >= 0) && ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, fp->prog.ng.p)) {
+        HIP_TRY(launch_ngram(op, a, fp->prog.ng.p, fp->d_ng, n_cus, (hipStream_t)stream));
+        return NEEDLE_OK;
     }
     HIP_TRY(launch_scan(op, (int)v->char_width, a, n_cus, (hipStream_t)stream));
     return NEEDLE_OK;
@@ -982,6 +1008,42 @@ int needle_pattern_program_info(const needle_pattern *p, int which, int char_wid
         o->window_lo = (int32_t)(pr.hdr.win_lo_e / e);
         o->window_hi = (int32_t)(pr.hdr.win_hi_e / e);
     }
+    return NEEDLE_OK;
+}
+
+// The n-gram candidate filter (needle_ngram_host.h) of the program containedIn() (which = 1) / find() (which = 2) runs on 8-bit
+// rows, as run_dev chooses it: whether there is one, its parameters, why not, and (bitmap != NULL) the bitmap itself.
+int needle_pattern_prefilter_info(const needle_pattern *p, int which, needle_prefilter_info *o, uint32_t *bitmap) {
+    if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    if (which != W_CONTAINED_IN && which != W_FORWARDS) return fail(NEEDLE_ERR_INVALID, "which must be 1 (contained_in) or 2 (forwards)");
+    memset(o, 0, sizeof(*o));
+    const bool backward = which == W_FORWARDS && p->t.fixed_len < 0;
+    Program pr = lower(p->t, (Which)which, 1, max_prog_lds(), false, backward);
+    bool usable = which == W_CONTAINED_IN || p->t.fixed_len >= 0;
+    if (backward && find_lengths_for(pr.hdr.mode)) {
+        const MatchLengths ml = match_length_automaton(p->t);
+        if (ml.ok) {
+            Program lp = lower_match_lengths(p->t, ml, 1, max_prog_lds(), false);
+            static const bool force_tables = getenv("NEEDLE_FIND_LENGTHS") && atoi(getenv("NEEDLE_FIND_LENGTHS")) > 1;
+            const bool pair_lost = pr.hdr.mode == MODE_PAIR && lp.hdr.mode != MODE_PAIR && !force_tables;
+            if (!lp.blob.empty() && !pair_lost) pr = std::move(lp), usable = true;
+        }
+    }
+    const NgramFilter &f = pr.ng;
+    o->mode = (int32_t)pr.hdr.mode;
+    if (!usable) {
+        snprintf(o->why, sizeof(o->why), "find() needs its backward walk for this pattern");
+        return NEEDLE_OK;
+    }
+    o->on = (int32_t)(f.p.on && ngram_lds_bytes(pr.hdr, f.p) ? 1 : 0);
+    o->stride = (int32_t)f.p.stride;
+    o->warm = (int32_t)f.p.warm;
+    o->min_len = (int32_t)f.p.min_len;
+    o->n_windows = (int32_t)f.p.n_grams;
+    o->bitmap_bytes = (int32_t)f.p.bm_bytes;
+    o->m1 = f.p.m1, o->m2 = f.p.m2, o->addr_shift = f.p.addr_shift, o->addr_mask = f.p.addr_mask;
+    snprintf(o->why, sizeof(o->why), "%s", f.p.on ? "" : (f.why.empty() ? (ngram_level() > 0 ? "not a mode the filter is built for" : "NEEDLE_PREFILTER=0") : f.why.c_str()));
+    if (bitmap && f.p.on) memcpy(bitmap, f.bitmap.data(), f.bitmap.size() * 4);
     return NEEDLE_OK;
 }
 

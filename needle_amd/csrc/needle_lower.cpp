@@ -10,6 +10,7 @@
 //   * ragged rows              -> a PAD column (identity for matches/containedIn, sink for the index walks)
 //   * wasAccepted<X>(state)    -> states renumbered so that accepted(s) == (s >= A0)
 #include "needle_lower.h"
+#include "needle_ngram_host.h"
 #include <algorithm>
 #include <array>
 #include <cstdio>
@@ -420,8 +421,45 @@ bool build_sparse(const std::vector<uint16_t> &next_full, int n_dev, int n_cols_
 }
 } // namespace
 
+namespace {
+// what the n-gram filter analysis (needle_ngram_host.cpp) needs of a lowering: the device-numbered table before any encoding
+struct LowerAux {
+    std::vector<uint16_t> next;
+    std::vector<uint8_t> cmap8;
+    int n_dev = 0, n_cols = 0, start = 0, accept_lo = 0, dead_hi = 0;
+};
+} // namespace
+static Program lower_core(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
+                          bool with_backward_maps, bool no_pair, const MatchLengths *ml, LowerAux *aux);
+
+// NEEDLE_PREFILTER: 0 = never build / use the n-gram candidate filter, 1 (default) = for automata in the compressed form
+// (MODE_SPARSE: the walk is latency-bound there), 2 = for every LDS table automaton that allows one (tests, A/B)
+int ngram_level() {
+    static const int level = getenv("NEEDLE_PREFILTER") ? atoi(getenv("NEEDLE_PREFILTER")) : 1;
+    return level;
+}
+
 Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
               bool with_backward_maps, bool no_pair, const MatchLengths *ml) {
+    // The scan kernels' containedIn / forward programs on 8-bit rows may carry an n-gram candidate filter (needle_ngram_host.h).
+    const bool want = ngram_level() > 0 && char_width == 1 && !global_walk && !no_pair && lds_table_budget > 0 &&
+                      (which == W_CONTAINED_IN || which == W_FORWARDS);
+    LowerAux aux;
+    Program p = lower_core(t, which, char_width, lds_table_budget, global_walk, with_backward_maps, no_pair, ml, want ? &aux : nullptr);
+    memset(&p.ng.p, 0, sizeof(p.ng.p));
+    if (!want || p.blob.empty()) return p;
+    const bool mode_ok = p.hdr.mode == MODE_SPARSE || (ngram_level() > 1 && (p.hdr.mode == MODE_TABLE8 || p.hdr.mode == MODE_TABLE16));
+    if (!mode_ok) return p;
+    // LDS left beside the program: 16 waves x (queue + row slots) of the filter kernel (needle_ngram.hip)
+    const size_t used = ((p.hdr.lds_bytes + 15u) & ~15u) + 16u * 1024u;
+    const size_t room = used < 160u * 1024u ? 160u * 1024u - used : 0;
+    p.ng = build_ngram_filter(aux.next.data(), aux.n_dev, aux.n_cols, aux.cmap8.data(), aux.start, aux.accept_lo, aux.dead_hi,
+                              which == W_CONTAINED_IN, room);
+    return p;
+}
+
+static Program lower_core(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
+                          bool with_backward_maps, bool no_pair, const MatchLengths *ml, LowerAux *aux) {
     // ml (W_FORWARDS only): the refined "lengths" automaton stands in for the reference's search automaton (needle_lower.h)
     const RefDfa &d = ml ? ml->dfa : t.dfa[which];
     const int N = t.stride;
@@ -478,6 +516,14 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
         for (int c = 0; c < n_cols; ++c) row[c] = (uint16_t)(k == 1 ? dev[0] : skip_lo + k - 2);
     }
 
+    if (aux) {
+        aux->next = next;
+        aux->n_dev = n_dev;
+        aux->n_cols = n_cols;
+        aux->start = dev[0];
+        aux->accept_lo = accept_lo;
+        aux->dead_hi = ml ? ml->n_dead : 0;
+    }
     Program p;
     memset(&p.hdr, 0, sizeof(p.hdr));
     p.hdr.n_states = n_dev;
@@ -489,6 +535,7 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
 
     const ColumnMaps cm = column_maps(t, d, char_width);
     p.hdr.n_pages = (uint32_t)(cm.pages.size() / 256);
+    if (aux) aux->cmap8 = cm.cmap8;
 
     if (global_walk) {
         // backward automaton of find(): only the uint16 table, read from HBM/L2 (its column maps travel inside the

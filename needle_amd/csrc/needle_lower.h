@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 #include "needle_device.h"
+#include "needle_ngram_host.h"
 
 namespace needle {
 
@@ -29,6 +30,7 @@ struct RefTables {
 struct Program {
     ProgHeader hdr;
     std::vector<uint8_t> blob;
+    NgramFilter ng; // ng.p.on: the program may run behind the n-gram candidate filter (needle_ngram_host.h)
 };
 
 // ByteClassUtil.fillMultipleByteClassesFromString*_singleArray (needle-types/.../ByteClassUtil.java:50-120)

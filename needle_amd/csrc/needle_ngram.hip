@@ -1,0 +1,325 @@
+// needle_ngram.hip -- containedIn() / find() behind the n-gram candidate filter: hand-written for gfx950.
+//
+// The ordinary kernel (needle_scan.h) walks the automaton over every char of every row; with an automaton that fills the LDS
+// (a 1000-keyword dictionary: 4487 states, 96 KB) that walk is a chain of dependent LDS lookups at 1024 chains per CU and runs
+// at 0.30 of the HBM rate.  Here the text is never transposed and no lane owns a row: the batch is one byte stream, a lane
+// tests the windows that end in the 16 bytes IT loaded (needle_ngram.h: no dependence between chars), and the automaton only
+// runs where a window passes -- one candidate per lane, 64 candidates at a time, K + S - 1 chars each, on text re-read from
+// L2 -- from the start state, K chars ahead of the window's end.  What makes that the same answer as the reference's walk from
+// the row's start (DFAClassBuilder.java:438-468 indexForwards, :1004-1022 containedIn) is established on the table by
+// needle_ngram_host.cpp: a restarted walk has caught up after K chars, and no first accept happens without a window in the bitmap.
+//
+// Per wave: 64-row groups, as in the scan kernel (one bitmap word per group).  A group is a contiguous run of 64 * stride
+// bytes = a whole number of 1 KiB units (stride % 64 == 0: four units per batch); unit u is loaded as 64 lanes x 16 bytes,
+// four units in flight.  Candidates -- byte offset of the window's END inside the group -- go to the wave's LDS queue; full
+// sets of 64 are run as soon as they exist, the rest at the group's end.  A run that accepts reports (first accepting index,
+// end, start) to its row's LDS slot by a 64-bit minimum: several windows of a row may find matches, the reference's is the one
+// that accepts first.  find() takes "lengths" programs (start = end - pend[stop state], needle_lower.h) or patterns of one
+// length (DFAClassBuilder.java:640-646).
+#include "needle_walk.h"
+#include "needle_ngram.h"
+
+namespace needle {
+
+struct NgramArgs {
+    ScanArgs a;
+    NgramParams ng;
+    const uint32_t *ng_bitmap;
+    uint32_t stride_log2;   // stride_bytes is a power of two (else 0xFFFFFFFF)
+    uint32_t stride_recip;  // floor(2^32 / stride_bytes)
+};
+
+constexpr uint32_t kNgQueue = 128;                      // candidates a wave can hold (at most 63 wait while 64 more arrive)
+constexpr uint32_t kNgWaveLds = kNgQueue * 4 + 64 * 8;  // queue + one u64 slot per row of the group
+constexpr int kNgPF = 4;                                // units in flight per wave = units per batch
+
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+
+template <int OP, int MODE, int S>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramArgs A) {
+    const ScanArgs &a = A.a;
+    constexpr int NW = 16 / S; // windows per 16-byte piece
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = blockDim.x >> 6;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    const uint32_t bm_base = (a.hdr.lds_bytes + 15u) & ~15u;
+    for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
+    for (uint32_t i = tid * 16u; i < A.ng.bm_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + bm_base + i) = *(const u32x4 *)((const uint8_t *)A.ng_bitmap + i);
+    __syncthreads();
+
+    Walk wk;
+    constexpr uint32_t ELEM = MODE == MODE_TABLE16 ? 2u : 1u;
+    wk.ncols_e = a.hdr.n_cols * ELEM;
+    wk.pad_e = wk.pre_e = wk.pad_b = wk.pre_b = 0;
+    wk.win_on = a.hdr.win_on;
+    wk.win_lo = a.hdr.win_lo_e;
+    wk.win_hi = a.hdr.win_hi_e;
+    wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_hi : 0u;
+    wk.sp_chains = a.hdr.sp_chains;
+    wk.sp_pad_ident = a.hdr.sp_pad_ident;
+    wk.table_off = a.hdr.off_table - (MODE == MODE_SPARSE ? 0u : a.hdr.win_lo_e);
+    wk.lane4 = 0;
+    wk.gtable = nullptr;
+    wk.hot_last = 0;
+    const uint32_t accept_lo = a.hdr.accept_lo, start_state = a.hdr.start;
+    const uint32_t qbase = bm_base + A.ng.bm_bytes + (uint32_t)wave * kNgWaveLds;
+    const uint32_t sbase = qbase + kNgQueue * 4u;
+    const uint32_t m1 = A.ng.m1, m2 = A.ng.m2, ash = A.ng.addr_shift, amask = A.ng.addr_mask;
+    const uint32_t K = A.ng.warm;
+    const uint32_t stride = (uint32_t)a.stride_bytes;
+
+    const uint64_t n_groups = (a.n_rows + 63) >> 6;
+    const uint64_t wave_cnt = (uint64_t)gridDim.x * n_waves;
+    uint64_t g = (uint64_t)blockIdx.x * n_waves + wave;
+    if (g >= n_groups) return;
+    const uint32_t units_full = (64u * stride) >> 10; // a multiple of kNgPF (stride % 64 == 0)
+    auto units_of = [&](uint64_t grp) -> uint32_t {
+        if (grp + 1 < n_groups) return units_full;
+        const uint32_t rows_in = (uint32_t)(a.n_rows - (grp << 6));
+        return (((rows_in * stride + 1023u) >> 10) + (kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
+    };
+    // 16 bytes of unit `unit` of group `grp`.  Always issued (a load under a branch makes the compiler drain vmcnt at the join);
+    // units past the batch are read from its last KiB, lanes past it from its last 16 bytes -- never used.
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    auto load_unit = [&](uint64_t grp, uint32_t unit) __attribute__((always_inline)) -> u32x4 {
+        uint64_t base = (grp << 6) * a.stride_bytes + ((uint64_t)unit << 10);
+        uint32_t off = lane16;
+        if (base + 1024u > a.total_bytes) { // wave-uniform: the batch's last, partial unit, or a prefetch past the end
+            if (base + 16u > a.total_bytes) base = a.total_bytes - 16u;
+            const uint32_t room = (uint32_t)(a.total_bytes - 16u - base);
+            off = off < room ? off : room;
+        }
+        return *(const u32x4 *)(a.rows + base + off);
+    };
+
+    // prefetch cursor: kNgPF units ahead of the batch being filtered
+    uint64_t pf_g = g;
+    uint32_t pf_u = 0, pf_units = units_of(g);
+    auto pf_advance = [&]() __attribute__((always_inline)) {
+        if (++pf_u == pf_units) {
+            pf_u = 0;
+            pf_g += wave_cnt;
+            pf_units = pf_g < n_groups ? units_of(pf_g) : (uint32_t)kNgPF;
+        }
+    };
+    u32x4 R[kNgPF];
+#pragma unroll
+    for (int k = 0; k < kNgPF; ++k) {
+        R[k] = load_unit(pf_g, pf_u);
+        pf_advance();
+    }
+
+    uint32_t qhead = 0, qtail = 0; // wave-uniform
+    for (; g < n_groups; g += wave_cnt) {
+        const uint32_t rows_in = (g + 1 < n_groups) ? 64u : (uint32_t)(a.n_rows - (g << 6));
+        const uint32_t gbytes = rows_in * stride;
+        const uint32_t units = units_of(g);
+        // ---- the group's result slots
+        if (OP == OP_FIND) *(lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u) = ~0ull;
+        else if (lane == 0) *(lds_u64_t *)(uintptr_t)sbase = 0ull;
+        uint32_t carry = 0; // (the window reaching back from a row's first bytes is dropped below: what it holds does not matter)
+        for (uint32_t u0 = 0; u0 < units; u0 += kNgPF) {
+            // ---- filter: four units, each slot re-loaded for the batch after next as soon as it is read
+            uint32_t log = 0;
+#pragma unroll
+            for (int k = 0; k < kNgPF; ++k) {
+                const u32x4 v = R[k];
+                asm volatile("" ::: "memory");
+                R[k] = load_unit(pf_g, pf_u);
+                pf_advance();
+                asm volatile("" ::: "memory");
+                const uint32_t pw = ngram_prev_dword(v[3], carry);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);
+                log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], m1, m2, ash, amask, bm_base);
+            }
+            const uint32_t po0 = (u0 << 10) + lane16; // byte offset of this lane's piece of the batch's first unit
+            if (NW * kNgPF < 32) log >>= 32 - NW * kNgPF; // window wi of unit j at bit j * NW + wi
+            if (gbytes < ((u0 + kNgPF) << 10)) { // wave-uniform: the batch's last group: pieces past its rows hold nothing
+#pragma unroll
+                for (int k = 0; k < kNgPF; ++k)
+                    if (po0 + ((uint32_t)k << 10) >= gbytes) log &= ~(((1u << NW) - 1u) << (k * NW));
+            }
+            // ---- candidates to the queue; full sets of 64 run at once, the rest with the group's last batch
+            const bool last_batch = u0 + kNgPF >= units;
+            for (;;) {
+                const uint64_t any = __ballot(log != 0u);
+                if (any != 0ull) {
+                    const bool has = log != 0u;
+                    const uint32_t b = (uint32_t)__builtin_ctz(log | 0x80000000u);
+                    const uint32_t e = po0 + ((b / NW) << 10) + ((b % NW) + 1u) * S; // end of the window inside the group
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                    if (has) *(lds_u32_t *)(uintptr_t)(qbase + (((qtail + rank) & (kNgQueue - 1u)) << 2)) = e;
+                    qtail += (uint32_t)__builtin_popcountll(any);
+                    log &= log - 1u;
+                }
+                const bool more = __ballot(log != 0u) != 0ull;
+                const uint32_t thr = (more || !last_batch) ? 64u : 1u;
+                while (qtail - qhead >= thr) {
+                    // ---- run the automaton on up to 64 candidates, one per lane
+                    const uint32_t n_take = qtail - qhead < 64u ? qtail - qhead : 64u;
+                    const bool act = (uint32_t)lane < n_take;
+                    uint32_t e = *(const lds_u32_t *)(uintptr_t)(qbase + (((qhead + (uint32_t)lane) & (kNgQueue - 1u)) << 2));
+                    qhead += n_take;
+                    e = act ? e : 4u;
+                    const uint32_t em1 = e - 1u;
+                    uint32_t row;
+                    if (A.stride_log2 != 0xFFFFFFFFu) {
+                        row = em1 >> A.stride_log2;
+                    } else {
+                        row = __umulhi(em1, A.stride_recip);
+                        if (em1 - row * stride >= stride) ++row;
+                    }
+                    const uint32_t qn = e - row * stride; // window [qn - 4, qn) of the row
+                    const uint64_t grow = (g << 6) + row;
+                    bool valid = act && row < rows_in && qn >= 4u;
+                    uint32_t len = a.row_len;
+                    if (a.lengths) len = valid ? a.lengths[grow] : 0u;
+                    valid = valid && qn <= len;
+                    const uint64_t rowabs = grow * a.stride_bytes;
+                    uint32_t r = qn > K ? qn - K : 0u; // the walk restarts here, in the start state
+                    {
+                        const uint64_t room = a.total_bytes - 16u - (valid ? rowabs : 0ull); // keep the 16-byte read inside the batch: an
+                        r = (uint64_t)r < room ? r : (uint32_t)room;                          // EARLIER restart is as good
+                    }
+                    const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull);
+                    const u32x4 tx = *(const u32x4_u *)(rowp + (valid ? r : 0u));
+                    const uint32_t w[4] = {tx[0], tx[1], tx[2], tx[3]};
+                    uint32_t col[16];
+                    piece_lookups<MODE, 1, false>(wk, w, 0u, 0u, 0u, col);
+                    uint32_t lim = qn + (uint32_t)S - 1u; // a FIRST accept is looked for at indexes qn .. qn + S - 1
+                    lim = lim < len ? lim : len;
+                    uint32_t st = start_state, last = 0, first = 0;
+                    bool found = false, over = !valid;
+                    auto step = [&](uint32_t colv, uint32_t pos) __attribute__((always_inline)) {
+                        const bool go = !over && pos < lim;
+                        const uint32_t ns = apply<MODE, 1>(wk, st, colv);
+                        st = go ? ns : st;
+                        const bool acc = go && st >= accept_lo && pos + 1u >= qn;
+                        if (OP == OP_FIND) {
+                            last = acc ? pos + 1u : last;
+                            first = (acc && !found) ? pos + 1u : first;
+                            lim = acc ? len : lim; // after the first accept the walk runs on until the automaton dies
+                            found = found || acc;
+                            over = over || (go && st <= wk.dead_hi);
+                        } else {
+                            found = found || acc;
+                            over = over || acc;
+                        }
+                    };
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        step(col[k], r + (uint32_t)k);
+                        if ((k & 3) == 3 && k != 15 && __ballot(!over && r + (uint32_t)k + 1u < lim) == 0ull) break;
+                    }
+                    // (rare) a match that runs past the 16 bytes: one char at a time from memory
+                    uint32_t pos = r + 16u;
+                    while (__ballot(!over && pos < lim) != 0ull) {
+                        uint32_t c = 0;
+                        if (!over && pos < lim) c = rowp[pos];
+                        uint32_t colv;
+                        if (wk.win_on) {
+                            colv = c << elem_shift<MODE>();
+                            colv = colv < wk.win_lo ? wk.win_lo : (colv > wk.win_hi ? wk.win_hi : colv);
+                        } else {
+                            colv = lds_u16((c << 1) + kLdsCmap1);
+                        }
+                        step(colv, pos);
+                        ++pos;
+                    }
+                    if (OP == OP_FIND) {
+                        int32_t s;
+                        if (a.fixed_len >= 0) {
+                            s = (int32_t)last - a.fixed_len; // :640-646
+                        } else {
+                            uint32_t pidx = st;
+                            if (MODE == MODE_SPARSE) { // (needle_scan.h finish_rows: a live stop state asks its END record)
+                                const uint32_t st_end = sparse_end<1>(wk, st, found && st > wk.dead_hi, a.hdr.sp_end_col4);
+                                pidx = (st_end & 0xFFFFu) - a.hdr.sp_dead_row0;
+                            }
+                            s = (int32_t)last - (int32_t)lds_u8(a.hdr.fa_len_off + (found ? pidx : 0u));
+                        }
+                        if (found) {
+                            const uint64_t key = (uint64_t)first << 32 | (uint64_t)last << 16 | (uint64_t)(uint32_t)s;
+                            __hip_atomic_fetch_min((lds_u64_t *)(uintptr_t)(sbase + row * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    } else if (found) {
+                        __hip_atomic_fetch_or((lds_u64_t *)(uintptr_t)sbase, 1ull << row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                }
+                if (!more) break;
+            }
+        }
+        // ---- the group's verdicts: lane = row
+        asm volatile("" ::: "memory");
+        if (OP == OP_FIND) {
+            const uint64_t key = *(const lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u);
+            const bool row_ok = (uint32_t)lane < rows_in;
+            const bool res = row_ok && key != ~0ull;
+            const uint64_t word = __ballot(res);
+            if (lane == 0) a.bitmap[g] = word;
+            if (row_ok) {
+                a.start[(g << 6) + lane] = res ? (int32_t)(key & 0xFFFFu) : -1;
+                a.end[(g << 6) + lane] = res ? (int32_t)((key >> 16) & 0xFFFFu) : -1;
+            }
+        } else if (lane == 0) {
+            a.bitmap[g] = *(const lds_u64_t *)(uintptr_t)sbase;
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+template <int OP, int MODE, int S>
+static hipError_t launch_ng(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
+    auto k = ngram_kernel<OP, MODE, S>;
+    static thread_local uint64_t configured = 0;
+    if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_cus), dim3(kWavesPerBlock * 64), lds, stream, A);
+    return hipGetLastError();
+}
+
+template <int OP, int MODE>
+static hipError_t launch_ng_s(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
+    return A.ng.stride == 4 ? launch_ng<OP, MODE, 4>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2>(A, n_cus, lds, stream);
+}
+
+template <int OP>
+static hipError_t launch_ng_m(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
+    switch (A.a.hdr.mode) {
+    case MODE_TABLE8: return launch_ng_s<OP, MODE_TABLE8>(A, n_cus, lds, stream);
+    case MODE_TABLE16: return launch_ng_s<OP, MODE_TABLE16>(A, n_cus, lds, stream);
+    case MODE_SPARSE: return launch_ng_s<OP, MODE_SPARSE>(A, n_cus, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// LDS a launch takes; 0 = does not fit (the caller keeps the ordinary kernel)
+size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
+    const size_t need = ((h.lds_bytes + 15u) & ~15u) + (size_t)ng.bm_bytes + (size_t)kWavesPerBlock * kNgWaveLds;
+    return need <= 160u * 1024u ? need : 0;
+}
+
+// Whether this batch shape can take the filter kernel at all (8-bit rows of 64 .. 4096 bytes apart, whole KiB units).
+bool ngram_shape_ok(const ScanArgs &a) {
+    return a.stride_bytes % 64 == 0 && a.stride_bytes <= 4096 && a.total_bytes >= 16384 && a.from == nullptr && a.end_state == nullptr &&
+           a.row_len <= 65535u;
+}
+
+hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, int n_cus, hipStream_t stream) {
+    NgramArgs A;
+    A.a = a;
+    A.ng = ng;
+    A.ng_bitmap = d_bitmap;
+    const uint32_t stride = (uint32_t)a.stride_bytes;
+    A.stride_log2 = 0xFFFFFFFFu;
+    if ((stride & (stride - 1u)) == 0u) A.stride_log2 = (uint32_t)__builtin_ctz(stride);
+    A.stride_recip = (uint32_t)((1ull << 32) / stride);
+    const size_t lds = ngram_lds_bytes(a.hdr, ng);
+    if (!lds) return hipErrorInvalidValue;
+    return op == OP_FIND ? launch_ng_m<OP_FIND>(A, n_cus, lds, stream) : launch_ng_m<OP_CONTAINED_IN>(A, n_cus, lds, stream);
+}
+
+} // namespace needle

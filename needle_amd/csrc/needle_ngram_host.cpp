@@ -1,0 +1,243 @@
+// Host analysis behind the n-gram candidate filter (needle_ngram_host.h): everything the kernel relies on is read off the
+// lowered table itself -- the depth after which a restarted walk has caught up, the shortest match, the byte windows that
+// can precede a first accepting transition.  Cold path (once per program).
+//
+// Reference: the CPU-side narrowing this generalises -- prefix `indexOf` (DFAClassBuilder.java:365-376), first-byte mask
+// (:420-426, :508-511; DFA.initialAsciiBytes, DFA.java:706-726), their gate (CompilationPolicy.java:44-57 over
+// Factorization.getPrefixes(), Factorization.java:116).  Those read literals off the regex AST; here the table is the source,
+// so whatever DFACompiler produced (leftmost-first pruning, case folding, classes) is covered without a second semantics.
+#include "needle_ngram_host.h"
+#include <algorithm>
+#include <string.h>
+#include <unordered_set>
+
+namespace needle {
+
+namespace {
+constexpr int kN = 4;            // window length in chars (= one dword of 8-bit text)
+constexpr int kMaxWarm = 14;     // K + S - 1 <= 16: the run ahead of a window fits one 16-byte load
+constexpr size_t kMaxWindows = 1u << 20;
+constexpr size_t kMaxFrontier = 4u << 20;
+
+uint64_t splitmix(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+} // namespace
+
+NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, const uint8_t *cmap8, int start, int accept_lo, int dead_hi,
+                               bool absorbing, size_t max_bm_bytes) {
+    NgramFilter f;
+    memset(&f.p, 0, sizeof(f.p));
+    auto no = [&](const char *why) {
+        f.why = why;
+        f.p.on = 0;
+        f.bitmap.clear();
+        return f;
+    };
+    (void)absorbing; // (accepting states are only ever ENTERED here: what they do afterwards does not matter)
+    if (n_dev <= 1 || start <= 0 || start >= n_dev) return no("no automaton");
+    if (start >= accept_lo) return no("the start state accepts");
+    if (max_bm_bytes < 4096) return no("no LDS left for a bitmap");
+    // columns some byte maps to, and their bytes
+    std::vector<std::vector<uint8_t>> bytes_of(n_cols);
+    for (int c = 0; c < 256; ++c) {
+        if (cmap8[c] >= n_cols) return no("column map out of range");
+        bytes_of[cmap8[c]].push_back((uint8_t)c);
+    }
+    std::vector<int> cols;
+    for (int k = 0; k < n_cols; ++k)
+        if (!bytes_of[k].empty()) cols.push_back(k);
+    auto nx = [&](int s, int k) { return (int)next[(size_t)s * n_cols + k]; };
+    auto accepting = [&](int s) { return s >= accept_lo; };
+
+    // ---- states a walk can be in before its first accepting transition
+    std::vector<uint8_t> pre(n_dev, 0);
+    std::vector<int> order{start};
+    pre[start] = 1;
+    for (size_t h = 0; h < order.size(); ++h)
+        for (int k : cols) {
+            const int t = nx(order[h], k);
+            if (!accepting(t) && !pre[t]) pre[t] = 1, order.push_back(t);
+        }
+    // a walk that can die before it ever accepted (sink, or a dead state) would be revived by a restart: no filter
+    for (int s : order)
+        if (s <= dead_hi) return no("the walk can end before a first match");
+
+    // ---- shortest accepted string
+    int min_len = -1;
+    {
+        std::vector<int> dist(n_dev, -1), q{start};
+        dist[start] = 0;
+        for (size_t h = 0; h < q.size() && min_len < 0; ++h)
+            for (int k : cols) {
+                const int t = nx(q[h], k);
+                if (accepting(t)) { min_len = dist[q[h]] + 1; break; }
+                if (dist[t] < 0) dist[t] = dist[q[h]] + 1, q.push_back(t);
+            }
+    }
+    if (min_len < 0) return no("no accepting state is reachable");
+    if (min_len < kN) return no("matches shorter than a window");
+
+    // ---- K: pairs (state of the walk from the row's start, state of a walk restarted in `start`) run in lockstep until they meet
+    int warm = -1;
+    {
+        std::vector<uint32_t> cur;
+        for (int s : order)
+            if (s != start) cur.push_back((uint32_t)s << 16 | (uint32_t)start);
+        for (int k = 1; k <= kMaxWarm && warm < 0; ++k) {
+            std::vector<uint32_t> nxt;
+            bool apart = false; // some pair is still in two states after k chars
+            for (uint32_t pr : cur) {
+                const int s = (int)(pr >> 16), t = (int)(pr & 0xFFFFu);
+                for (int c : cols) {
+                    const int s2 = nx(s, c), t2 = nx(t, c);
+                    if (!accepting(s2) && accepting(t2)) return no("a restarted walk can accept where the walk from the row's start does not");
+                    if (s2 == t2) continue;
+                    apart = true; // (an accept of the real walk that the restarted one misses counts: the k-th char is where reports begin)
+                    // the real walk accepted inside the run-up: this restart is not the one that reports it -- nothing to follow
+                    if (!accepting(s2)) nxt.push_back((uint32_t)s2 << 16 | (uint32_t)t2);
+                }
+                if (nxt.size() > kMaxFrontier) {
+                    std::sort(nxt.begin(), nxt.end());
+                    nxt.erase(std::unique(nxt.begin(), nxt.end()), nxt.end());
+                    if (nxt.size() > kMaxFrontier / 2) return no("too many state pairs");
+                }
+            }
+            std::sort(nxt.begin(), nxt.end());
+            nxt.erase(std::unique(nxt.begin(), nxt.end()), nxt.end());
+            cur.swap(nxt);
+            if (!apart) warm = k;
+        }
+        if (order.size() == 1) warm = 0;
+    }
+    if (warm < 0) return no("a restarted walk does not catch up within 14 chars");
+
+    // ---- stride: one window every S chars needs min_len >= 4 + S - 1 and K + S - 1 <= 16
+    int S = 1;
+    for (int cand : {4, 2})
+        if (kN + cand - 1 <= min_len && warm + cand - 1 <= 16) { S = cand; break; }
+    if (S == 1) return no("matches shorter than 5 chars: every char would need a window (the kernel samples every 2nd or 4th)");
+    if (warm + S - 1 > 16) return no("run-up longer than one load");
+
+    // ---- T[j]: states from which a FIRST accepting transition is exactly j chars away (j = 0: the accepting states entered
+    // from a pre-accept state); T[j >= 1] within the pre-accept states
+    const int depth = kN + S - 1;
+    std::vector<std::vector<uint8_t>> T(depth + 1, std::vector<uint8_t>(n_dev, 0));
+    for (int s : order)
+        for (int k : cols)
+            if (accepting(nx(s, k))) T[0][nx(s, k)] = 1;
+    for (int j = 1; j <= depth; ++j)
+        for (int s : order)
+            for (int k : cols)
+                if (T[j - 1][nx(s, k)]) { T[j][s] = 1; break; }
+
+    // ---- windows: label sequences x1..x4 of paths p0 -> .. -> p4 with p_m in T[o + 4 - m]; frontier = (state, labels so far)
+    std::unordered_set<uint32_t> labels; // 4 columns, 8 bits each
+    for (int o = 0; o < S; ++o) {
+        std::vector<uint64_t> fr; // state << 32 | labels
+        for (int s : order)
+            if (T[o + kN][s]) fr.push_back((uint64_t)s << 32);
+        for (int m = 1; m <= kN; ++m) {
+            std::vector<uint64_t> nf;
+            for (uint64_t e : fr) {
+                const int s = (int)(e >> 32);
+                const uint32_t lab = (uint32_t)e;
+                for (int k : cols) {
+                    const int t = nx(s, k);
+                    if (!T[o + kN - m][t]) continue;
+                    if (m < kN && accepting(t)) continue; // (only the last step of a path may enter an accepting state, and only for o = 0)
+                    nf.push_back((uint64_t)t << 32 | (lab | (uint32_t)k << (8 * (m - 1))));
+                }
+                if (nf.size() > kMaxFrontier) {
+                    std::sort(nf.begin(), nf.end());
+                    nf.erase(std::unique(nf.begin(), nf.end()), nf.end());
+                    if (nf.size() > kMaxFrontier / 2) return no("too many window paths");
+                }
+            }
+            std::sort(nf.begin(), nf.end());
+            nf.erase(std::unique(nf.begin(), nf.end()), nf.end());
+            fr.swap(nf);
+        }
+        for (uint64_t e : fr) labels.insert((uint32_t)e);
+    }
+    if (labels.empty()) return no("no windows");
+
+    // ---- expand columns to bytes
+    std::vector<uint32_t> grams;
+    for (uint32_t lab : labels) {
+        const std::vector<uint8_t> *b[kN];
+        size_t n = 1;
+        for (int i = 0; i < kN; ++i) {
+            b[i] = &bytes_of[(lab >> (8 * i)) & 255u];
+            n *= b[i]->size();
+        }
+        if (grams.size() + n > kMaxWindows) return no("too many byte windows");
+        for (uint8_t c0 : *b[0])
+            for (uint8_t c1 : *b[1])
+                for (uint8_t c2 : *b[2])
+                    for (uint8_t c3 : *b[3]) grams.push_back((uint32_t)c0 | (uint32_t)c1 << 8 | (uint32_t)c2 << 16 | (uint32_t)c3 << 24);
+    }
+    std::sort(grams.begin(), grams.end());
+    grams.erase(std::unique(grams.begin(), grams.end()), grams.end());
+
+    // ---- bitmap size: the largest power of two that fits, at most 64 KiB; useless when it fills up
+    size_t bm_bytes = 65536;
+    while (bm_bytes > max_bm_bytes) bm_bytes >>= 1;
+    while (bm_bytes > 4096 && grams.size() * 256 < bm_bytes * 8) bm_bytes >>= 1; // (fill below 1/256: a smaller one is as good)
+    const double fill = (double)grams.size() / (double)(bm_bytes * 8);
+    if (fill > 0.05) return no("the windows would fill the bitmap");
+    int bits_log2 = 0;
+    while ((size_t)1 << bits_log2 < bm_bytes * 8) ++bits_log2;
+    f.p.addr_shift = (uint32_t)(32 - (bits_log2 - 5) - 2);
+    f.p.addr_mask = (uint32_t)(bm_bytes - 1) & ~3u;
+    f.p.bm_bytes = (uint32_t)bm_bytes;
+
+    // ---- multipliers: the text is not ours to know; judge a pair by the windows over the SAME bytes (per position) that are
+    // not in the set -- near misses are what real text is made of
+    std::vector<uint8_t> alpha[kN];
+    {
+        bool seen[kN][256];
+        memset(seen, 0, sizeof(seen));
+        for (uint32_t g : grams)
+            for (int i = 0; i < kN; ++i) seen[i][(g >> (8 * i)) & 255u] = true;
+        for (int i = 0; i < kN; ++i)
+            for (int c = 0; c < 256; ++c)
+                if (seen[i][c]) alpha[i].push_back((uint8_t)c);
+    }
+    static const uint32_t kMul[][2] = {{0xB5297Bu, 0x68E31Du}, {0x9E3779u, 0x85EBCBu}, {0x7FEB35u, 0x846CA7u}, {0x9E3779u, 0xC2B2AFu},
+                                       {0xD35A2Du, 0x1B873Fu}, {0xA24BAFu, 0xE6546Bu}, {0x2C1B3Du, 0x5BD1E9u}, {0xC6A4A7u, 0x935DE3u}};
+    size_t best_fp = (size_t)-1;
+    std::vector<uint32_t> bm(bm_bytes / 4);
+    for (const auto &mm : kMul) {
+        std::fill(bm.begin(), bm.end(), 0u);
+        for (uint32_t g : grams) {
+            const uint32_t i = ngram_bit_index(ngram_hash_host(g, mm[0], mm[1]), f.p.addr_shift, f.p.addr_mask);
+            bm[i >> 5] |= 1u << (i & 31);
+        }
+        uint64_t seed = 0x5EED1234u;
+        size_t fp = 0;
+        for (int t = 0; t < 16384; ++t) {
+            const uint64_t r = splitmix(seed);
+            uint32_t x = 0;
+            for (int i = 0; i < kN; ++i) x |= (uint32_t)alpha[i][(r >> (16 * i)) % alpha[i].size()] << (8 * i);
+            const uint32_t i = ngram_bit_index(ngram_hash_host(x, mm[0], mm[1]), f.p.addr_shift, f.p.addr_mask);
+            fp += (bm[i >> 5] >> (i & 31)) & 1u;
+        }
+        if (fp < best_fp) {
+            best_fp = fp;
+            f.p.m1 = mm[0], f.p.m2 = mm[1];
+            f.bitmap = bm;
+        }
+    }
+    f.p.on = 1;
+    f.p.stride = (uint32_t)S;
+    f.p.warm = (uint32_t)warm;
+    f.p.min_len = (uint32_t)min_len;
+    f.p.n_grams = (uint32_t)grams.size();
+    return f;
+}
+
+} // namespace needle

@@ -1,0 +1,35 @@
+// Host side of the n-gram candidate filter (device side: needle_ngram.h / needle_ngram.hip).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "needle_ngram.h"
+
+namespace needle {
+
+struct NgramFilter {
+    NgramParams p;                // p.on == 0: no filter (why says why)
+    std::vector<uint32_t> bitmap; // p.bm_bytes / 4 words; bit (i & 31) of word (i >> 5)
+    std::string why;
+};
+
+// The automaton as the kernels walk it, BEFORE any mode-specific encoding: next[state * n_cols + column] in device numbering
+// (0 = sink; states <= dead_hi end a search; states >= accept_lo accept), cmap8[byte] = column of an 8-bit code unit.
+// `absorbing`: containedIn (the first accepting state ends the walk).  max_bm_bytes: LDS left for the bitmap.
+//
+// What is established ON THE TABLE, not argued from the regex (any failure => no filter for this program):
+//  * the start state does not accept, and the shortest accepted string has min_len >= 4 chars;
+//  * K ("warm"): whatever non-accepting state s a walk is in, a second walk started in the start state at the same char is in
+//    the SAME state after K chars, and never accepts before the first one does -- so a walk restarted K chars before a
+//    position reports what the walk from the row's start reports there (as long as that one has not accepted yet);
+//  * the windows: every 4-column sequence that labels the 4 transitions ending o chars ahead of a FIRST accepting transition
+//    (o = 0 .. S - 1), expanded to bytes and hashed into the bitmap.  A first accept at char index i therefore has, for the
+//    one o with (i - o) = 0 (mod S), a window [i - o - 4, i - o) in the bitmap: no accept without a candidate.
+NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, const uint8_t *cmap8, int start, int accept_lo, int dead_hi,
+                               bool absorbing, size_t max_bm_bytes);
+
+// host mirror of the device hash (needle_ngram.h): index of window x in a bitmap of 2^bits_log2 bits
+inline uint32_t ngram_hash_host(uint32_t x, uint32_t m1, uint32_t m2) { return (x & 0xFFFFFFu) * m1 + (x >> 16) * m2; }
+inline uint32_t ngram_bit_index(uint32_t u, uint32_t addr_shift, uint32_t addr_mask) { return (((u >> addr_shift) & addr_mask) << 3) | (u & 31u); }
+
+} // namespace needle

@@ -183,6 +183,21 @@ class Pattern:
         _check(_lib.lib().needle_pattern_program_info(self._h, list(WHICH).index(which), char_width, int(with_backward), ctypes.byref(i)))
         return {k: getattr(i, k) for k, _ in i._fields_}
 
+    def prefilter_info(self, which="forwards", with_bitmap=False):
+        """The n-gram candidate filter behind which containedIn() / find() run on batches of 8-bit rows (SURVEY.md s8 f-4;
+        host-side diagnostics: needs no GPU): {"on", "mode", "stride", "warm", "min_len", "n_windows", "bitmap_bytes", hash
+        parameters, "why" (what ruled it out)} and, with_bitmap, "bitmap" (uint32 words)."""
+        i = _lib.PrefilterInfo()
+        L = _lib.lib()
+        _check(L.needle_pattern_prefilter_info(self._h, list(WHICH).index(which), ctypes.byref(i), None))
+        out = {k: getattr(i, k) for k, _ in i._fields_}
+        out["why"] = out["why"].decode()
+        if with_bitmap and i.on:
+            bm = np.zeros(i.bitmap_bytes // 4, dtype=np.uint32)
+            _check(L.needle_pattern_prefilter_info(self._h, list(WHICH).index(which), ctypes.byref(i), bm.ctypes.data))
+            out["bitmap"] = bm
+        return out
+
     def match_length_automaton(self):
         """The refined forward automaton behind find-all's "lengths" form (needle_pattern_match_lengths), or None when the
         pattern does not allow it -> {"n_states", "n_dead", "max_char", "table" int16[n, stride + 1] (last column: chars beyond max_char), "accepting"

@@ -1,0 +1,107 @@
+"""Host-side restatement of what needle_amd/csrc/needle_ngram.hip computes (the n-gram candidate filter), on the
+REFERENCE-layout tables: test one hashed 4-byte window every S chars; where one passes, run the automaton from the start
+state K chars ahead of the window's end for K + S - 1 chars, on after a first accept until it dies; a row's answer is the run
+that accepted first.  Plain Python, small inputs -- the checker's view of the algorithm, not the product."""
+import numpy as np
+
+
+def window_passes(info, bitmap, x):
+    u = ((x & 0xFFFFFF) * info["m1"] + (x >> 16) * info["m2"]) & 0xFFFFFFFF
+    i = (((u >> info["addr_shift"]) & info["addr_mask"]) << 3) | (u & 31)
+    return (int(bitmap[i >> 5]) >> (i & 31)) & 1
+
+
+class Automaton:
+    """step(state, char) -> state (-1 dead), in reference numbering (0 = start)."""
+
+    def __init__(self, table, accepting, class_map, max_char, over=None, dead_to_start=False, absorbing=False, n_dead=0, pend=None):
+        self.table, self.acc, self.cm, self.max_char = table, accepting, class_map, max_char
+        self.over, self.dead_to_start, self.absorbing, self.n_dead, self.pend = over, dead_to_start, absorbing, n_dead, pend
+
+    def step(self, s, c):
+        if self.absorbing and self.acc[s]:
+            return s
+        if c > self.max_char:
+            t = -1 if self.over is None else int(self.over[s])
+        else:
+            t = int(self.table[s, self.cm[c]])
+        if t < 0 and self.dead_to_start:
+            t = 0
+        return t
+
+    def dead(self, s):
+        return s < 0 or 1 <= s <= self.n_dead
+
+
+def _acc(d):
+    a = np.zeros(d["n_states"], dtype=bool)
+    a[d["accepting"]] = True  # (Pattern.tables() lists the accepting state ids)
+    return a
+
+
+def from_pattern(p, op):
+    """The automaton run_dev puts behind the filter: containedIn's, the lengths automaton, or (one-length patterns) indexForwards'."""
+    t = p.tables()
+    cm = t["class_map"]
+    if op == "contained_in":
+        d = t["dfas"]["contained_in"]
+        tab = np.asarray(d["table"]).reshape(-1, t["stride"])
+        return Automaton(tab, _acc(d), cm, d["max_char"], dead_to_start=True, absorbing=True), None
+    if t["fixed_len"] >= 0:
+        d = t["dfas"]["forwards"]
+        tab = np.asarray(d["table"]).reshape(-1, t["stride"])
+        return Automaton(tab, _acc(d), cm, d["max_char"]), t["fixed_len"]
+    ml = p.match_length_automaton()
+    assert ml is not None
+    return Automaton(ml["table"][:, :-1], ml["accepting"], cm, ml["max_char"], over=ml["table"][:, -1], n_dead=ml["n_dead"], pend=ml["pend"]), None
+
+
+def run_window(au, text, qn, K, S, fixed_len, contained):
+    """One candidate (window [qn - 4, qn)): -> None | (first, last, start)."""
+    n = len(text)
+    r = max(qn - K, 0)
+    lim = min(qn + S - 1, n)
+    st, pos, first, last = 0, r, None, None
+    while pos < lim:
+        st = au.step(st, int(text[pos]))
+        pos += 1
+        if st >= 0 and au.acc[st] and pos >= qn:
+            if contained:
+                return (pos, pos, 0)
+            if first is None:
+                first, lim = pos, n
+            last = pos
+        if au.dead(st):
+            break  # (after an accept: possibly one before qn, which is another window's to report)
+    if first is None:
+        return None
+    if fixed_len is not None:
+        return (first, last, last - fixed_len)
+    if not au.dead(st):  # the row ended with the automaton alive: the END transition leads to the D_L of the pending length
+        L = int(au.pend[st])
+    else:
+        L = int(au.pend[st]) if st > 0 else 0
+    assert L > 0
+    return (first, last, last - L)
+
+
+def filtered(p, op, text, all_windows=False, info=None):
+    """(found, start, end) of one row by the filter algorithm; all_windows: every sampled window counts as a candidate."""
+    info = info or p.prefilter_info("contained_in" if op == "contained_in" else "forwards", with_bitmap=True)
+    assert info["on"], info
+    au, fixed = from_pattern(p, op)
+    S, K = info["stride"], info["warm"]
+    best = None
+    t = np.asarray(text).astype(np.int64)
+    for e in range(S, len(t) + 1, S):
+        if e < 4:
+            continue
+        x = int(t[e - 4] | (t[e - 3] << 8) | (t[e - 2] << 16) | (t[e - 1] << 24))
+        if not all_windows and not window_passes(info, info["bitmap"], x):
+            continue
+        rep = run_window(au, t, e, K, S, fixed, op == "contained_in")
+        if rep is not None and (best is None or rep < best):
+            best = rep
+    if best is None:
+        return (False, -1, -1)
+    return (True, best[2], best[1]) if op != "contained_in" else (True, -1, -1)

@@ -1,0 +1,94 @@
+"""SURVEY.md s8 f-4 on the device: containedIn() / find() behind the n-gram candidate filter (needle_amd/csrc/needle_ngram.hip)
+must give the reference's answers -- bit for bit what the CPU oracle (oracle/needle_walk.c: DFAClassBuilder.java:335-471,
+625-659, 956-1025) computes, and what the ordinary scan kernel computes with the filter switched off.  NEEDLE_PREFILTER is read
+once per process: 1 (default: automata in the compressed form), 2 (every LDS-table automaton that allows a filter), 0 (off)
+each run in a child.  Shapes: full rows, ragged rows, rows 64 / 192 / 1024 bytes apart, batches that end inside a 64-row group
+and inside a 1 KiB unit, keywords at both ends of a row and cut by it, near-miss text that floods the filter with candidates."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from needle_amd import workload as W
+from needle_amd.pattern import DFACompiler, unpack_bitmap
+from test_compile_matches_txt import oracle_for
+level = int(sys.argv[1])
+big = W.keywords(1000, min_len=6, max_len=8)
+small = ["Sherlock", "Holmes", "Watson", "Moriarty", "Mycroft", "Baskerville"]
+cases = [("|".join(big), big, 6, True)]
+if level == 2:
+    cases += [("|".join(small), small, None, True), ("abcdef|bcdefgh|cdefghij|xabcde", ["abcdef", "bcdefgh", "cdefghij", "xabcde"], None, True),
+              ("abcdefgh", ["abcdefgh"], None, True), ("|".join(W.keywords(200, min_len=5, max_len=9)), W.keywords(200, min_len=5, max_len=9), None, True)]
+dev = "cuda"
+def check(p, o, rows, lens, tag):
+    n = rows.shape[0]
+    host = rows.cpu().numpy()
+    hl = None if lens is None else lens.cpu().numpy().astype(np.uint32)
+    fw, fs, fe = p.find_batch(rows, lens)
+    cw = p.contained_in_batch(rows, lens)
+    torch.cuda.synchronize()
+    of, ofs, ofe = o.batch_find(host, hl, threads=8)
+    oc = o.batch_contained_in(host, hl, threads=8)
+    got = unpack_bitmap(fw, n)
+    bad = np.nonzero(got != of)[0]
+    assert bad.size == 0, (tag, "find bitmap", bad[:5], n)
+    bs = np.nonzero((fs.cpu().numpy() != ofs) | (fe.cpu().numpy() != ofe))[0]
+    assert bs.size == 0, (tag, "start/end", bs[:5], fs.cpu().numpy()[bs[:5]], ofs[bs[:5]], fe.cpu().numpy()[bs[:5]], ofe[bs[:5]])
+    assert (unpack_bitmap(cw, n) == oc).all(), (tag, "containedIn")
+    return int(of.sum())
+for rx, words, mode, expect in cases:
+    p = DFACompiler.compile(rx, "t", 0)
+    o, _ = oracle_for(rx, 0)
+    fi, ci = p.prefilter_info("forwards"), p.prefilter_info("contained_in")
+    if level == 0:
+        assert not fi["on"] and not ci["on"]
+    else:
+        assert fi["on"] and ci["on"], (rx[:40], fi, ci)
+    if mode is not None:
+        assert fi["mode"] == mode, fi
+    kw = [torch.tensor([ord(c) for c in w], dtype=torch.uint8, device=dev) for w in words[:8]]
+    total = 0
+    for stride, n in ((256, 64 * 700 + 13), (64, 64 * 900 + 7), (192, 64 * 300 + 63), (1024, 64 * 60 + 1), (256, 70)):
+        rows = W.keyword_batch(torch, words, 3, n, stride, device=dev)
+        k0, k1, k2 = kw[0], kw[1 % len(kw)], kw[2 % len(kw)]
+        rows[::11, stride - len(k0):] = k0                  # a keyword that ends with the row
+        rows[5::11, stride - len(k1) + 1:] = k1[:-1]        # one that the row's end cuts
+        rows[7::11, :len(k2)] = k2                          # one at the very start
+        rows[9::11, 1:1 + len(k0)] = k0                     # one a char in (the window reaching back over the row start)
+        for j in range(0, stride - 12, 16):                 # keywords across every 16-byte piece boundary and 1 KiB unit boundary
+            r = 13 + 11 * (j // 16)
+            if r < n:
+                rows[r, j + 12:j + 12 + min(len(k1), stride - j - 12)] = k1[:stride - j - 12]
+        total += check(p, o, rows, None, (rx[:30], stride, n, "full"))
+        lens = (torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 % (stride + 1)).to(torch.int32)
+        total += check(p, o, rows, lens, (rx[:30], stride, n, "ragged"))
+    # near misses: rows made of keyword prefixes / keywords with one char changed -- candidates everywhere, few matches
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    n = 64 * 200 + 5
+    wt = torch.zeros((len(words), 16), dtype=torch.uint8, device=dev) + 32
+    for i, w in enumerate(words):
+        wt[i, :len(w)] = torch.tensor([ord(c) for c in w], dtype=torch.uint8, device=dev)
+    pick = torch.randint(0, len(words), (n, 16), device=dev, generator=g)
+    rows = wt[pick].reshape(n, 256).clone()
+    flip = torch.rand((n, 256), device=dev, generator=g) < 0.08
+    rows = torch.where(flip, torch.full_like(rows, ord("q")), rows)
+    total += check(p, o, rows, None, (rx[:30], "near-miss"))
+    assert total > 1000, total
+print("PREFILTER-GPU-OK")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2, 0], ids=["default", "all-table-automata", "off"])
+def test_prefilter_levels_match_oracle(level):
+    env = dict(os.environ, NEEDLE_PREFILTER=str(level))
+    if level == 2:
+        env["NEEDLE_PAIR_MAX_BYTES"] = "0"  # (the small automata as plain uint8 tables: the pair table has no filter kernel)
+    r = subprocess.run([sys.executable, "-c", CODE, str(level)], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert "PREFILTER-GPU-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
