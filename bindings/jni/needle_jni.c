@@ -97,7 +97,13 @@ static void view_of(JNIEnv *env, needle_batch_view *v, jobject rows, jint cw, jl
     v->lengths = lengths ? (const uint32_t *)(*env)->GetDirectBufferAddress(env, lengths) : NULL;
 }
 
+/* n ints / longs fit the Java array (a short array from the caller must not become a write past it) */
+static int int_room(JNIEnv *env, jintArray a, jlong n) { return a != NULL && (jlong)(*env)->GetArrayLength(env, a) >= n; }
+static int long_room(JNIEnv *env, jlongArray a, jlong n) { return a != NULL && (jlong)(*env)->GetArrayLength(env, a) >= n; }
+
 static jint bitmap_call(JNIEnv *env, int which, jlong h, needle_batch_view *v, jlongArray bitmap, jintArray start, jintArray end) {
+    if (!long_room(env, bitmap, ((jlong)v->n_rows + 63) / 64)) return NEEDLE_ERR_INVALID;
+    if (which == 2 && (!int_room(env, start, (jlong)v->n_rows) || !int_room(env, end, (jlong)v->n_rows))) return NEEDLE_ERR_INVALID;
     jlong *bm = (*env)->GetLongArrayElements(env, bitmap, NULL);
     jint *s = start ? (*env)->GetIntArrayElements(env, start, NULL) : NULL;
     jint *e = end ? (*env)->GetIntArrayElements(env, end, NULL) : NULL;
@@ -130,13 +136,14 @@ NATIVE(jint, findHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jl
 NATIVE(jint, findAllHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jint maxPerRow, jintArray counts, jintArray start, jintArray end, jintArray more) {
     needle_batch_view v;
     view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    if (maxPerRow < 0 || !int_room(env, counts, n) || !int_room(env, start, n * (jlong)maxPerRow) || !int_room(env, end, n * (jlong)maxPerRow)) return NEEDLE_ERR_INVALID;
     jint *cn = (*env)->GetIntArrayElements(env, counts, NULL);
     jint *st = (*env)->GetIntArrayElements(env, start, NULL);
     jint *en = (*env)->GetIntArrayElements(env, end, NULL);
     int m = 0;
     int rc = needle_find_all_host((const needle_pattern *)(intptr_t)h, &v, (uint32_t)maxPerRow, (uint32_t *)cn, (int32_t *)st, (int32_t *)en, &m);
     jint jm = m;
-    (*env)->SetIntArrayRegion(env, more, 0, 1, &jm);
+    if (int_room(env, more, 1)) (*env)->SetIntArrayRegion(env, more, 0, 1, &jm);
     (*env)->ReleaseIntArrayElements(env, counts, cn, 0);
     (*env)->ReleaseIntArrayElements(env, start, st, 0);
     (*env)->ReleaseIntArrayElements(env, end, en, 0);
@@ -146,12 +153,13 @@ NATIVE(jint, findAllHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw,
 NATIVE(jint, findAllPacked16Host)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jint maxPerRow, jintArray counts, jintArray startEnd, jintArray more) {
     needle_batch_view v;
     view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    if (maxPerRow < 0 || !int_room(env, counts, n) || !int_room(env, startEnd, n * (jlong)maxPerRow)) return NEEDLE_ERR_INVALID;
     jint *cn = (*env)->GetIntArrayElements(env, counts, NULL);
     jint *se = (*env)->GetIntArrayElements(env, startEnd, NULL);
     int m = 0;
     int rc = needle_find_all_packed16_host((const needle_pattern *)(intptr_t)h, &v, (uint32_t)maxPerRow, (uint32_t *)cn, (uint32_t *)se, &m);
     jint mm = m;
-    (*env)->SetIntArrayRegion(env, more, 0, 1, &mm);
+    if (int_room(env, more, 1)) (*env)->SetIntArrayRegion(env, more, 0, 1, &mm);
     (*env)->ReleaseIntArrayElements(env, counts, cn, 0);
     (*env)->ReleaseIntArrayElements(env, startEnd, se, 0);
     return rc;

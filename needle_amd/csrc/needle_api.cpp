@@ -55,11 +55,26 @@ int set_error(int code, const std::string &msg) { return fail(code, msg); } // (
 // Stream-ordered scratch memory comes from a pool of the library's own, one per device, that KEEPS what it is given back:
 // HIP's default pool returns freed memory to the driver at the next synchronisation point (release threshold 0), so a
 // caller that synchronises after every call would pay a fresh driver allocation of tens of megabytes per call
-// (needle_find_compact_dev: 2.5 ms per step on a 10M-row batch before this).
+// (needle_find_compact_dev: 2.5 ms per step on a 10M-row batch before this).  What the pool keeps is bounded:
+// NEEDLE_SCRATCH_KEEP_MB (default 512) is its release threshold -- freed memory above it goes back to the driver at the next
+// synchronisation point, so one large batch does not pin its peak scratch for the life of the process -- and
+// needle_trim_scratch() hands back everything that is free.
 namespace needle {
+static std::mutex g_scratch_mu;
+static std::map<int, hipMemPool_t> g_scratch_pools;
+hipError_t scratch_trim(size_t keep_bytes) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    hipError_t first = hipSuccess;
+    for (auto &kv : g_scratch_pools)
+        if (kv.second) {
+            const hipError_t e = hipMemPoolTrimTo(kv.second, keep_bytes);
+            if (e != hipSuccess && first == hipSuccess) first = e;
+        }
+    return first;
+}
 hipError_t scratch_malloc(void **out, size_t bytes, hipStream_t stream) {
-    static std::mutex mu;
-    static std::map<int, hipMemPool_t> pools;
+    std::mutex &mu = g_scratch_mu;
+    std::map<int, hipMemPool_t> &pools = g_scratch_pools;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -75,7 +90,8 @@ hipError_t scratch_malloc(void **out, size_t bytes, hipStream_t stream) {
             props.location.type = hipMemLocationTypeDevice;
             props.location.id = dev;
             if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
-                uint64_t keep = UINT64_MAX;
+                static const uint64_t keep_mb = getenv("NEEDLE_SCRATCH_KEEP_MB") ? (uint64_t)atoll(getenv("NEEDLE_SCRATCH_KEEP_MB")) : 512;
+                uint64_t keep = keep_mb << 20;
                 (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
             } else {
                 (void)hipGetLastError();
@@ -117,6 +133,7 @@ struct needle_pattern {
     //          7 the same for find() in the scan kernels
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
+    std::mutex ml_mu;       // guards the one-time match-length analysis only: scans of programs that exist already do not wait for it
     int ml_state = 0;       // 0: not analysed yet, 1: find-all can report starts as end - length (ml), -1: it cannot
     MatchLengths ml;
     ~needle_pattern() {
@@ -133,9 +150,23 @@ static size_t max_prog_lds() {
     return v < kMaxProgLdsBytes ? v : (size_t)kMaxProgLdsBytes;
 }
 
+// The pattern's match-length analysis (needle_lower.h), run once per pattern -- it can take seconds of host time on a big
+// dictionary -- and shared by every caller: the scans, needle_pattern_program_info / _prefilter_info / _match_lengths.
+// nullptr: the pattern does not allow the "lengths" form.
+static const MatchLengths *pattern_ml(const needle_pattern *cp) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    std::lock_guard<std::mutex> lk(p->ml_mu);
+    if (p->ml_state == 0) {
+        p->ml = match_length_automaton(p->t);
+        p->ml_state = p->ml.ok ? 1 : -1;
+    }
+    return p->ml_state > 0 ? &p->ml : nullptr;
+}
+
 static int get_program(needle_pattern *p, int which, int cw, int variant, const DevProgram **out, int *n_cus) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    const MatchLengths *ml67 = (variant == 6 || variant == 7) ? pattern_ml(p) : nullptr; // (before p->mu: see ml_mu)
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->cus.count(dev)) {
         hipDeviceProp_t prop;
@@ -149,15 +180,11 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
         DevProgram dp;
         if (variant == 6 || variant == 7) { // "lengths" form: the refined forward automaton + pend[] (needle_lower.h);
                                             // 6: the find-all kernel's plain layout, 7: the scan kernels' (window addressing)
-            if (p->ml_state == 0) {
-                p->ml = match_length_automaton(p->t);
-                p->ml_state = p->ml.ok ? 1 : -1;
-            }
-            if (p->ml_state < 0) {
+            if (!ml67) {
                 *out = nullptr;
                 return NEEDLE_OK;
             }
-            dp.prog = lower_match_lengths(p->t, p->ml, cw, max_prog_lds(), variant == 6);
+            dp.prog = lower_match_lengths(p->t, *ml67, cw, max_prog_lds(), variant == 6);
             if (dp.prog.blob.empty()) { // (does not fit the LDS as a plain table: the ordinary program with backward walks)
                 p->cache.emplace(key, DevProgram());
                 *out = nullptr;
@@ -207,6 +234,13 @@ static int check_host_lengths(const needle_batch_view *v) {
     for (uint64_t r = 0; r < v->n_rows; ++r)
         if (v->lengths[r] > v->row_stride) return fail(NEEDLE_ERR_INVALID, "lengths[r] > row_stride");
     return NEEDLE_OK;
+}
+
+// 16-bit result offsets: what the API can tell about the longest row -- row_len, or with per-row lengths (device memory, not
+// readable here) the stride, which may be the caller's limit rounded up to the 16-byte alignment of device rows (65 536); the
+// lengths themselves must stay within `limit` (the host entry points check them).
+static bool offsets16_ok(const needle_batch_view *v, uint32_t limit) {
+    return v->lengths ? v->row_stride <= 65536u : v->row_len <= limit;
 }
 
 // Few, long rows: one row per lane would leave the chip idle.  Packed-mode automata take the stripe path (function
@@ -275,7 +309,7 @@ static bool find_lengths_for(uint32_t mode) {
 
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
                    int32_t *d_end, void *stream, const int32_t *d_from = nullptr, uint32_t *d_end_state = nullptr,
-                   bool no_backward = false);
+                   bool no_backward = false, uint32_t *d_packed = nullptr);
 
 // Few, long rows of an automaton too big for function composition: speculative stripes (needle_stripe.hip).  Returns
 // NEEDLE_OK with *done = false when the path does not apply or did not reach its fixpoint (the caller then walks the
@@ -393,15 +427,27 @@ static int run_speculative_stripes(needle_pattern *p, int op, const needle_batch
     return finish(NEEDLE_OK);
 }
 
+// d_packed (OP_FIND, needle_find_packed16_dev): a row's start / end go there as one dword, stored by the scan kernel itself;
+// d_start / d_end are not used.  The paths for few long rows (stripes) and the opt-in two-row-set kernel keep their int32
+// arrays: they run into scratch and one pack pass follows.
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
-                   int32_t *d_end, void *stream, const int32_t *d_from, uint32_t *d_end_state, bool no_backward) {
+                   int32_t *d_end, void *stream, const int32_t *d_from, uint32_t *d_end_state, bool no_backward, uint32_t *d_packed) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
     int rc = check_view(v, true);
     if (rc) return rc;
     if (v->n_rows == 0) return NEEDLE_OK;
     if (!d_bitmap) return fail(NEEDLE_ERR_INVALID, "bitmap is NULL");
-    if (op == OP_FIND && (!d_start || !d_end)) return fail(NEEDLE_ERR_INVALID, "start/end is NULL");
+    if (op == OP_FIND && !d_packed && (!d_start || !d_end)) return fail(NEEDLE_ERR_INVALID, "start/end is NULL");
+    static const int dict_env = getenv("NEEDLE_DICT") ? atoi(getenv("NEEDLE_DICT")) : 0;
+    if (d_packed && (dict_env > 0 || v->row_stride * v->char_width >= 8 * (uint64_t)kStripeBytes)) {
+        int32_t *tmp = nullptr;
+        HIP_TRY(scratch_malloc((void **)&tmp, (size_t)v->n_rows * 8, (hipStream_t)stream));
+        rc = run_dev(cp, op, v, d_bitmap, tmp, tmp + v->n_rows, stream, d_from, d_end_state, no_backward, nullptr);
+        if (rc == NEEDLE_OK) rc = needle_pack_start_end16_dev(tmp, tmp + v->n_rows, v->n_rows, d_packed, stream);
+        (void)scratch_free(tmp, (hipStream_t)stream);
+        return rc;
+    }
 
     const int which = op == OP_MATCHES ? W_MATCHES : op == OP_CONTAINED_IN ? W_CONTAINED_IN : W_FORWARDS;
     const DevProgram *fp = nullptr, *bp = nullptr;
@@ -463,6 +509,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     a.bitmap = d_bitmap;
     a.start = d_start;
     a.end = d_end;
+    a.packed = d_packed;
     a.end_state = d_end_state;
     bool skip_backward = no_backward; // (speculative pass: only lastMatch is wanted)
 #ifdef NEEDLE_TUNING // measurement builds only (scripts/build_tuning.sh): a switch that changes ANSWERS (start = end) never ships
@@ -474,7 +521,6 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // ordinary kernel on what is left; find()'s starts by indexBackwards afterwards, one lane per matched row.
     // NEEDLE_DICT: 0 off (default: measured, it is no faster -- DESIGN.md s4), 1 on for the compressed automaton, 2 also for
     // plain uint16 LDS tables.
-    static const int dict_env = getenv("NEEDLE_DICT") ? atoi(getenv("NEEDLE_DICT")) : 0;
     if (dict_env > 0 && !lengths_form && (a.hdr.mode == MODE_SPARSE || dict_env > 1) && dict_kernel_applies((int)v->char_width, a)) {
         HIP_TRY(launch_dict(op, a, n_cus, (hipStream_t)stream));
         const uint64_t done_rows = (a.n_rows >> 7) << 7;
@@ -890,6 +936,10 @@ int needle_find_packed_host(const needle_pattern *p, const needle_packed_view *v
 const char *needle_version(void) { return "needle_hip 0.1 (gfx950)"; }
 const char *needle_last_error(void) { return g_err.c_str(); }
 
+int needle_trim_scratch(size_t keep_bytes) {
+    const hipError_t e = needle::scratch_trim(keep_bytes);
+    return e == hipSuccess ? NEEDLE_OK : hip_fail(e, "hipMemPoolTrimTo");
+}
 int needle_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -984,9 +1034,8 @@ int needle_pattern_program_info(const needle_pattern *p, int which, int char_wid
     const bool backward = with_backward != 0 && which == W_FORWARDS && p->t.fixed_len < 0;
     Program pr = lower(p->t, (Which)which, char_width, max_prog_lds(), false, backward);
     if (backward && find_lengths_for(pr.hdr.mode)) { // (as run_dev chooses)
-        const MatchLengths ml = match_length_automaton(p->t);
-        if (ml.ok) {
-            Program lp = lower_match_lengths(p->t, ml, char_width, max_prog_lds(), false);
+        if (const MatchLengths *ml = pattern_ml(p)) {
+            Program lp = lower_match_lengths(p->t, *ml, char_width, max_prog_lds(), false);
             static const bool force_tables = getenv("NEEDLE_FIND_LENGTHS") && atoi(getenv("NEEDLE_FIND_LENGTHS")) > 1;
             const bool pair_lost = pr.hdr.mode == MODE_PAIR && lp.hdr.mode != MODE_PAIR && !force_tables;
             if (!lp.blob.empty() && !pair_lost) pr = std::move(lp), o->lengths_form = 1;
@@ -1021,9 +1070,8 @@ int needle_pattern_prefilter_info(const needle_pattern *p, int which, needle_pre
     Program pr = lower(p->t, (Which)which, 1, max_prog_lds(), false, backward);
     bool usable = which == W_CONTAINED_IN || p->t.fixed_len >= 0;
     if (backward && find_lengths_for(pr.hdr.mode)) {
-        const MatchLengths ml = match_length_automaton(p->t);
-        if (ml.ok) {
-            Program lp = lower_match_lengths(p->t, ml, 1, max_prog_lds(), false);
+        if (const MatchLengths *ml = pattern_ml(p)) {
+            Program lp = lower_match_lengths(p->t, *ml, 1, max_prog_lds(), false);
             static const bool force_tables = getenv("NEEDLE_FIND_LENGTHS") && atoi(getenv("NEEDLE_FIND_LENGTHS")) > 1;
             const bool pair_lost = pr.hdr.mode == MODE_PAIR && lp.hdr.mode != MODE_PAIR && !force_tables;
             if (!lp.blob.empty() && !pair_lost) pr = std::move(lp), usable = true;
@@ -1054,12 +1102,7 @@ int needle_pattern_match_lengths(const needle_pattern *cp, int32_t *available, i
                                  int16_t *table, uint8_t *accepting, uint8_t *pend) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p || !available) return fail(NEEDLE_ERR_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(p->mu);
-    if (p->ml_state == 0) {
-        p->ml = match_length_automaton(p->t);
-        p->ml_state = p->ml.ok ? 1 : -1;
-    }
-    *available = p->ml_state > 0 ? 1 : 0;
+    *available = pattern_ml(p) ? 1 : 0;
     if (!*available) return NEEDLE_OK;
     if (n_states) *n_states = p->ml.dfa.n_states;
     if (n_dead) *n_dead = p->ml.n_dead;
@@ -1176,6 +1219,13 @@ int needle_contained_in_dev(const needle_pattern *p, const needle_batch_view *v,
 }
 int needle_find_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, int32_t *st, int32_t *en, void *s) {
     return run_dev(p, OP_FIND, v, bm, st, en, s);
+}
+// find() with a row's start / end as one dword (start | end << 16, 0xFFFFFFFF = no match), stored by the scan kernel itself:
+// 4 result bytes per row instead of 8, no separate pack pass.  Rows of at most 65 534 chars.
+int needle_find_packed16_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, uint32_t *start_end16, void *s) {
+    if (v && v->n_rows && !start_end16) return fail(NEEDLE_ERR_INVALID, "start_end16 is NULL");
+    if (v && !offsets16_ok(v, 65534u)) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit offsets: rows of at most 65 534 chars (use needle_find_dev)");
+    return run_dev(p, OP_FIND, v, bm, nullptr, nullptr, s, nullptr, nullptr, false, start_end16);
 }
 int needle_find_next_dev(const needle_pattern *p, const needle_batch_view *v, const int32_t *cur, uint64_t *bm, int32_t *st,
                          int32_t *en, void *s) {
@@ -1319,7 +1369,7 @@ int needle_find_all_packed16_dev(const needle_pattern *cp, const needle_batch_vi
     if (more) *more = 0;
     if (v->n_rows == 0) return NEEDLE_OK;
     if (!d_counts || (slots && !d_start_end16)) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
-    if (v->row_stride > 65535u) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit start / end: rows of at most 65535 chars");
+    if (!offsets16_ok(v, 65535u)) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit start / end: rows of at most 65535 chars");
     return find_all_one_pass(p, v, slots, d_counts, nullptr, nullptr, nullptr, false, more, (hipStream_t)stream_, d_start_end16);
 }
 
@@ -1519,7 +1569,8 @@ int needle_find_all_host(const needle_pattern *p, const needle_batch_view *v, ui
 int needle_find_all_packed16_host(const needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *counts,
                                   uint32_t *start_end16, int *more) {
     if (slots && !start_end16) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
-    if (v && v->row_stride > 65535u) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit start / end: rows of at most 65535 chars");
+    if (v && (v->lengths ? v->row_stride : v->row_len) > 65535u) // (the caller's stride, before any padding; lengths[r] <= row_stride is checked below)
+        return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit start / end: rows of at most 65535 chars");
     static uint32_t none = 0; // (slots == 0: counting only; a non-null marker keeps the packed form)
     return find_all_host(p, v, slots, counts, nullptr, nullptr, more, start_end16 ? start_end16 : &none);
 }

@@ -50,13 +50,18 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(256) void word_scan_kernel(const uint64_t *bitmap, uint64_t n_words, uint32_t *word_off, uint32_t *block_sum) {
+// Bits of the last bitmap word at or beyond n_rows do not count, whatever the scan that wrote the word left there.
+__device__ __forceinline__ uint64_t live_bits(uint64_t word, uint64_t w, uint64_t n_words, uint64_t n_rows) {
+    return (w + 1 == n_words && (n_rows & 63ull)) ? word & ((1ull << (n_rows & 63ull)) - 1ull) : word;
+}
+
+__global__ __launch_bounds__(256) void word_scan_kernel(const uint64_t *bitmap, uint64_t n_words, uint64_t n_rows, uint32_t *word_off, uint32_t *block_sum) {
     __shared__ uint32_t lds4[4];
     const uint64_t w0 = (uint64_t)blockIdx.x * kWordsPerBlock + (uint64_t)threadIdx.x * 8;
     uint32_t c[8], sum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        c[k] = (w0 + k < n_words) ? (uint32_t)__popcll(bitmap[w0 + k]) : 0u;
+        c[k] = (w0 + k < n_words) ? (uint32_t)__popcll(live_bits(bitmap[w0 + k], w0 + k, n_words, n_rows)) : 0u;
         sum += c[k];
     }
     uint32_t total;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void fill_kernel(const uint64_t *bitmap, uint6
     const int lane = threadIdx.x & 63;
     const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_words; w += waves) {
-        const uint64_t m = bitmap[w];
+        const uint64_t m = live_bits(bitmap[w], w, n_words, n_rows);
         if (m == 0ull) continue;
         const uint64_t row = (w << 6) + (uint64_t)lane;
         if (((m >> lane) & 1ull) && row < n_rows) {
@@ -112,7 +117,9 @@ int find_compact(const needle_pattern *p, const needle_batch_view *v, uint64_t *
                  uint64_t *d_n_matched, uint64_t row_base, void *stream_) {
     if (!p || !v) return fail(NEEDLE_ERR_INVALID, "NULL argument");
     if (!d_bitmap || !d_n_matched || (cap && !d_recs)) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
-    if (v->row_stride > 65534) return fail(NEEDLE_ERR_UNSUPPORTED, "the compact records hold 16-bit offsets: rows of at most 65 534 chars (use needle_find_dev)");
+    // (per-row lengths are device memory: the stride bounds them, and it may be the limit rounded up to the 16-byte row alignment)
+    if (v->lengths ? v->row_stride > 65536u : v->row_len > 65534u)
+        return fail(NEEDLE_ERR_UNSUPPORTED, "the compact records hold 16-bit offsets: rows of at most 65 534 chars (use needle_find_dev)");
     if (row_base + v->n_rows >= (1ull << 32)) return fail(NEEDLE_ERR_UNSUPPORTED, "the compact records hold 32-bit row numbers");
     hipStream_t stream = (hipStream_t)stream_;
     if (v->n_rows == 0) {
@@ -135,7 +142,7 @@ int find_compact(const needle_pattern *p, const needle_batch_view *v, uint64_t *
     uint64_t *block_off = (uint64_t *)(tmp + o_boff);
     const int rc = needle_find_dev(p, v, d_bitmap, d_start, d_end, stream_);
     if (rc) return done(rc);
-    hipLaunchKernelGGL(word_scan_kernel, dim3(n_blocks), dim3(256), 0, stream, d_bitmap, n_words, word_off, block_sum);
+    hipLaunchKernelGGL(word_scan_kernel, dim3(n_blocks), dim3(256), 0, stream, d_bitmap, n_words, n, word_off, block_sum);
     hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, stream, block_sum, n_blocks, block_off, d_n_matched);
     const unsigned grid = (unsigned)std::min<uint64_t>((n_words + 3) / 4, 4096);
     hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, stream, d_bitmap, n_words, n, d_start, d_end, word_off, block_off, d_recs, cap, row_base);
@@ -216,6 +223,8 @@ int needle_find_compact_host(const needle_pattern *p, const needle_batch_view *v
     *n_matched = 0;
     if (v->n_rows == 0) return NEEDLE_OK;
     if (!bitmap || (cap && !recs)) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    if ((v->lengths ? v->row_stride : v->row_len) > 65534u) // the caller's own stride: the upload pads it to 16 bytes
+        return fail(NEEDLE_ERR_UNSUPPORTED, "the compact records hold 16-bit offsets: rows of at most 65 534 chars (use needle_find_host)");
     const uint64_t per = rows_per_chunk(v);
     for (uint64_t r0 = 0; r0 < v->n_rows; r0 += per) {
         const uint64_t cnt = std::min<uint64_t>(per, v->n_rows - r0), words = (cnt + 63) / 64;
@@ -249,17 +258,17 @@ int needle_find_packed16_host(const needle_pattern *p, const needle_batch_view *
     if (rc) return rc;
     if (v->n_rows == 0) return NEEDLE_OK;
     if (!bitmap || !start_end16) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
-    if (v->row_stride > 65534) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit offsets: rows of at most 65 534 chars (use needle_find_host)");
+    if ((v->lengths ? v->row_stride : v->row_len) > 65534u) // the caller's own stride: the upload pads it to 16 bytes
+        return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit offsets: rows of at most 65 534 chars (use needle_find_host)");
     const uint64_t per = rows_per_chunk(v);
     for (uint64_t r0 = 0; r0 < v->n_rows; r0 += per) {
         const uint64_t cnt = std::min<uint64_t>(per, v->n_rows - r0), words = (cnt + 63) / 64;
         HostChunk ch;
         if ((rc = ch.upload(v, r0, cnt))) return rc;
-        uint8_t *d_out = nullptr; // bitmap | start | end | packed
-        const uint64_t o_s = (words * 8 + 15) & ~(uint64_t)15, o_e = o_s + cnt * 4, o_p = o_e + cnt * 4;
+        uint8_t *d_out = nullptr; // bitmap | packed
+        const uint64_t o_p = (words * 8 + 15) & ~(uint64_t)15;
         if (hipMalloc((void **)&d_out, o_p + cnt * 4) != hipSuccess) return fail(NEEDLE_ERR_DEVICE, "hipMalloc (find results)");
-        rc = needle_find_dev(p, &ch.view, (uint64_t *)d_out, (int32_t *)(d_out + o_s), (int32_t *)(d_out + o_e), nullptr);
-        if (rc == NEEDLE_OK) rc = needle_pack_start_end16_dev((const int32_t *)(d_out + o_s), (const int32_t *)(d_out + o_e), cnt, (uint32_t *)(d_out + o_p), nullptr);
+        rc = needle_find_packed16_dev(p, &ch.view, (uint64_t *)d_out, (uint32_t *)(d_out + o_p), nullptr);
         hipError_t e = hipSuccess;
         if (rc == NEEDLE_OK) {
             e = hipMemcpy(bitmap + r0 / 64, d_out, words * 8, hipMemcpyDeviceToHost);

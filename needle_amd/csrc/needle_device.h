@@ -124,6 +124,8 @@ struct ScanArgs {
     uint64_t *bitmap;
     int32_t *start;
     int32_t *end;
+    uint32_t *packed;       // OP_FIND, rows of at most 65 534 chars: when set, a row's result is stored as ONE dword here --
+                            // start | end << 16, 0xFFFFFFFF = no match (needle_find_packed16_dev) -- and start / end are not written
     uint32_t *end_state;    // optional: the automaton state (device id) in which every row's walk stopped
     uint32_t short_window;   // short_kernel (rows <= 64 B), find(): LDS holds an 80-byte slot per lane behind the program -- the
                              // matched rows' text goes there for the backward walk instead of being re-read from memory

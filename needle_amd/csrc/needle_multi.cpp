@@ -369,6 +369,7 @@ int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const ne
     static const int pack_env = getenv("NEEDLE_MULTI_PACK16") ? atoi(getenv("NEEDLE_MULTI_PACK16")) : 1;
     bool can_pack = find && pack_env != 0;
     for (int g = 0; g < n; ++g) can_pack = can_pack && (shards[g].n_rows == 0 || shards[g].row_stride <= 65534);
+    // (such a shard's scan stores the dword form itself -- needle_find_packed16_dev -- into the send buffer: no int32 arrays, no pack pass)
     uint64_t stage_rows = 0;
     for (int g = 0; g < n; ++g) {
         hipError_t e = hipSetDevice(m->dev[g]);
@@ -381,7 +382,7 @@ int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const ne
             continue;
         }
         const bool pack = can_pack && rows && (m->dev[g] != m->dev[0] || pack_env == 2);
-        const size_t o_st = (size_t)words * 8, o_en = o_st + (find ? (size_t)rows * 4 : 0), o_pk = o_en + (find ? (size_t)rows * 4 : 0),
+        const size_t o_st = (size_t)words * 8, o_en = o_st + (find && !pack ? (size_t)rows * 4 : 0), o_pk = o_en + (find && !pack ? (size_t)rows * 4 : 0),
                      total = o_pk + (pack ? (size_t)rows * 4 : 0);
         needle_multi::Buf &b = m->local[g];
         if (b.cap < total) {
@@ -396,8 +397,7 @@ int needle_multi_scan(needle_multi *m, const needle_pattern *p, int op, const ne
             b.cap = want;
         }
         part[g] = Part{(uint64_t *)b.p, (int32_t *)(b.p + o_st), (int32_t *)(b.p + o_en), pack ? (uint32_t *)(b.p + o_pk) : nullptr, stage_rows};
-        int rc = scan(g, part[g].bm, part[g].st, part[g].en);
-        if (rc == NEEDLE_OK && pack) rc = needle_pack_start_end16_dev(part[g].st, part[g].en, rows, part[g].packed, m->stream[g]);
+        int rc = pack ? needle_find_packed16_dev(p, &shards[g], part[g].bm, part[g].packed, m->stream[g]) : scan(g, part[g].bm, part[g].st, part[g].en);
         if (rc) return fail(rc, needle_last_error());
         if (pack) stage_rows += rows;
     }

@@ -262,8 +262,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             const uint64_t word = __ballot(res);
             if (lane == 0) a.bitmap[g] = word;
             if (row_ok) {
-                a.start[(g << 6) + lane] = res ? (int32_t)(key & 0xFFFFu) : -1;
-                a.end[(g << 6) + lane] = res ? (int32_t)((key >> 16) & 0xFFFFu) : -1;
+                if (a.packed) { // the key's low dword is end << 16 | start already; ~0 = no match
+                    a.packed[(g << 6) + lane] = (uint32_t)key;
+                } else {
+                    a.start[(g << 6) + lane] = res ? (int32_t)(key & 0xFFFFu) : -1;
+                    a.end[(g << 6) + lane] = res ? (int32_t)((key >> 16) & 0xFFFFu) : -1;
+                }
             }
         } else if (lane == 0) {
             a.bitmap[g] = *(const lds_u64_t *)(uintptr_t)sbase;

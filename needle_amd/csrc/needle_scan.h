@@ -416,8 +416,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             s = res ? lastb : -1;
         }
         if (row_ok) {
-            a.start[my_row] = s;
-            a.end[my_row] = e;
+            if (a.packed) { // wave-uniform: one dword per row (no match: s = e = -1 -> 0xFFFFFFFF)
+                a.packed[my_row] = ((uint32_t)s & 0xFFFFu) | ((uint32_t)e << 16);
+            } else {
+                a.start[my_row] = s;
+                a.end[my_row] = e;
+            }
         }
     };
 

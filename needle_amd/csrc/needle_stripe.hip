@@ -801,8 +801,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
                 s = res ? lastb : -1;
             }
             if (row_ok) {
-                a.start[my_row] = s;
-                a.end[my_row] = e;
+                if (a.packed) { // wave-uniform: one dword per row (ScanArgs::packed)
+                    a.packed[my_row] = ((uint32_t)s & 0xFFFFu) | ((uint32_t)e << 16);
+                } else {
+                    a.start[my_row] = s;
+                    a.end[my_row] = e;
+                }
             }
         }
         if (ng >= n_groups) break;

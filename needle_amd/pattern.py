@@ -517,6 +517,24 @@ class Pattern:
         caller-owned (bitmap int64, start int32, end int32) device tensors."""
         return self._run("find", rows, lengths, stream, out)
 
+    def find_packed16_batch(self, rows, lengths=None, stream=None, out=None):
+        """needle_find_packed16_dev: find() on device rows of at most 65 534 chars -> (bitmap words, int32[n] tensor whose
+        elements are the dwords start | end << 16, -1 (0xFFFFFFFF) = no match), stored by the scan kernel itself: 4 result bytes
+        per row instead of 8.  out: optional caller-owned (bitmap int64, packed int32) device tensors."""
+        import torch
+        v = self._dev_view(rows, lengths)
+        n = rows.shape[0]
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            if out is not None:
+                words, se = out
+                assert words.dtype == torch.int64 and words.numel() >= (n + 63) // 64 and se.dtype == torch.int32 and se.numel() >= n
+            else:
+                words = torch.empty((n + 63) // 64, dtype=torch.int64, device=rows.device)
+                se = torch.empty(n, dtype=torch.int32, device=rows.device)
+            _check(_lib.lib().needle_find_packed16_dev(self._h, ctypes.byref(v), words.data_ptr(), se.data_ptr(), s))
+        return words, se
+
     MATCH_REC = np.dtype([("row", np.uint32), ("start", np.uint16), ("end", np.uint16)])  # needle_match_rec
 
     def find_compact(self, rows, lengths=None, stream=None, out=None):

@@ -144,7 +144,7 @@ class ShardedScan:
     step k + 1 may scan while the gather of step k is still in flight."""
 
     def __init__(self, scan, total_rows, world, rank, is_find, device, n_buffers=2, comm=None, overlap=None, pack16=False,
-                 max_row_len=None):
+                 max_row_len=None, scan_packed=None):
         """comm: a needle_amd.multi.RankComm -- the gather is then ONE call into the library's own RCCL communicator (GPU
         runs); without it the gather goes through torch.distributed (any backend: the gloo tests).
         overlap (with comm): issue the gather on a side stream so that the next scan runs beside it.  That costs two
@@ -157,6 +157,9 @@ class ShardedScan:
         # only for rows of at most 65 534 chars (an end of 65 535 would read as "no match", longer offsets would be cut).
         # The caller states the longest row (max_row_len); longer rows, or no statement at all, keep the 8-byte form.
         self.pack16 = bool(pack16) and is_find and max_row_len is not None and int(max_row_len) <= PACK16_MAX_ROW_LEN
+        # scan_packed(bitmap, packed) (with pack16): the scan stores the dword form itself (needle_find_packed16_dev) straight into
+        # the send buffer -- no int32 start / end arrays, no pack pass between the scan and the gather
+        self.scan_packed = scan_packed if self.pack16 else None
         self.overlap = bool(overlap)
         if comm is not None and self.overlap:
             self.side = torch.cuda.Stream(device=device)
@@ -173,8 +176,9 @@ class ShardedScan:
                 buf = torch.full((per_rows + 2 * self.per_words,), -1, dtype=torch.int32, device=device)
                 buf[per_rows:] = 0
                 s["buf"] = buf
-                s["start"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
-                s["end"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
+                if self.scan_packed is None:
+                    s["start"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
+                    s["end"] = torch.full((per_rows,), -1, dtype=torch.int32, device=device)
                 s["packed"] = buf[:per_rows]
                 s["bitmap"] = buf[per_rows:].view(torch.int64)
                 if (self.dist or comm is not None) and rank == 0:
@@ -198,7 +202,10 @@ class ShardedScan:
         """The scan of this rank's shard into the current buffer set (no communication)."""
         s = self.sets[self.k % len(self.sets)]
         if self.n_rows:
-            self.scan(s["bitmap"], s.get("start"), s.get("end"))
+            if self.scan_packed is not None:
+                self.scan_packed(s["bitmap"], s["packed"])
+            else:
+                self.scan(s["bitmap"], s.get("start"), s.get("end"))
         return s
 
     def step(self, events=None):
@@ -214,7 +221,7 @@ class ShardedScan:
         if events is not None:
             events[1].record()
         self.k += 1
-        if self.pack16 and self.dist:
+        if self.pack16 and self.dist and self.scan_packed is None:
             self._pack(s)
         if not self.dist:
             s["pending"] = _Pending(None, None, 0, None)
@@ -271,6 +278,9 @@ class ShardedScan:
         if not self.dist:
             if h is not None:
                 h.wait()
+            if self.scan_packed is not None:  # (one rank, no gather: the packed scan's dwords are unpacked here)
+                start, end = self._unpack(s["packed"][:self.total_rows])
+                return s["bitmap"][:n_words], start, end
             return s["bitmap"][:n_words], (s["start"][:self.total_rows] if self.is_find else None), (s["end"][:self.total_rows] if self.is_find else None)
         if not self.is_find:
             return h.wait(), None, None

@@ -11,7 +11,7 @@ for grp in "$@"; do
   # only the scan kernel's counter rows are kept: gpurun copies back at most 64 MiB
   python - "$OUT/p$i/p_counter_collection.csv" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "scan_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if ("scan_kernel" in r["Kernel_Name"] or "ngram_kernel" in r["Kernel_Name"])]
 if rows:
     w = csv.DictWriter(open(sys.argv[1], "w", newline=""), fieldnames=list(rows[0].keys()))
     w.writeheader(); w.writerows(rows)
@@ -25,7 +25,7 @@ agg = collections.defaultdict(list)
 dur = []
 for f in sorted(glob.glob("$OUT/p*/p_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "scan_kernel" in r["Kernel_Name"]:
+        if ("scan_kernel" in r["Kernel_Name"] or "ngram_kernel" in r["Kernel_Name"]):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 print("kernel dur us (under pmc):", sum(dur)/len(dur)/1e3)

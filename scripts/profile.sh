@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_s
 python - $OUT <<'PY'
 import csv, glob, os, sys
 for f in glob.glob(os.path.join(sys.argv[1], "*", "*_counter_collection.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "scan_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if ("scan_kernel" in r["Kernel_Name"] or "ngram_kernel" in r["Kernel_Name"])]
     if rows:
         w = csv.DictWriter(open(f, "w", newline=""), fieldnames=list(rows[0].keys()))
         w.writeheader(); w.writerows(rows)

@@ -14,7 +14,7 @@ def summ(d):
     agg, dur = collections.defaultdict(list), []
     for f in sorted(glob.glob(os.path.join(root, "gpurun_out", d, "p*", "p_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
-            if "scan_kernel" in r["Kernel_Name"]:
+            if ("scan_kernel" in r["Kernel_Name"] or "ngram_kernel" in r["Kernel_Name"]):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     out = {k: sum(v) / len(v) for k, v in agg.items()}

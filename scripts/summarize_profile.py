@@ -15,7 +15,7 @@ src, rnd, w = sys.argv[1], sys.argv[2], sys.argv[3]
 fetch_factor = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
 out = {"workload": w, "round": rnd, "fetch_size_to_bytes_factor": fetch_factor}
 for r in csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))):
-    if "scan_kernel" in r["Name"]:
+    if ("scan_kernel" in r["Name"] or "ngram_kernel" in r["Name"]):
         out["kernel"] = r["Name"]
         out["calls"] = int(r["Calls"])
         out["avg_ns"] = float(r["AverageNs"])
@@ -25,7 +25,7 @@ for r in csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))):
 for name, sub, f in (("FETCH_SIZE", "fetch", "f"), ("WRITE_SIZE", "write", "w")):
     vals = []
     for r in csv.DictReader(open(os.path.join(src, sub, f + "_counter_collection.csv"))):
-        if "scan_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+        if ("scan_kernel" in r["Kernel_Name"] or "ngram_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == name:
             vals.append(float(r["Counter_Value"]))
             out["vgpr"], out["sgpr"], out["workgroup"], out["grid"] = r["VGPR_Count"], r["SGPR_Count"], r["Workgroup_Size"], r["Grid_Size"]
     out[name + "_KiB_per_launch"] = sum(vals) / len(vals)
@@ -35,7 +35,7 @@ def mean_counters(sub, f):
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
-        if "scan_kernel" in r["Kernel_Name"]:
+        if ("scan_kernel" in r["Kernel_Name"] or "ngram_kernel" in r["Kernel_Name"]):
             agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
