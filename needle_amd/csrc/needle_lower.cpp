@@ -450,11 +450,8 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     if (!want || p.blob.empty()) return p;
     const bool mode_ok = p.hdr.mode == MODE_SPARSE || (ngram_level() > 1 && (p.hdr.mode == MODE_TABLE8 || p.hdr.mode == MODE_TABLE16));
     if (!mode_ok) return p;
-    // LDS left beside the program: 16 waves x (queue + row slots) of the filter kernel (needle_ngram.hip)
-    const size_t used = ((p.hdr.lds_bytes + 15u) & ~15u) + 16u * 1024u;
-    const size_t room = used < 160u * 1024u ? 160u * 1024u - used : 0;
     p.ng = build_ngram_filter(aux.next.data(), aux.n_dev, aux.n_cols, aux.cmap8.data(), aux.start, aux.accept_lo, aux.dead_hi,
-                              which == W_CONTAINED_IN, room);
+                              which == W_CONTAINED_IN, p.hdr.lds_bytes);
     return p;
 }
 

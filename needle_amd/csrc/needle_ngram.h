@@ -6,8 +6,8 @@
 // CPU.  The table-level generalisation built here (host side: needle_ngram_host.cpp) reads, off the automaton's own table, every
 // 4-byte window that can stand `o` chars ahead of an accepting transition (o = 0 .. S-1) and hashes them into a bitmap that
 // is staged in LDS next to the automaton.  The kernel tests one window every S chars -- S = 2: half of them are aligned
-// dwords of the text, the others one v_alignbit away -- with no dependence between chars: two multiply-adds, one LDS read,
-// a shift.  Only where a window passes does the automaton run, from K chars before the window's end (K: the depth after
+// dwords of the text, the others one v_alignbit away -- with no dependence between chars: a dot product of the window's two
+// halves with the multipliers (v_dot2_u32_u16), an and-or that makes the LDS address, the read, a shift by the hash's top byte.  Only where a window passes does the automaton run, from K chars before the window's end (K: the depth after
 // which the automaton has forgotten where it was started, verified on the table by the host), for K + S - 1 chars.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -20,28 +20,57 @@ struct NgramParams {
     uint32_t on;          // 0: no filter for this program
     uint32_t stride;      // S: one window every S chars (1, 2 or 4), row-relative positions q = 0 (mod S)
     uint32_t warm;        // K: chars the automaton is run ahead of a window's end
-    uint32_t m1, m2;      // hash multipliers (24 bits each): u = (x & 0xFFFFFF) * m1 + (x >> 16) * m2
-    uint32_t addr_shift;  // word address = ((u >> addr_shift) & addr_mask) + LDS base of the bitmap; bit = u & 31
-    uint32_t addr_mask;
+    uint32_t m1, m2;      // hash multipliers (16 bits each): u = (x & 0xFFFF) * m1 + (x >> 16) * m2 (mod 2^32) -- one v_dot2_u32_u16
+    uint32_t addr_shift;  // the window's two bits of the word: (u >> addr_shift) & 31 and (u >> (addr_shift - 8)) & 31; addr_shift = 24: the shift
+                          // amounts are u's bytes 3 and 2 as they stand (SDWA)
+    uint32_t addr_mask;   // byte offset of the word inside the bitmap = u & addr_mask (the bitmap's LDS base is a multiple of its size:
+                          // base | offset is the address -- one v_and_or_b32)
     uint32_t bm_bytes;    // bitmap size (power of two)
     uint32_t min_len;     // shortest accepted string (informational)
     uint32_t n_grams;     // distinct byte windows in the bitmap (informational)
 };
 
-// u = (x & 0xFFFFFF) * m1 + (x >> 16) * m2 (mod 2^32): two full-rate VALU ops.
-__device__ __forceinline__ uint32_t ngram_hash(uint32_t x, uint32_t m1, uint32_t m2) {
-    uint32_t t, u;
-    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(t) : "v"(x), "v"(m2));
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(u) : "v"(x), "v"(m1), "v"(t));
-    return u;
+// LDS of the filter kernel (needle_ngram.hip), per wave: the candidate queue + one u64 result slot per row of the group
+constexpr uint32_t kNgQueue = 128;                      // candidates a wave can hold (at most 63 wait while 64 more arrive)
+constexpr uint32_t kNgWaveLds = kNgQueue * 4 + 64 * 8;
+constexpr uint32_t kNgWaves = 16;
+constexpr uint32_t kNgLdsCap = 160u * 1024u;
+
+// Where the bitmap and the waves' queues sit behind a program of prog_bytes: the bitmap at the next multiple of its own size
+// (its address bits and the hash's do not overlap), the queues in the gap in front of it when they fit there, else behind it.
+struct NgramLayout {
+    uint32_t bm_base, q_base, total;
+};
+inline bool ngram_layout(uint32_t prog_bytes, uint32_t bm_bytes, NgramLayout *out) {
+    if (bm_bytes < 4096u || (bm_bytes & (bm_bytes - 1u))) return false;
+    const uint32_t p = (prog_bytes + 15u) & ~15u, qb = kNgWaves * kNgWaveLds;
+    NgramLayout l;
+    l.bm_base = (p + bm_bytes - 1u) & ~(bm_bytes - 1u);
+    if (l.bm_base - p >= qb) l.q_base = p, l.total = l.bm_base + bm_bytes;
+    else l.q_base = l.bm_base + bm_bytes, l.total = l.q_base + qb;
+    if (l.total > kNgLdsCap) return false;
+    if (out) *out = l;
+    return true;
 }
 
-// The bitmap word of window x (LDS read at an absolute address, needle_walk.h) shifted so that bit 0 is the window's bit.
-__device__ __forceinline__ uint32_t ngram_probe(uint32_t x, uint32_t m1, uint32_t m2, uint32_t addr_shift, uint32_t addr_mask, uint32_t bm_base) {
-    const uint32_t u = ngram_hash(x, m1, m2);
-    const uint32_t a = ((u >> addr_shift) & addr_mask) + bm_base;
+// host mirror of the hash.  A window owns TWO bits of ONE bitmap word (a blocked Bloom filter: one LDS read tests both):
+// word (u & addr_mask) >> 2, bits (u >> addr_shift) & 31 and (u >> (addr_shift - 8)) & 31 -- the shift amounts are u's bytes 3
+// and 2 as they stand (SDWA).  With ~2000 windows in 8192 words a text window that is not in the set passes with probability
+// ~0.12 % (one bit: 0.76 %) -- every pass costs a 16-byte re-read of the row and a share of an automaton run.
+inline uint32_t ngram_hash_host(uint32_t x, uint32_t m1, uint32_t m2) { return (x & 0xFFFFu) * m1 + (x >> 16) * m2; }
+inline uint32_t ngram_word_index(uint32_t u, uint32_t addr_mask) { return (u & addr_mask) >> 2; }
+inline uint32_t ngram_word_bits(uint32_t u, uint32_t addr_shift) { return 1u << ((u >> addr_shift) & 31u) | 1u << ((u >> (addr_shift - 8u)) & 31u); }
+
+// Bit 0 of the result: window x has both its bits in the bitmap.  Hash, address, LDS read, two shifts, an and: five VALU ops.
+// m = m1 | m2 << 16; bm_base: a multiple of the bitmap's size (ngram_layout).
+__device__ __forceinline__ uint32_t ngram_probe(uint32_t x, uint32_t m, uint32_t addr_mask, uint32_t bm_base) {
+    uint32_t u, r1, r2;
+    asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(u) : "v"(x), "v"(m));
+    const uint32_t a = (u & addr_mask) | bm_base; // v_and_or_b32
     const uint32_t w = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a;
-    return w >> (u & 31u); // (v_lshrrev_b32 takes the low five bits of u by itself)
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r1) : "v"(u), "v"(w)); // w >> (u >> 24 & 31)
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r2) : "v"(u), "v"(w)); // w >> (u >> 16 & 31)
+    return r1 & r2;
 }
 
 // One 16-byte piece of text held by one lane (w0 .. w3; pw = the dword before it: the previous lane's w3).  Tests the windows
@@ -49,9 +78,9 @@ __device__ __forceinline__ uint32_t ngram_probe(uint32_t x, uint32_t m1, uint32_
 // shifts their verdicts into `log` from the top (v_alignbit): afterwards bit 31 = the last window of this piece, bit 32 - n = its
 // first one (n = 16 / S windows), and whatever the log held before sits n bits further down.
 template <int S>
-__device__ __forceinline__ uint32_t ngram_piece(uint32_t log, uint32_t pw, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t m1,
-                                                uint32_t m2, uint32_t addr_shift, uint32_t addr_mask, uint32_t bm_base) {
-#define NEEDLE_NG(X) log = __builtin_amdgcn_alignbit(ngram_probe((X), m1, m2, addr_shift, addr_mask, bm_base), log, 1);
+__device__ __forceinline__ uint32_t ngram_piece(uint32_t log, uint32_t pw, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t m,
+                                                uint32_t addr_mask, uint32_t bm_base) {
+#define NEEDLE_NG(X) log = __builtin_amdgcn_alignbit(ngram_probe((X), m, addr_mask, bm_base), log, 1);
     if (S == 4) { // windows ending at byte 4, 8, 12, 16: the piece's own dwords
         NEEDLE_NG(w0) NEEDLE_NG(w1) NEEDLE_NG(w2) NEEDLE_NG(w3)
     } else if (S == 2) { // ending at byte 2, 4, .. 16

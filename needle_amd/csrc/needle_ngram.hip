@@ -25,12 +25,14 @@ struct NgramArgs {
     ScanArgs a;
     NgramParams ng;
     const uint32_t *ng_bitmap;
+    NgramLayout lay;        // where the bitmap and the waves' queues sit in LDS (ngram_layout)
+    uint32_t dbg;           // measurement builds (-DNEEDLE_TUNING) only: NEEDLE_NG_DBG -- 1: candidates are dropped, 2: text gathered but
+                            // no walk, 3: walk on zeros (no gather), +16: runs start as soon as 32 candidates wait; 0 in the product
     uint32_t stride_log2;   // stride_bytes is a power of two (else 0xFFFFFFFF)
     uint32_t stride_recip;  // floor(2^32 / stride_bytes)
 };
 
-constexpr uint32_t kNgQueue = 128;                      // candidates a wave can hold (at most 63 wait while 64 more arrive)
-constexpr uint32_t kNgWaveLds = kNgQueue * 4 + 64 * 8;  // queue + one u64 slot per row of the group
+static_assert(kNgWaves == (uint32_t)kWavesPerBlock, "ngram_layout assumes the scan kernels' workgroup");
 constexpr int kNgPF = 4;                                // units in flight per wave = units per batch
 
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_waves = blockDim.x >> 6;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
-    const uint32_t bm_base = (a.hdr.lds_bytes + 15u) & ~15u;
+    const uint32_t bm_base = A.lay.bm_base;
     for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
     for (uint32_t i = tid * 16u; i < A.ng.bm_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + bm_base + i) = *(const u32x4 *)((const uint8_t *)A.ng_bitmap + i);
     __syncthreads();
@@ -66,10 +68,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     wk.gtable = nullptr;
     wk.hot_last = 0;
     const uint32_t accept_lo = a.hdr.accept_lo, start_state = a.hdr.start;
-    const uint32_t qbase = bm_base + A.ng.bm_bytes + (uint32_t)wave * kNgWaveLds;
+    const uint32_t qbase = A.lay.q_base + (uint32_t)wave * kNgWaveLds;
     const uint32_t sbase = qbase + kNgQueue * 4u;
-    const uint32_t m1 = A.ng.m1, m2 = A.ng.m2, ash = A.ng.addr_shift, amask = A.ng.addr_mask;
+    const uint32_t mm = A.ng.m1 | A.ng.m2 << 16, amask = A.ng.addr_mask;
     const uint32_t K = A.ng.warm;
+#ifdef NEEDLE_TUNING
+    const uint32_t dbg = A.dbg & 15u, full_set = (A.dbg & 16u) ? 32u : 64u;
+#else
+    constexpr uint32_t dbg = 0, full_set = 64u;
+#endif
     const uint32_t stride = (uint32_t)a.stride_bytes;
 
     const uint64_t n_groups = (a.n_rows + 63) >> 6;
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 asm volatile("" ::: "memory");
                 const uint32_t pw = ngram_prev_dword(v[3], carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);
-                log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], m1, m2, ash, amask, bm_base);
+                log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], mm, amask, bm_base);
             }
             const uint32_t po0 = (u0 << 10) + lane16; // byte offset of this lane's piece of the batch's first unit
             if (NW * kNgPF < 32) log >>= 32 - NW * kNgPF; // window wi of unit j at bit j * NW + wi
@@ -157,7 +164,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                     log &= log - 1u;
                 }
                 const bool more = __ballot(log != 0u) != 0ull;
-                const uint32_t thr = (more || !last_batch) ? 64u : 1u;
+                const uint32_t thr = (more || !last_batch) ? full_set : 1u;
+                if (dbg == 1u) qhead = qtail;
                 while (qtail - qhead >= thr) {
                     // ---- run the automaton on up to 64 candidates, one per lane
                     const uint32_t n_take = qtail - qhead < 64u ? qtail - qhead : 64u;
@@ -186,7 +194,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                         r = (uint64_t)r < room ? r : (uint32_t)room;                          // EARLIER restart is as good
                     }
                     const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull);
-                    const u32x4 tx = *(const u32x4_u *)(rowp + (valid ? r : 0u));
+                    u32x4 tx = {0, 0, 0, 0};
+                    if (dbg != 3u) tx = *(const u32x4_u *)(rowp + (valid ? r : 0u));
                     const uint32_t w[4] = {tx[0], tx[1], tx[2], tx[3]};
                     uint32_t col[16];
                     piece_lookups<MODE, 1, false>(wk, w, 0u, 0u, 0u, col);
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                     lim = lim < len ? lim : len;
                     uint32_t st = start_state, last = 0, first = 0;
                     bool found = false, over = !valid;
+                    if (dbg == 2u) over = over || tx[0] != 0x12345678u; // (the text is waited for, the walk is not taken)
                     auto step = [&](uint32_t colv, uint32_t pos) __attribute__((always_inline)) {
                         const bool go = !over && pos < lim;
                         const uint32_t ns = apply<MODE, 1>(wk, st, colv);
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
                         step(col[k], r + (uint32_t)k);
-                        if ((k & 3) == 3 && k != 15 && __ballot(!over && r + (uint32_t)k + 1u < lim) == 0ull) break;
+                        if ((k >= 7 || (k & 3) == 3) && k != 15 && __ballot(!over && r + (uint32_t)k + 1u < lim) == 0ull) break; // (K + S - 1 = 9 or 10 steps is the usual run)
                     }
                     // (rare) a match that runs past the 16 bytes: one char at a time from memory
                     uint32_t pos = r + 16u;
@@ -302,8 +312,8 @@ static hipError_t launch_ng_m(const NgramArgs &A, int n_cus, size_t lds, hipStre
 
 // LDS a launch takes; 0 = does not fit (the caller keeps the ordinary kernel)
 size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
-    const size_t need = ((h.lds_bytes + 15u) & ~15u) + (size_t)ng.bm_bytes + (size_t)kWavesPerBlock * kNgWaveLds;
-    return need <= 160u * 1024u ? need : 0;
+    NgramLayout l;
+    return ngram_layout(h.lds_bytes, ng.bm_bytes, &l) ? l.total : 0;
 }
 
 // Whether this batch shape can take the filter kernel at all (8-bit rows of 64 .. 4096 bytes apart, whole KiB units).
@@ -321,8 +331,13 @@ hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const 
     A.stride_log2 = 0xFFFFFFFFu;
     if ((stride & (stride - 1u)) == 0u) A.stride_log2 = (uint32_t)__builtin_ctz(stride);
     A.stride_recip = (uint32_t)((1ull << 32) / stride);
-    const size_t lds = ngram_lds_bytes(a.hdr, ng);
-    if (!lds) return hipErrorInvalidValue;
+    if (!ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay) || ng.addr_shift != 24u) return hipErrorInvalidValue;
+    A.dbg = 0;
+#ifdef NEEDLE_TUNING
+    static const uint32_t dbg_env = getenv("NEEDLE_NG_DBG") ? (uint32_t)atoi(getenv("NEEDLE_NG_DBG")) : 0u;
+    A.dbg = dbg_env;
+#endif
+    const size_t lds = A.lay.total;
     return op == OP_FIND ? launch_ng_m<OP_FIND>(A, n_cus, lds, stream) : launch_ng_m<OP_CONTAINED_IN>(A, n_cus, lds, stream);
 }
 

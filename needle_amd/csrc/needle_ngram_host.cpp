@@ -28,7 +28,7 @@ uint64_t splitmix(uint64_t &s) {
 } // namespace
 
 NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, const uint8_t *cmap8, int start, int accept_lo, int dead_hi,
-                               bool absorbing, size_t max_bm_bytes) {
+                               bool absorbing, size_t prog_lds_bytes) {
     NgramFilter f;
     memset(&f.p, 0, sizeof(f.p));
     auto no = [&](const char *why) {
@@ -40,7 +40,7 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     (void)absorbing; // (accepting states are only ever ENTERED here: what they do afterwards does not matter)
     if (n_dev <= 1 || start <= 0 || start >= n_dev) return no("no automaton");
     if (start >= accept_lo) return no("the start state accepts");
-    if (max_bm_bytes < 4096) return no("no LDS left for a bitmap");
+    if (!ngram_layout((uint32_t)prog_lds_bytes, 4096u, nullptr)) return no("no LDS left for a bitmap");
     // columns some byte maps to, and their bytes
     std::vector<std::vector<uint8_t>> bytes_of(n_cols);
     for (int c = 0; c < 256; ++c) {
@@ -183,15 +183,13 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     std::sort(grams.begin(), grams.end());
     grams.erase(std::unique(grams.begin(), grams.end()), grams.end());
 
-    // ---- bitmap size: the largest power of two that fits, at most 64 KiB; useless when it fills up
+    // ---- bitmap size: the largest power of two that fits behind the program (ngram_layout), at most 64 KiB; useless when it fills up
     size_t bm_bytes = 65536;
-    while (bm_bytes > max_bm_bytes) bm_bytes >>= 1;
+    while (bm_bytes > 4096 && !ngram_layout((uint32_t)prog_lds_bytes, (uint32_t)bm_bytes, nullptr)) bm_bytes >>= 1;
     while (bm_bytes > 4096 && grams.size() * 256 < bm_bytes * 8) bm_bytes >>= 1; // (fill below 1/256: a smaller one is as good)
     const double fill = (double)grams.size() / (double)(bm_bytes * 8);
     if (fill > 0.05) return no("the windows would fill the bitmap");
-    int bits_log2 = 0;
-    while ((size_t)1 << bits_log2 < bm_bytes * 8) ++bits_log2;
-    f.p.addr_shift = (uint32_t)(32 - (bits_log2 - 5) - 2);
+    f.p.addr_shift = 24;
     f.p.addr_mask = (uint32_t)(bm_bytes - 1) & ~3u;
     f.p.bm_bytes = (uint32_t)bm_bytes;
 
@@ -207,24 +205,26 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
             for (int c = 0; c < 256; ++c)
                 if (seen[i][c]) alpha[i].push_back((uint8_t)c);
     }
-    static const uint32_t kMul[][2] = {{0xB5297Bu, 0x68E31Du}, {0x9E3779u, 0x85EBCBu}, {0x7FEB35u, 0x846CA7u}, {0x9E3779u, 0xC2B2AFu},
-                                       {0xD35A2Du, 0x1B873Fu}, {0xA24BAFu, 0xE6546Bu}, {0x2C1B3Du, 0x5BD1E9u}, {0xC6A4A7u, 0x935DE3u}};
+    // (16-bit odd multipliers: the word's address is bits 2 .. of u, its bit u's bits 24 .. 28 -- both halves of the window reach both)
+    static const uint32_t kMul[][2] = {{0x9E37u, 0x85EBu}, {0xB529u, 0x68E3u}, {0x7FEBu, 0xC2B3u}, {0xD35Bu, 0x1B87u}, {0xA24Bu, 0xE655u}, {0x2C1Bu, 0x5BD1u},
+                                       {0xC6A5u, 0x935Du}, {0x6A09u, 0xBB67u}, {0x3C6Fu, 0xA54Fu}, {0x510Fu, 0x9B05u}, {0x1F83u, 0x5BE1u}, {0xCBBBu, 0x9D5Du},
+                                       {0x629Bu, 0x367Du}, {0x9159u, 0x152Fu}, {0xF70Fu, 0x4FA5u}, {0x8EB5u, 0x7B3Du}};
     size_t best_fp = (size_t)-1;
     std::vector<uint32_t> bm(bm_bytes / 4);
     for (const auto &mm : kMul) {
         std::fill(bm.begin(), bm.end(), 0u);
         for (uint32_t g : grams) {
-            const uint32_t i = ngram_bit_index(ngram_hash_host(g, mm[0], mm[1]), f.p.addr_shift, f.p.addr_mask);
-            bm[i >> 5] |= 1u << (i & 31);
+            const uint32_t u = ngram_hash_host(g, mm[0], mm[1]);
+            bm[ngram_word_index(u, f.p.addr_mask)] |= ngram_word_bits(u, f.p.addr_shift);
         }
         uint64_t seed = 0x5EED1234u;
         size_t fp = 0;
-        for (int t = 0; t < 16384; ++t) {
+        for (int t = 0; t < 65536; ++t) {
             const uint64_t r = splitmix(seed);
             uint32_t x = 0;
             for (int i = 0; i < kN; ++i) x |= (uint32_t)alpha[i][(r >> (16 * i)) % alpha[i].size()] << (8 * i);
-            const uint32_t i = ngram_bit_index(ngram_hash_host(x, mm[0], mm[1]), f.p.addr_shift, f.p.addr_mask);
-            fp += (bm[i >> 5] >> (i & 31)) & 1u;
+            const uint32_t u = ngram_hash_host(x, mm[0], mm[1]), bits = ngram_word_bits(u, f.p.addr_shift);
+            fp += (bm[ngram_word_index(u, f.p.addr_mask)] & bits) == bits;
         }
         if (fp < best_fp) {
             best_fp = fp;

@@ -15,7 +15,8 @@ struct NgramFilter {
 
 // The automaton as the kernels walk it, BEFORE any mode-specific encoding: next[state * n_cols + column] in device numbering
 // (0 = sink; states <= dead_hi end a search; states >= accept_lo accept), cmap8[byte] = column of an 8-bit code unit.
-// `absorbing`: containedIn (the first accepting state ends the walk).  max_bm_bytes: LDS left for the bitmap.
+// `absorbing`: containedIn (the first accepting state ends the walk).  prog_lds_bytes: the LDS the program itself takes (the
+// bitmap is sized so that ngram_layout() places it and the waves' queues behind it).
 //
 // What is established ON THE TABLE, not argued from the regex (any failure => no filter for this program):
 //  * the start state does not accept, and the shortest accepted string has min_len >= 4 chars;
@@ -26,10 +27,6 @@ struct NgramFilter {
 //    (o = 0 .. S - 1), expanded to bytes and hashed into the bitmap.  A first accept at char index i therefore has, for the
 //    one o with (i - o) = 0 (mod S), a window [i - o - 4, i - o) in the bitmap: no accept without a candidate.
 NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, const uint8_t *cmap8, int start, int accept_lo, int dead_hi,
-                               bool absorbing, size_t max_bm_bytes);
-
-// host mirror of the device hash (needle_ngram.h): index of window x in a bitmap of 2^bits_log2 bits
-inline uint32_t ngram_hash_host(uint32_t x, uint32_t m1, uint32_t m2) { return (x & 0xFFFFFFu) * m1 + (x >> 16) * m2; }
-inline uint32_t ngram_bit_index(uint32_t u, uint32_t addr_shift, uint32_t addr_mask) { return (((u >> addr_shift) & addr_mask) << 3) | (u & 31u); }
+                               bool absorbing, size_t prog_lds_bytes);
 
 } // namespace needle

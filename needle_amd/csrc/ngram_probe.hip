@@ -34,7 +34,7 @@ __global__ __launch_bounds__(1024) void ngram_filter_probe(const uint8_t *text, 
             r[j % PF] = __builtin_nontemporal_load(j + PF < 16 ? addr(g, j + PF) : addr(g + waves, j + PF - 16));
             const uint32_t pw = needle::ngram_prev_dword(v[3], carry);
             carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);
-            const uint32_t log = needle::ngram_piece<S>(0u, pw, v[0], v[1], v[2], v[3], np.m1, np.m2, np.addr_shift, np.addr_mask, 0u);
+            const uint32_t log = needle::ngram_piece<S>(0u, pw, v[0], v[1], v[2], v[3], np.m1 | np.m2 << 16, np.addr_mask, 0u);
             count += (uint32_t)__builtin_popcount(log);
         }
     }

@@ -6,9 +6,9 @@ import numpy as np
 
 
 def window_passes(info, bitmap, x):
-    u = ((x & 0xFFFFFF) * info["m1"] + (x >> 16) * info["m2"]) & 0xFFFFFFFF
-    i = (((u >> info["addr_shift"]) & info["addr_mask"]) << 3) | (u & 31)
-    return (int(bitmap[i >> 5]) >> (i & 31)) & 1
+    u = ((x & 0xFFFF) * info["m1"] + (x >> 16) * info["m2"]) & 0xFFFFFFFF  # (needle_ngram.h: one v_dot2_u32_u16)
+    w = int(bitmap[(u & info["addr_mask"]) >> 2])  # a window owns two bits of one word
+    return (w >> ((u >> info["addr_shift"]) & 31)) & (w >> ((u >> (info["addr_shift"] - 8)) & 31)) & 1
 
 
 class Automaton:
