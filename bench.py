@@ -2,7 +2,7 @@
 """bench.py -- the BASELINE.json metric on MI355X: GB/s of haystack scanned (+ rows/s, matches/s) by the DFA
 table-walk hot path on the 10M x 256-char synthetic batch.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c3s|c5] [--also c3,c3s,c5|none]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c3s|c5|c5w] [--also c3,c3s,c5,c5w|none]
                     [--rows R] [--scaling strong|weak] [--graph off|scan]
 
 One "step" = one pass of the hot path over the whole device-resident batch: one kernel launch per GPU and, for
@@ -16,7 +16,8 @@ instead); there is no data-path collective.  Rank 0 prints ONE JSON line.
               GPUs) over the barrier-bracketed wall time of exactly K steps (max over ranks), inputs resident in HBM.
   workloads   the other BASELINE configs measured the same way in the same run (`--also`): c3 (union of 1k keywords,
               find), c3s (its sparse-match variant: keywords of 6..8 chars, only the planted 25 % of the rows match,
-              every lane stays live to the end of its row), c5 (BMP class regex over UTF-16, find).
+              every lane stays live to the end of its row), c5 (BMP class regex over UTF-16, find), c5w (its wide variant: per-script
+              runs in sequence -- 30 char classes, 33 states: UTF-16 rows through the two-level page map into an LDS table).
   N > 1       the gathers are issued by the library itself (needle_multi_*: its own RCCL communicator, ONE call per
               step, queued on the scan's stream right behind the kernel); torch.distributed only carries the
               communicator id, the barrier and the max-over-ranks of the clock.  Reported beside the step time: scan_ms,
@@ -39,7 +40,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 ENGINE_CLOCK_MHZ = 2400.0  # MI355X peak engine clock (same guide); chars/clk/CU is quoted against it
-KERNEL_SOURCES = ["needle_scan.h", "needle_kernels.hip", "needle_stripe.hip", "needle_walk.h", "needle_device.h", "needle_lower.cpp"]
+KERNEL_SOURCES = ["needle_scan.h", "needle_kernels.hip", "needle_stripe.hip", "needle_walk.h", "needle_device.h", "needle_lower.cpp",
+                  "needle_ngram.h", "needle_ngram.hip", "needle_ngram_host.cpp"]
 
 
 def kernel_source_sha():
@@ -65,6 +67,9 @@ def make_pattern(workload):
                 "union-of-1k-keywords, sparse-match variant (6..8 chars: only the planted 25 % of the rows match) find()", words)
     if workload == "c5":
         return DFACompiler.compile(W.script_regex(), "ScriptRuns"), "BMP char-class regex find() over UTF-16", None
+    if workload == "c5w":
+        return (DFACompiler.compile(W.scriptseq_regex(), "ScriptSeq"),
+                "BMP multi-class regex (per-script runs in sequence: 30 classes, 33 states) find() over UTF-16", None)
     raise SystemExit("unknown workload " + workload)
 
 
@@ -72,7 +77,7 @@ def make_rows(workload, words, row0, n_rows, device):
     """Shard [row0, row0 + n_rows) of the synthetic batch, generated on the GPU in slabs."""
     import torch
     from needle_amd import workload as W
-    dtype = torch.int16 if workload == "c5" else torch.uint8
+    dtype = torch.int16 if workload in ("c5", "c5w") else torch.uint8
     out = torch.empty((n_rows, 256), dtype=dtype, device=device)
     slab = 1 << 19
     for s in range(0, n_rows, slab):
@@ -81,6 +86,8 @@ def make_rows(workload, words, row0, n_rows, device):
             out[s:s + n] = W.digits_batch(torch, row0 + s, n, 256, device=device)
         elif workload in ("c3", "c3s"):
             out[s:s + n] = W.keyword_batch(torch, words, row0 + s, n, 256, device=device)
+        elif workload == "c5w":
+            out[s:s + n] = W.scriptseq_batch(torch, row0 + s, n, 256, device=device)
         else:
             out[s:s + n] = W.script_batch(torch, row0 + s, n, 256, device=device)
     return out
@@ -206,8 +213,12 @@ def verify_gather(sh, dev, row0, n_rows, total_rows, is_find, rank):
         return int(((a.long() + 3 * b.long() + 7) * idx).sum().item())
 
     local_words = (n_rows + 63) // 64
+    if is_find and n_rows and "start" not in s:  # the scan stored the dword form itself (ShardedScan scan_packed): this rank's own halves
+        loc_st, loc_en = sh._unpack(s["packed"][:n_rows].clone())
+    elif is_find and n_rows:
+        loc_st, loc_en = s["start"][:n_rows], s["end"][:n_rows]
     mine = torch.tensor([popcount(s["bitmap"][:local_words]) if n_rows else 0,
-                         checksum(s["start"][:n_rows], s["end"][:n_rows], row0) if (is_find and n_rows) else 0],
+                         checksum(loc_st, loc_en, row0) if (is_find and n_rows) else 0],
                         dtype=torch.int64, device=dev)
     dist.all_reduce(mine)
     want_pop, want_sum = int(mine[0].item()), int(mine[1].item())
@@ -252,9 +263,13 @@ def measure(workload, args, ctx, headline):
     def scan(bitmap, start, end):
         op(rows, out=(bitmap, start, end) if is_find else bitmap)
 
-    # N > 1, find: start / end cross the links as one dword per row (rows are 256 chars: two 16-bit halves)
+    def scan_packed(bitmap, packed):  # needle_find_packed16_dev: the scan kernel stores the dword form itself
+        pattern.find_packed16_batch(rows, out=(bitmap, packed))
+
+    # N > 1, find: start / end cross the links as one dword per row (rows are 256 chars: two 16-bit halves), written by the scan
+    # straight into the send buffer
     sh = ShardedScan(scan, total_rows, world, rank, is_find, dev, n_buffers=args.buffers, comm=ctx.comm, overlap=args.overlap == "on",
-                     pack16=use_dist and is_find, max_row_len=rows.shape[1])
+                     pack16=use_dist and is_find, max_row_len=rows.shape[1], scan_packed=scan_packed if is_find else None)
     for _ in range(2):  # first launches: program upload, kernel attributes (never part of a captured graph)
         sh.scan_only()
     torch.cuda.synchronize()
@@ -382,6 +397,9 @@ def measure(workload, args, ctx, headline):
     props = torch.cuda.get_device_properties(dev)
     inf = pattern.info()
     which = {"contained_in": "contained_in", "find": "forwards", "matches": "matches"}[op_name]
+    # the kernel behind the op: the n-gram candidate filter kernel where the program carries a filter (8-bit rows, containedIn / find)
+    pre = pattern.prefilter_info(which) if cw == 1 and which != "matches" else {"on": 0}
+    kernel_name = "needle::ngram_kernel" if pre["on"] else "needle::scan_kernel"
     mode_names = {0: "packed functions", 1: "LDS table u8", 2: "LDS table u16", 3: "HBM table", 4: "LDS pair table", 5: "LDS hot rows + HBM table",
                   6: "compressed automaton in LDS (dense rows + exception records)"}
     out = {
@@ -400,11 +418,13 @@ def measure(workload, args, ctx, headline):
                    "parallelism": "row-shard x%d" % world,
                    "result": "bitmap" + (("+start/end int32" + (" (on the links: one dword per row, two 16-bit halves)" if use_dist else "")) if is_find else ""),
                    "automaton": {"states": inf["n_states"][which], "classes": inf["stride"],
-                                 "kernel_mode": mode_names.get(inf["kernel_mode"][which], str(inf["kernel_mode"][which]))},
+                                 "kernel_mode": mode_names.get(inf["kernel_mode"][which], str(inf["kernel_mode"][which])),
+                                 "prefilter": ({"windows": pre["n_windows"], "stride": pre["stride"], "run_up": pre["warm"], "bitmap_bytes": pre["bitmap_bytes"]}
+                                               if pre["on"] else None)},
                    "launch": "HIP graph replay" if graphs else "eager"},
         "roofline": {"bound": "hbm", "achieved": bytes_gpu / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_gpu / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "needle::scan_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_gpu,
+                     "kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_gpu,
                      "chars_per_clk_per_cu": n_rows * 256 / (kernel_ms * 1e-3) / (ENGINE_CLOCK_MHZ * 1e6) / props.multi_processor_count},
         "host_issue_us_per_step": t_issue / args.steps * 1e6,
         "prewarm": {"ms": prewarm_ms, "what": "untimed copies of the batch before the W warm-up steps (steady clocks)"},
@@ -455,6 +475,32 @@ def measure(workload, args, ctx, headline):
                                        else ("ONE all-gather (RCCL) of the bitmap words: %d B per rank" % (sh.per_words * 8)),
                          "issued_by": "libneedle_hip.so (needle_multi_*)" if ctx.comm is not None else "torch.distributed",
                          "note": "gather_ms = blocking (scan + gathers) - blocking scan; inside the timed steps the gathers overlap the next scan"}
+    if use_dist and args.all_on_device is not None:
+        # C4 rehearsal on ONE GPU (every rank's shard on the same device, gloo carrying the gathers): inside the timed steps the
+        # ranks' kernels contend for the chip, so each rank also times its shard's scan ALONE, in turn -- what one GPU of an
+        # 8-GPU node would spend on its 1/N of the batch.  N x the slowest of these against the N = 1 kernel time says what row
+        # sharding itself costs (shorter launches, the tail) before any link is involved.
+        solo = 0.0
+        for r in range(world):
+            dist.barrier()
+            if r == rank and n_rows:
+                for _ in range(5):
+                    sh.scan_only()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(50):
+                    sh.scan_only()
+                b.record()
+                torch.cuda.synchronize()
+                solo = a.elapsed_time(b) / 50
+        dist.barrier()
+        tt = torch.tensor([solo], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out["solo_kernel_ms"] = {"max_over_ranks": float(tt.item()), "x_ranks": float(tt.item()) * world,
+                                 "what": "each rank's shard scanned alone on the shared device: 50 back-to-back launches between two HIP events; x_ranks = N x the "
+                                         "slowest.  With N processes holding queues on one device this includes the driver's switching between "
+                                         "their queues -- an upper bound on a rank's kernel, not the kernel (c4_shard_step has that)"}
     if headline and rank == 0 and world == 1 and not args.no_extras:
         out["roofline"]["device"] = {"name": props.name, "cus": props.multi_processor_count, "clock_mhz_nominal": ENGINE_CLOCK_MHZ}
         ceil = measured_read_ceiling(rows)
@@ -501,8 +547,6 @@ def measure(workload, args, ctx, headline):
         if is_find and rows.shape[1] <= 65534:
             # the compact result forms (include/needle_hip.h): matched rows only as {row, start, end} records in row order
             # (needle_find_compact_dev: 8 B per MATCHED row over PCIe, after an 8-byte count), and start / end as one dword per row
-            from needle_amd import _lib as _nl
-            from needle_amd.pattern import _check as _nchk
             cw_, cr_, cc_ = torch.empty(sh.per_words, dtype=torch.int64, device=dev), torch.empty((n_rows, 2), dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
             hcnt = torch.zeros(1, dtype=torch.int64).pin_memory()
             d2h = [0]
@@ -522,13 +566,12 @@ def measure(workload, args, ctx, headline):
             hpk = hs
 
             def landed_packed():
-                s = sh.scan_only()
-                _nchk(_nl.lib().needle_pack_start_end16_dev(s["start"].data_ptr(), s["end"].data_ptr(), n_rows, pk.data_ptr(), torch.cuda.current_stream().cuda_stream))
-                hb.copy_(s["bitmap"], non_blocking=True)
+                pattern.find_packed16_batch(rows, out=(cw_, pk))
+                hb.copy_(cw_, non_blocking=True)
                 hpk.copy_(pk, non_blocking=True)
             dtp = per_step(landed_packed)
             out["host_landed"]["packed16"] = {"ms_per_step": dtp * 1e3, "d2h_bytes_per_step": sh.per_words * 8 + 4 * n_rows,
-                                              "note": "scan + needle_pack_start_end16_dev + D2H of 4 B per row"}
+                                              "note": "needle_find_packed16_dev (the scan stores one dword per row itself) + D2H of 4 B per row"}
             del cw_, cr_, cc_, pk
     if rank == 0 and world == 1 and not args.no_extras and workload == "c3" and is_find:
         # EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
@@ -573,9 +616,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c5"], help="the headline workload")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c5", "c5w"], help="the headline workload")
     ap.add_argument("--also", default=None, help="comma list of further workloads measured into \"workloads\" "
-                    "(default: c3,c3s,c5 at 1 GPU, c3 at N > 1; 'none' for profiling runs)")
+                    "(default: c3,c3s,c5,c5w at 1 GPU, c3 at N > 1; 'none' for profiling runs)")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--graph", default="off", choices=["off", "scan"], help="launch the scan as a HIP graph (experiment; plain launches are faster)")
@@ -633,7 +676,7 @@ def main():
         if int(ok.item()) == 0:
             ctx.comm = None
     if args.also is None:
-        also = ["c3", "c3s", "c5"] if world == 1 else ["c3"]
+        also = ["c3", "c3s", "c5", "c5w"] if world == 1 else ["c3"]
         if args.regex or args.op or args.rows != 10_000_000:
             also = []
     else:

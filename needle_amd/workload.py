@@ -144,6 +144,80 @@ def script_batch(xp, row0, n_rows, n_cols=256, seed=SEED, device=None):
     return out.astype(np.uint16) if xp is np else out.to(xp.int16)
 
 
+# C5w ("wide"): what C5 was meant to stress (tens of classes, tens of states) -- per-script runs IN SEQUENCE, so
+# that every script (and several sub-ranges of it) is a char class of its own and the automaton has to remember where in which
+# alternative it is: UTF-16 rows go ptab -> page -> column -> LDS table.  Explicit ranges only (no \\w / \\p; the reference's parser has {n} and {n,m}, no {n,}).
+SEQ_ALTS = [
+    # (regex alternative, [(lo, hi, min, max) per element of a planted instance])
+    ("[\u0391-\u03a1][\u03b1-\u03c1\u03c3-\u03c9]{2}[\u03b1-\u03c1\u03c3-\u03c9]*", [(0x0391, 0x03A1, 1, 1), (0x03B1, 0x03C1, 2, 5)]),              # Greek capital, then lower
+    ("[\u0410-\u042f][\u0430-\u044f]+\u0451?", [(0x0410, 0x042F, 1, 1), (0x0430, 0x044F, 1, 5)]),                        # Cyrillic
+    ("[\u05d0-\u05ea]{3}[\u05d0-\u05ea]*", [(0x05D0, 0x05EA, 3, 6)]),                                                                      # Hebrew
+    ("[\u0531-\u0556][\u0561-\u0586]{2}[\u0561-\u0586]*", [(0x0531, 0x0556, 1, 1), (0x0561, 0x0586, 2, 4)]),                             # Armenian
+    ("[\u0905-\u0914][\u0915-\u0939]+[\u093e-\u094c]", [(0x0905, 0x0914, 1, 1), (0x0915, 0x0939, 1, 3), (0x093E, 0x094C, 1, 1)]),  # Devanagari
+    ("[\u0e01-\u0e2e][\u0e30-\u0e3a][\u0e01-\u0e2e]", [(0x0E01, 0x0E2E, 1, 1), (0x0E30, 0x0E3A, 1, 1), (0x0E01, 0x0E2E, 1, 1)]),   # Thai
+    ("[\u10d0-\u10fa]{4}", [(0x10D0, 0x10FA, 4, 4)]),                                                                       # Georgian
+    ("[\u3041-\u3096]+[\u30a1-\u30fa]{2}", [(0x3041, 0x3096, 1, 4), (0x30A1, 0x30FA, 2, 2)]),                              # Hiragana, then Katakana
+    ("[\u4e00-\u4e3f][\u4e80-\u4ebf][\u4f00-\u4f3f]", [(0x4E00, 0x4E3F, 1, 1), (0x4E80, 0x4EBF, 1, 1), (0x4F00, 0x4F3F, 1, 1)]),   # three CJK blocks in order
+    ("[\u5000-\u503f]{2}[\u5100-\u513f]+[\u5200-\u523f]", [(0x5000, 0x503F, 2, 2), (0x5100, 0x513F, 1, 3), (0x5200, 0x523F, 1, 1)]),
+    ("[\uac00-\uac7f]{2}[\uad00-\uad7f]", [(0xAC00, 0xAC7F, 2, 2), (0xAD00, 0xAD7F, 1, 1)]),                              # Hangul
+    ("[0-9]+[A-Z][a-z]{2}\u00e9", [(0x30, 0x39, 1, 3), (0x41, 0x5A, 1, 1), (0x61, 0x7A, 2, 2), (0xE9, 0xE9, 1, 1)]),
+]
+
+
+def scriptseq_regex():
+    """C5w regex: the union of SEQ_ALTS."""
+    return "|".join(a for a, _ in SEQ_ALTS)
+
+
+def scriptseq_instances(n=256, seed=SEED):
+    """n matching strings (lists of code units), round-robin over the alternatives, lengths / chars hashed."""
+    out = []
+    for i in range(n):
+        _, els = SEQ_ALTS[i % len(SEQ_ALTS)]
+        w = []
+        for j, (lo, hi, mn, mx) in enumerate(els):
+            k = mn + _h32i((seed ^ 0x5E9) + i * 131 + j * 7) % (mx - mn + 1)
+            w += [lo + _h32i(seed + i * 1009 + j * 101 + t * 1000003) % (hi - lo + 1) for t in range(k)]
+        out.append(w)
+    return out
+
+
+def scriptseq_batch(xp, row0, n_rows, n_cols=256, seed=SEED, device=None):
+    """C5w: UTF-16 code units: 60 % ASCII letters / digits / space, 10 % BMP symbols outside every range, 30 % chars drawn from the
+    alternatives' own ranges (so walks keep entering alternatives and falling out of them); in 30 % of the rows one matching
+    instance is planted."""
+    r, c = _grid(xp, row0, n_rows, n_cols, device)
+    h = _hash32(seed + 55 + r * 1315423911 + c * 2654435761)
+    sel = h % 100
+    ascii_ch = _lut(xp, ALPHA_C2, device)[(h >> 8) % len(ALPHA_C2)]
+    rng = [(lo, hi) for _, els in SEQ_ALTS for lo, hi, _, _ in els if lo > 0x7F and hi > lo]
+    starts = _lut(xp, [a for a, _ in rng], device)
+    sizes = _lut(xp, [b - a + 1 for a, b in rng], device)
+    ri = (h >> 10) % len(rng)
+    in_range = starts[ri] + (h >> 17) % sizes[ri]
+    other = 0x2000 + (h >> 9) % 0x0C00
+    base = xp.where(sel < 60, ascii_ch, xp.where(sel < 70, other, in_range))
+    inst = scriptseq_instances()
+    maxlen = max(len(w) for w in inst)
+    wtab = np.zeros((len(inst), maxlen), dtype=np.int64)
+    wlen = np.zeros(len(inst), dtype=np.int64)
+    for i, w in enumerate(inst):
+        wtab[i, :len(w)] = w
+        wlen[i] = len(w)
+    wtab, wlen = _lut(xp, wtab, device), _lut(xp, wlen, device)
+    hr = _hash32((seed ^ 0x5C5C5C5C) + r * 40503)
+    plant = (hr % 10) < 3
+    k = (hr >> 4) % len(inst)
+    ln = wlen[k]
+    pos = (hr >> 12) % (n_cols - ln + 1)
+    rel = c - pos
+    inside = plant & (rel >= 0) & (rel < ln)
+    relc = xp.clip(rel, 0, maxlen - 1) if xp is np else rel.clamp(0, maxlen - 1)
+    planted = wtab[k + 0 * c, relc]
+    out = xp.where(inside, planted, base)
+    return out.astype(np.uint16) if xp is np else out.to(xp.int16)
+
+
 def url_strings(n=1000, seed=SEED):
     """C1: 50 % "http://"+1..40 chars of [a-z0-9./]; 25 % the same without the prefix; 25 % prefix + a newline inside."""
     alpha = "abcdefghijklmnopqrstuvwxyz0123456789./"

@@ -111,6 +111,50 @@ def test_c5_bmp_class_regex_utf16():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ragged", [False, True])
+def test_c5w_multi_class_bmp_regex_utf16(ragged):
+    """C5's wide variant (needle_amd/workload.py SEQ_ALTS): 30 char classes, 33 states -- UTF-16 rows through the two-level page
+    map (DFA.java:438-463 byte classes; DFAClassBuilder.java:269-305 the class lookup) into an LDS table.  Against the oracle on
+    the same tables and, on a sample, against Python's `re` on the same regex (an implementation that shares nothing with either)."""
+    import re
+    import torch
+    from needle_amd import workload as W
+    from needle_amd.pattern import unpack_bitmap
+    rx = W.scriptseq_regex()
+    p, o = compiled(rx)
+    inf = p.info()
+    assert inf["stride"] >= 20 and inf["n_states"]["forwards"] > 5
+    n = 100_000
+    rows = W.scriptseq_batch(torch, 41, n, 256, device="cuda")
+    host = rows.cpu().numpy().view(np.uint16)
+    assert (host == W.scriptseq_batch(np, 41, n, 256)).all()
+    lens = tl = None
+    if ragged:
+        lens = (np.arange(n, dtype=np.uint32) * 2654435761 % 257).astype(np.uint32)
+        tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    fw, fs, fe = p.find_batch(rows, tl)
+    of, ofs, ofe = o.batch_find(host, lens, threads=4)
+    fs, fe = fs.cpu().numpy(), fe.cpu().numpy()
+    assert (unpack_bitmap(fw, n) == of).all()
+    assert (fs == ofs).all() and (fe == ofe).all()
+    assert (0.15 if ragged else 0.25) < of.mean() < 0.6
+    assert (unpack_bitmap(p.contained_in_batch(rows, tl), n) == o.batch_contained_in(host, lens, threads=4)).all()
+    assert (unpack_bitmap(p.matches_batch(rows, tl), n) == o.batch_matches(host, lens, threads=4)).all()
+    cre = re.compile(rx)
+    for i in range(0, n, 97):
+        text = "".join(map(chr, host[i][:None if lens is None else lens[i]]))
+        mm = cre.search(text)
+        assert ((True, mm.start(), mm.end()) if mm else (False, -1, -1)) == (bool(of[i]), int(fs[i]), int(fe[i])), i
+    # every match of every row (one-pass find-all) on a slice, against the oracle's repeated find()
+    k = 20_000
+    offs, as_, ae = p.find_all_batch(rows[:k], None if tl is None else tl[:k])
+    offs, as_, ae = offs.cpu().numpy(), as_.cpu().numpy(), ae.cpu().numpy()
+    for i in range(0, k, 53):
+        want = o.find_all(host[i] if lens is None else host[i][:lens[i]])
+        assert list(zip(as_[offs[i]:offs[i + 1]].tolist(), ae[offs[i]:offs[i + 1]].tolist())) == want, i
+
+
+@pytest.mark.gpu
 def test_matches_txt_rows_through_gpu_matcher():
     doc = json.load(open(os.path.join(GOLDEN, "matches.json")))
     from needle_amd.pattern import DFACompiler

@@ -8,6 +8,8 @@ resident batch, plus the oracle itself on a seeded sample of rows spread over th
   C3  keywords    find.matched ==   containedIn bitmap; [start, end) spells one of the 1000 keywords; nothing matches
                   when the row is cut one char before `end` (lengths = end - 1): leftmost match really ends at `end`
   C5  BMP runs    find.matched ==   containedIn; [start, end) is a maximal run of in-range chars of length >= 3
+  C5w scripts     find.matched ==   containedIn; [start, end) spells one alternative (Python `re.fullmatch` on sampled rows) and
+                  `re.search` finds the same span; the span starts with a char of an alternative's first class
   C3  find-all    (every match of every row, 46.6 M of them) slot 0 == find(); every match spells a keyword; matches are
                   ordered and disjoint; count pass == filed counts; compact form == dense form; rounds of find_next agree
                   on the second match; the oracle's repeated find() on sampled rows
@@ -234,3 +236,43 @@ def test_c5_full_size_properties():
         assert bool((run3.any(dim=1) == mt).all())
     partition_invariant(p.find_batch, rows, fw)
     check_sample_against_oracle(p, rows, f_bits, fs.cpu().numpy(), fe.cpu().numpy(), c_bits)
+
+
+@pytest.mark.gpu
+def test_c5w_full_size_properties():
+    """C5's wide variant at 10^7 UTF-16 rows (30 classes, 33 states: page-map lookups into an LDS table)."""
+    import re
+    import torch
+    from needle_amd import workload as W
+    from needle_amd.pattern import unpack_bitmap
+    p, rows, _ = make("c5w")
+    n = rows.shape[0]
+    fw, fs, fe = p.find_batch(rows)
+    f_bits = unpack_bitmap(fw, n)
+    cw = p.contained_in_batch(rows)
+    c_bits = unpack_bitmap(cw, n)
+    assert (f_bits == c_bits).all()
+    assert 0.25 < f_bits.mean() < 0.6
+    # a match starts with a char of some alternative's first class and is at least 2 chars long (a second way: torch lookups)
+    first = torch.zeros(65536, dtype=torch.bool, device="cuda")
+    for _, els in W.SEQ_ALTS:
+        first[els[0][0]:els[0][1] + 1] = True
+    matched = torch.from_numpy(f_bits).cuda()
+    slab = 1 << 20
+    for s in range(0, n, slab):
+        r = rows[s:s + slab].long() & 0xFFFF
+        st, en, mt = fs[s:s + slab].long(), fe[s:s + slab].long(), matched[s:s + slab]
+        c0 = r.gather(1, st.clamp(0, 255)[:, None])[:, 0]
+        assert bool((first[c0] | ~mt).all())
+        assert bool((((en - st) >= 2) & (en <= 256) | ~mt).all())
+        assert bool((((st == -1) & (en == -1)) | mt).all())
+    partition_invariant(p.find_batch, rows, fw)
+    hs, he = fs.cpu().numpy(), fe.cpu().numpy()
+    check_sample_against_oracle(p, rows, f_bits, hs, he, c_bits)
+    # Python's own regex engine on a sample spread over the batch
+    cre = re.compile(W.scriptseq_regex())
+    idx = sample_rows(n, k=3000, seed=11)[::3]
+    host = rows[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint16)
+    for j, i in enumerate(idx):
+        mm = cre.search("".join(map(chr, host[j])))
+        assert ((True, mm.start(), mm.end()) if mm else (False, -1, -1)) == (bool(f_bits[i]), int(hs[i]), int(he[i])), i

@@ -180,6 +180,48 @@ def test_bench_two_ranks_on_one_gpu(workload):
     assert "gather_verified" not in d1 and d1["cold"]["ms_per_step"] > 0 and d1["steady"]["steps_effective"] >= 3
 
 
+@pytest.mark.gpu
+def test_c4_rehearsal_eight_ranks_full_batch_on_one_gpu():
+    """C4 without an 8-GPU node: `bench.py --gpus 8` end to end on ONE GPU on the real 10^7-row batch -- eight
+    processes, shards of 1 250 048 rows on 64-row boundaries, gloo carrying the gathers, gather_verified, scan_ms / gather_ms --
+    and what row sharding itself costs: 8 x the slowest rank's shard kernel (timed alone on the device) within 15 % of the N = 1
+    kernel.  Rows are independent units (DFAClassBuilder.java:669-699: a Matcher per haystack), so nothing else can differ."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for workload in ("c2", "c3"):
+        base = [sys.executable, "bench.py", "--workload", workload, "--steps", "10", "--warmup", "2", "--also", "none", "--no-cpu-baseline", "--no-extras"]
+        one = subprocess.run(base, capture_output=True, text=True, cwd=ROOT, timeout=900)
+        assert one.returncode == 0, one.stderr[-2000:]
+        d1 = json.loads(one.stdout.strip().splitlines()[-1])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29547",
+               "bench.py", "--gpus", "8", "--backend", "gloo", "--all-on-device", "0"] + base[2:]
+        eight = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=1800)
+        assert eight.returncode == 0, eight.stderr[-3000:]
+        lines = [ln for ln in eight.stdout.strip().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d8 = json.loads(lines[0])
+        assert d8["n_gpus"] == 8 and d8["scaling"] == "strong" and d8["config"]["rows_total"] == 10_000_000 and d8["config"]["rows_per_gpu"] == 1_250_048
+        assert d8["gather_verified"] is True and d8["gather_check"]["popcount_gathered"] == d8["gather_check"]["popcount_ranks"]
+        if workload == "c3":
+            assert d8["gather_check"]["checksum_gathered"] == d8["gather_check"]["checksum_ranks"]
+            assert "one dword per row" in d8["config"]["result"]
+        assert abs(d8["matched_fraction"] - d1["matched_fraction"]) < 1e-12
+        assert d8["scan_ms"] > 0 and "gather_ms" in d8 and d8["value"] > 0
+        # what sharding itself costs: one GPU's shard (1 250 048 rows) scanned by ONE process on the same device, x 8, against the
+        # N = 1 kernel.  (The ranks' own solo timings inside the 8-process run are reported too, but with eight processes holding
+        # queues on one device they include the driver's switching between them: an upper bound only.)
+        shard = subprocess.run(base + ["--rows", "1250048"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+        assert shard.returncode == 0, shard.stderr[-2000:]
+        ds = json.loads(shard.stdout.strip().splitlines()[-1])
+        k1, k8 = d1["roofline"]["kernel_ms"], 8 * ds["roofline"]["kernel_ms"]
+        assert abs(k8 / k1 - 1.0) < 0.15, (workload, k1, k8)
+        assert d8["solo_kernel_ms"]["max_over_ranks"] >= 0.8 * ds["roofline"]["kernel_ms"], (d8["solo_kernel_ms"], ds["roofline"]["kernel_ms"])
+        print("C4 rehearsal %s: N=1 kernel %.4f ms, 8 x shard kernel %.4f ms, 8-process solo x8 %.4f ms, step %.4f ms (scan %.4f + gather %.4f)" % (
+            workload, k1, k8, d8["solo_kernel_ms"]["x_ranks"], d8["ms_per_step"], d8["scan_ms"], d8["gather_ms"]))
+
+
 PACKED = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")

@@ -91,3 +91,31 @@ def test_find_takes_the_lengths_form_on_lds_tables():
     assert names["mode"] == 4 and names["lengths_form"] == 1  # the pair table carries the lengths automaton too (40 states)
     assert DFACompiler.compile("[0-9]+x", "t", 0).program_info("forwards", 1)["lengths_form"] == 0  # unbounded
     assert DFACompiler.compile("(ab|a|bcdef|g)x", "t", 0).program_info("forwards", 1)["lengths_form"] in (0, 1)
+
+
+def test_c5w_is_a_multi_class_utf16_table_automaton(oracle_lib):
+    """C5's wide variant (needle_amd/workload.py SEQ_ALTS): tens of classes, tens of states; on UTF-16 rows a plain
+    uint8 LDS table behind the two-level page map (no pair table: 8-bit rows only).  The generator's planted instances match, and
+    the oracle agrees with Python's `re` on the generated rows."""
+    import re
+    import numpy as np
+    from needle_amd import workload as W
+    from test_compile_matches_txt import oracle_for
+    from needle_amd.pattern import DFACompiler
+    rx = W.scriptseq_regex()
+    p = DFACompiler.compile(rx, "ScriptSeq", 0)
+    inf = p.info()
+    assert inf["stride"] >= 20 and inf["n_states"]["forwards"] > 20 and inf["n_states"]["contained_in"] > 20, inf
+    for w in ("forwards", "contained_in", "matches"):
+        d = p.program_info(w, 2)
+        assert d["mode"] == 1 and d["waves"] == 16 and d["tile_bytes"] == 128, (w, d)
+    cre = re.compile(rx)
+    for w in W.scriptseq_instances():
+        assert cre.fullmatch("".join(map(chr, w))), w
+    o, _ = oracle_for(rx, 0)
+    rows = W.scriptseq_batch(np, 3, 1500, 256)
+    m, s, e = o.batch_find(rows, threads=4)
+    assert 0.25 < m.mean() < 0.6
+    for i in range(len(rows)):
+        mm = cre.search("".join(map(chr, rows[i])))
+        assert ((True, mm.start(), mm.end()) if mm else (False, -1, -1)) == (bool(m[i]), int(s[i]), int(e[i])), i

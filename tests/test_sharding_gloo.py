@@ -72,6 +72,22 @@ def _worker(rank, world, port, total_rows, q):
             assert (fullp == full).all() and (stp == st).all() and (enp == en).all()
         else:
             assert fullp is None and stp is None and enp is None
+        # ... and with the scan storing the dword form itself, straight into the send buffer (needle_find_packed16_dev on the GPU;
+        # here the oracle's results packed the same way): no int32 arrays, no pack pass, the same gathered results
+        def scan_packed(bitmap, packed):
+            m, s, e = o.batch_find(rows)
+            bitmap[:(n + 63) // 64] = _pack(m)
+            packed[:n] = torch.from_numpy(((s.astype(np.int64) & 0xFFFF) | ((e.astype(np.int64) & 0xFFFF) << 16)).astype(np.uint32).view(np.int32))
+
+        shd = ShardedScan(scan, total_rows, world, rank, True, "cpu", n_buffers=2, pack16=True, max_row_len=rows.shape[1] if n else 256,
+                          scan_packed=scan_packed)
+        assert shd.pack16 and "start" not in shd.sets[0]
+        fulld, std, end_ = shd.wait(shd.step())
+        if rank == 0:
+            assert (fulld == full).all() and (std == st).all() and (end_ == en).all()
+        else:
+            assert fulld is None and std is None and end_ is None
+        assert ShardedScan(scan, total_rows, world, rank, True, "cpu", pack16=True, max_row_len=70000, scan_packed=scan_packed).scan_packed is None
         # the contained_in step (bitmap only) and the plain helpers
         bits = o.batch_contained_in(rows) if n else np.zeros(0, dtype=bool)
 
@@ -89,7 +105,7 @@ def _worker(rank, world, port, total_rows, q):
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from bench import verify_gather
-        for find_op, step_obj in ((True, sh), (True, shp), (False, shc)):
+        for find_op, step_obj in ((True, sh), (True, shp), (True, shd), (False, shc)):
             chk = verify_gather(step_obj, "cpu", row0, n, total_rows, find_op, rank)
             assert chk["ok"] and chk["popcount_gathered" if (rank == 0 or not find_op) else "popcount_ranks"] == chk["popcount_ranks"]
         if world > 1 and total_rows > 64 * world:
