@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NEEDLE_LIB", os.path.join(_HERE, "libneedle_hip.so"))
 NEEDLE_OK, ERR_INVALID, ERR_SYNTAX, ERR_COMPILE, ERR_UNSUPPORTED, ERR_DEVICE = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
-    "needle_version", "needle_last_error", "needle_device_count", "needle_trim_scratch", "needle_compile", "needle_pattern_from_tables",
+    "needle_version", "needle_last_error", "needle_device_count", "needle_trim_scratch", "needle_tuning_info", "needle_compile", "needle_pattern_from_tables",
     "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_program_info", "needle_pattern_prefilter_info", "needle_pattern_match_lengths", "needle_pattern_get_class_map", "needle_pattern_get_table",
     "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_find_packed16_dev", "needle_find_next_dev", "needle_find_all_dev", "needle_find_all_packed16_dev", "needle_count_matches_dev", "needle_find_all_csr_dev", "needle_find_all_host", "needle_find_all_packed16_host", "needle_find_all_csr_host",
     "needle_pack_start_end16_dev", "needle_unpack_start_end16_dev", "needle_matches_host",

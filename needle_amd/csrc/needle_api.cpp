@@ -28,8 +28,10 @@ hipError_t launch_spec_init(const SpecArgs &a, hipStream_t stream);
 hipError_t launch_spec_fix(const SpecArgs &a, hipStream_t stream);
 hipError_t launch_spec_reduce(const SpecArgs &a, hipStream_t stream);
 hipError_t launch_backward_rows(int char_width, const StripeArgs &a, hipStream_t stream);
-bool dict_kernel_applies(int char_width, const ScanArgs &a);                      // needle_dict.hip: two row sets per wave
+#ifdef NEEDLE_TUNING // needle_dict.hip (two row sets per wave; measured, no faster -- DESIGN.md s4) is part of measurement builds only
+bool dict_kernel_applies(int char_width, const ScanArgs &a);
 hipError_t launch_dict(int op, const ScanArgs &a, int n_cus, hipStream_t stream);
+#endif
 // needle_ngram.hip: containedIn / find behind the n-gram candidate filter
 bool ngram_shape_ok(const ScanArgs &a);
 size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng);
@@ -439,7 +441,11 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     if (v->n_rows == 0) return NEEDLE_OK;
     if (!d_bitmap) return fail(NEEDLE_ERR_INVALID, "bitmap is NULL");
     if (op == OP_FIND && !d_packed && (!d_start || !d_end)) return fail(NEEDLE_ERR_INVALID, "start/end is NULL");
+#ifdef NEEDLE_TUNING
     static const int dict_env = getenv("NEEDLE_DICT") ? atoi(getenv("NEEDLE_DICT")) : 0;
+#else
+    constexpr int dict_env = 0;
+#endif
     if (d_packed && (dict_env > 0 || v->row_stride * v->char_width >= 8 * (uint64_t)kStripeBytes)) {
         int32_t *tmp = nullptr;
         HIP_TRY(scratch_malloc((void **)&tmp, (size_t)v->n_rows * 8, (hipStream_t)stream));
@@ -517,10 +523,11 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     skip_backward = skip_backward || dbg_no_backward;
 #endif
     if (skip_backward && op == OP_FIND) a.fixed_len = 0, a.bprog = nullptr;
+#ifdef NEEDLE_TUNING
     // Big automata on full 8-bit rows: two 64-row sets per wave (needle_dict.hip) over the whole 128-row pairs of the batch, the
     // ordinary kernel on what is left; find()'s starts by indexBackwards afterwards, one lane per matched row.
-    // NEEDLE_DICT: 0 off (default: measured, it is no faster -- DESIGN.md s4), 1 on for the compressed automaton, 2 also for
-    // plain uint16 LDS tables.
+    // Measurement builds only (scripts/build_tuning.sh).  NEEDLE_DICT: 0 off (default: measured, it is no faster -- DESIGN.md s4),
+    // 1 on for the compressed automaton, 2 also for plain uint16 LDS tables.
     if (dict_env > 0 && !lengths_form && (a.hdr.mode == MODE_SPARSE || dict_env > 1) && dict_kernel_applies((int)v->char_width, a)) {
         HIP_TRY(launch_dict(op, a, n_cus, (hipStream_t)stream));
         const uint64_t done_rows = (a.n_rows >> 7) << 7;
@@ -548,6 +555,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
         a.bitmap += done_rows >> 6;
         if (a.start) a.start += done_rows, a.end += done_rows;
     }
+#endif
     // The n-gram candidate filter (needle_ngram.hip): the automaton only runs where a hashed 4-byte window of the
     // text can stand ahead of a match.  For programs whose lowering established that this gives the reference's answers
     // (needle_ngram_host.cpp), on containedIn() and on find() whose start is end - length (lengths programs, one-length patterns).

@@ -73,4 +73,5 @@ for regex in ("Sherlock", "Moriarty", "Zanzibar", "Sherlock Holmes|Mycroft", "Ad
     }
     print(regex, out["patterns"][regex])
 os.makedirs(os.path.join(ROOT, "gpurun_out", "r3"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r3", "prefix_prefilter_ab.json"), "w"), indent=1)
+os.makedirs(os.path.join(ROOT, "gpurun_out", "r4"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r4", "prefix_prefilter_ab.json"), "w"), indent=1)

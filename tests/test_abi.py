@@ -134,3 +134,31 @@ def test_table_string_codec_known_answers(lib):
     assert (got == t).all()
     with pytest.raises(ValueError):  # fill_bytes_from_string_errors_on_bad_input: "1-z"
         Pattern.from_tables(cm, 4, {k: dict(spec, table_strings=["0:1-z"]) for k in ("matches", "contained_in", "forwards", "backwards")})
+
+
+def test_tuning_info_lists_every_environment_switch(lib):
+    """needle_tuning_info (include/needle_hip.h): every getenv("NEEDLE_...") in the library's sources is in the table, and the table
+    names nothing the sources do not read; the same list stands in INTEGRATION.md."""
+    import glob
+    need = ctypes.c_size_t(0)
+    lib.needle_tuning_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    assert lib.needle_tuning_info(None, 0, ctypes.byref(need)) == 0 and need.value > 1000
+    buf = ctypes.create_string_buffer(need.value)
+    assert lib.needle_tuning_info(buf, need.value, None) == 0
+    lines = buf.value.decode().strip().split("\n")
+    assert lines[0].split("\t") == ["name", "default", "current", "scope", "effect"]
+    rows = [ln.split("\t") for ln in lines[1:]]
+    assert all(len(r) == 5 and r[4] for r in rows)
+    listed = {r[0] for r in rows}
+    used = set()
+    for f in glob.glob(os.path.join(ROOT, "needle_amd", "csrc", "*")):
+        if f.endswith(("needle_tuning.cpp", "_probe.hip")):
+            continue
+        used |= set(re.findall(r'getenv\("(NEEDLE_[A-Z0-9_]+)"\)', open(f).read()))
+    assert used == listed, (sorted(used - listed), sorted(listed - used))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in listed:
+        assert "`%s`" % name in doc, name
+    # a short buffer gets a truncated, terminated copy
+    small = ctypes.create_string_buffer(16)
+    assert lib.needle_tuning_info(small, 16, None) == 0 and len(small.value) == 15
