@@ -221,8 +221,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         const uint32_t rem = len > idx0 ? len - idx0 : 0; // GUARD: chars of this row inside the tile and beyond
         const uint32_t skip = (uint32_t)cursor > idx0 ? (uint32_t)cursor - idx0 : 0; // GUARD: chars before the cursor
         int32_t last_rel = -1;                            // OP_FIND: last accepting position inside this tile
-        // ragged rows keep more values live per char: unroll less there or it spills
-        constexpr int kUnroll = GUARD ? (OP == OP_FIND ? 1 : 2) : G::kPieces;
+        // ragged rows keep more values live per char: unroll less there or it spills.  The big-table modes (compressed automaton,
+        // hot rows) are 70 .. 136 KB of ISA per instantiation this way (scripts/kernel_code_size.py) -- more than the 64 KB
+        // instruction cache a CU pair shares.  NEEDLE_BIG_ROLLED=1 keeps their piece loops rolled (23 .. 84 KB); measured on the
+        // C3-sparse walk (profiles/r04_code_diet.md): SQC_ICACHE_MISSES is ~2 .. 5 thousand of 1.8e8 requests per launch in
+        // BOTH forms -- the pipelined loop's hot part fits, the rest is never fetched -- and the rolled form is 2-3 % slower
+        // (loop overhead on the chain).  So the unrolled form stays.
+        constexpr bool BIG = NEEDLE_BIG_ROLLED && (MODE == MODE_SPARSE || MODE == MODE_HYBRID);
+        constexpr int kUnroll = BIG ? 1 : GUARD ? (OP == OP_FIND ? 1 : 2) : G::kPieces;
+        constexpr int kUnrollSplit = BIG ? 1 : G::kPieces;
         constexpr int CPP = 16 / CW; // chars per 16-byte piece
         u32x4 v = tile_piece<CHB>(tile, lane, 0);
         if (GUARD && NEEDLE_SPLIT_BOUNDARY) {
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
                 const uint32_t w[4] = {c[0], c[1], c[2], c[3]};
                 walk_piece<OP, CW, MODE, true>(wk, w, cp * CPP, rem, skip, accept_lo, st, last_rel);
             }
-#pragma unroll
+#pragma unroll kUnrollSplit
             for (int kk = 0; kk < G::kPieces; ++kk) {
                 const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
                 if (kk + 1 < G::kPieces) v = tile_piece<CHB>(tile, lane, kk + 1);

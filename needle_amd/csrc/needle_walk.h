@@ -19,6 +19,9 @@
 #ifndef NEEDLE_SPLIT_BOUNDARY
 #define NEEDLE_SPLIT_BOUNDARY 1
 #endif
+#ifndef NEEDLE_BIG_ROLLED // 1: the big-table modes' piece loops stay rolled (code size; needle_scan.h walk_tile).  Measured
+#define NEEDLE_BIG_ROLLED 0 // (profiles/r04_code_diet.md): 70 -> 23 KB per kernel, 2-3 % SLOWER, I-cache misses ~0 either way
+#endif
 #ifndef NEEDLE_PIECE_FENCE
 #define NEEDLE_PIECE_FENCE 1
 #endif

@@ -4,8 +4,9 @@ import sys, torch
 sys.path.insert(0, ".")
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-p, _, words = bench.make_pattern("c3")
-rows = bench.make_rows("c3", words, 0, n, "cuda:0")
+wl = sys.argv[2] if len(sys.argv) > 2 else "c3"  # c3 | c3s
+p, _, words = bench.make_pattern(wl)
+rows = bench.make_rows(wl, words, 0, n, "cuda:0")
 lens = (torch.arange(n, device="cuda", dtype=torch.int64) * 2654435761 % 256 + 1).to(torch.int32)
 full_lens = torch.full((n,), 256, dtype=torch.int32, device="cuda")
 for name, op in (("containedIn", p.contained_in_batch), ("find", p.find_batch)):
@@ -17,4 +18,4 @@ for name, op in (("containedIn", p.contained_in_batch), ("find", p.find_batch)):
         for _ in range(10): op(rows, l)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        print("%-12s %-14s %.3f ms" % (name, tag, ms))
+        print("%s %-12s %-14s %.3f ms" % (wl, name, tag, ms))
