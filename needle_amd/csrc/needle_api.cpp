@@ -1557,15 +1557,35 @@ static int find_all_host(const needle_pattern *p, const needle_batch_view *v, ui
     static const uint64_t kHostChunkBytes = getenv("NEEDLE_HOST_CHUNK_BYTES") ? (uint64_t)atoll(getenv("NEEDLE_HOST_CHUNK_BYTES")) : (2ull << 30);
     const uint64_t row_bytes = std::max<uint64_t>(16, (v->row_stride * v->char_width + 15) & ~(uint64_t)15) + 8 + 8ull * slots;
     const uint64_t per = std::max<uint64_t>(64, (kHostChunkBytes / row_bytes) & ~(uint64_t)63);
+    // (rows of at most 65 534 chars: an empty match at index 65 535 would read as an unfiled slot; NEEDLE_FIND_ALL_ROUNDS: the tests'
+    // cross-check of the round-per-match form goes through needle_find_all_dev)
+    static const bool rounds_forced = getenv("NEEDLE_FIND_ALL_ROUNDS") && atoi(getenv("NEEDLE_FIND_ALL_ROUNDS")) != 0;
+    const bool packed_inside = !rounds_forced && (v->lengths ? v->row_stride : v->row_len) <= 65534u; // (lengths[r] <= row_stride: checked above)
+    std::vector<uint32_t> stage;
     for (uint64_t r0 = 0; r0 < v->n_rows; r0 += per) {
         needle_batch_view c = *v;
         c.n_rows = std::min<uint64_t>(per, v->n_rows - r0);
         c.rows = (const uint8_t *)v->rows + r0 * v->row_stride * v->char_width;
         c.lengths = v->lengths ? v->lengths + r0 : nullptr;
         int m = 0;
-        rc = find_all_host_one(p, &c, slots, counts + r0, start ? start + r0 * slots : nullptr, end ? end + r0 * slots : nullptr, &m,
-                               start_end16 ? start_end16 + r0 * slots : nullptr);
-        if (rc) return rc;
+        if (!start_end16 && slots && packed_inside) {
+            // int32 results wanted, rows of at most 65 535 chars: the one-dword form on the device and over PCIe (half the result
+            // bytes both ways), opened into the caller's two arrays here on the host
+            stage.resize((size_t)c.n_rows * slots);
+            rc = find_all_host_one(p, &c, slots, counts + r0, nullptr, nullptr, &m, stage.data());
+            if (rc) return rc;
+            int32_t *so = start + r0 * slots, *eo = end + r0 * slots;
+            for (size_t i = 0; i < stage.size(); ++i) {
+                const uint32_t w = stage[i];
+                const bool none = w == 0xFFFFFFFFu; // an unfiled slot (a real match has start <= end, never 0xFFFF | 0xFFFF << 16)
+                so[i] = none ? -1 : (int32_t)(w & 0xFFFFu);
+                eo[i] = none ? -1 : (int32_t)(w >> 16);
+            }
+        } else {
+            rc = find_all_host_one(p, &c, slots, counts + r0, start ? start + r0 * slots : nullptr, end ? end + r0 * slots : nullptr, &m,
+                                   start_end16 ? start_end16 + r0 * slots : nullptr);
+            if (rc) return rc;
+        }
         if (m && more) *more = 1;
     }
     return NEEDLE_OK;

@@ -7,7 +7,7 @@ n = 2_560_000_000 // stride
 p = DFACompiler.compile(rx, "d")
 rows = torch.randint(97, 123, (n, stride), dtype=torch.uint8, device="cuda")
 rows[::3, stride // 2] = 53
-for op, name in ((p.contained_in_batch, "containedIn"), (p.find_batch, "find")):
+for op, name in ((p.contained_in_batch, "containedIn"), (p.find_batch, "find"), (p.find_packed16_batch, "find (one dword per row)")):
     for _ in range(2): r = op(rows)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -16,4 +16,4 @@ for op, name in ((p.contained_in_batch, "containedIn"), (p.find_batch, "find")):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     hits = unpack_bitmap(r[0] if isinstance(r, tuple) else r, n).mean()
-    print("%d rows x %d B  %-12s %.3f ms  %.0f GB/s  hit %.3f" % (n, stride, name, ms, rows.numel() / ms / 1e6, hits))
+    print("%d rows x %d B  %-26s %.3f ms  %.0f GB/s  hit %.3f" % (n, stride, name, ms, rows.numel() / ms / 1e6, hits))
