@@ -1296,6 +1296,16 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
         rc = get_program(p, W_FORWARDS, (int)v->char_width, 6, &fp, &n_cus);
         if (rc) return rc;
         lmode = fp != nullptr;
+        static const bool sparse_lengths = getenv("NEEDLE_FIND_ALL_LENGTHS") && atoi(getenv("NEEDLE_FIND_ALL_LENGTHS")) > 1;
+        if (!lmode && sparse_lengths && find_lengths_for(MODE_SPARSE)) {
+            // no plain LDS table holds the lengths automaton (a big dictionary): the scan kernels' compressed form of it, if there is
+            // one.  Opt-in (NEEDLE_FIND_ALL_LENGTHS=2): measured on C3-sparse (profiles/r04_find_all.md) it is no faster than hot rows +
+            // backward walks, 2.05 against 1.98 ms -- the per-lane piece walk is what costs there, not the 0.25 starts per row
+            const DevProgram *sp = nullptr;
+            rc = get_program(p, W_FORWARDS, (int)v->char_width, 7, &sp, &n_cus);
+            if (rc) return rc;
+            if (sp && sp->prog.hdr.mode == MODE_SPARSE) fp = sp, lmode = true;
+        }
         if (lmode) need_backward = false;
     }
     if (!lmode) rc = get_program(p, W_FORWARDS, (int)v->char_width, need_backward ? 5 : 4, &fp, &n_cus);

@@ -102,6 +102,9 @@ struct ProgHeader {
     // column and S_1 to the start state -- a search restarted k chars into a 16-byte piece enters the piece in S_k and needs
     // no per-char cursor guard (0: none)
     uint32_t fa_skip_lo;
+    uint32_t flat_pages; // char_width 2 table modes: 1 = every high byte has a page of its own and ptab[hi] = hi * 256 (the map is
+                         // then 64 KB and a char's column is ONE lookup at the char itself; the two-level lookup still gives
+                         // the same answer, so kernels that do not know the flag stay correct)
     uint32_t off_bpack;  // != 0: the backward automaton has <= 5 states and rides along as packed functions: 8-bit rows
                          // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)
                          // followed by its F area.  The backward walk then needs no state-dependent lookup.

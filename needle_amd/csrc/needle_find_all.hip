@@ -51,6 +51,19 @@ __device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t
     uint32_t col[CPP];
     piece_lookups<MODE, CW, false>(wk, w, 0, 0, 0, col);
     if (MODE == MODE_PACK) lds_fence();
+    if (MODE == MODE_SPARSE) {
+        // The compressed automaton (needle_device.h) has no PRE / PAD columns: chars before the lane's cursor and chars past the
+        // row's end (in_row: chars of the piece inside the row) leave the state as it is -- a lengths program's state FREEZES
+        // at the row's end and its END record names the pending length (needle_scan.h finish_rows).
+        uint32_t h = 0;
+#pragma unroll
+        for (int i = 0; i < CPP; ++i) {
+            const uint32_t ns = apply<MODE, CW>(wk, st, col[i]);
+            st = ((uint32_t)i >= skip_rel && (uint32_t)i < in_row) ? ns : st;
+            h |= (st >= accept_lo ? 1u : 0u) << i; // (flags of chars outside [skip_rel, in_row) are masked by the caller)
+        }
+        return h;
+    }
     if (CUT) {
 #pragma unroll
         for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < in_row) ? col[i] : wk.pad_e;
@@ -98,6 +111,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
     wk.table_off = a.hdr.off_table;
     wk.win_on = 0, wk.win_lo = 0, wk.win_hi = 0; // (the find-all programs are lowered without window addressing)
     wk.sp_chains = 0, wk.sp_pad_ident = 0, wk.dead_hi = 0;
+    wk.flat = (CW == 2 && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16)) ? a.hdr.flat_pages : 0u;
+    if (MODE == MODE_SPARSE) { // the scan kernels' compressed lengths program (needle_scan.h sets these up the same way)
+        wk.pad_e = wk.pre_e = a.hdr.win_lo_e;
+        wk.win_on = a.hdr.win_on, wk.win_lo = a.hdr.win_lo_e, wk.win_hi = a.hdr.win_hi_e;
+        wk.dead_hi = a.hdr.fa_dead_hi;
+        wk.sp_chains = a.hdr.sp_chains, wk.sp_pad_ident = a.hdr.sp_pad_ident;
+    }
     wk.lane4 = (uint32_t)lane * 4u; // packed mode on 8-bit rows: all 64 lane copies of F are there (no tiles in the F rows)
     wk.gtable = (const uint16_t *)(a.prog + (MODE == MODE_HYBRID ? a.hdr.off_gtable : a.hdr.off_table));
     wk.hot_last = a.hdr.hot_bytes - 2u;
@@ -213,15 +233,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             const uint32_t skip_rel = (uint32_t)cursor > p0 ? (uint32_t)cursor - p0 : 0u; // < CPP: the cursor's piece, or none
             const uint32_t st_old = st;
             uint32_t st_new = st;
-            uint32_t acc = walk_piece_fa<CW, MODE, false, LM>(wk, w, skip_rel, accept_lo, st_new);
             const uint32_t in_row = len > p0 ? len - p0 : 0u; // chars of the piece inside the row (all, if >= CPP)
+            uint32_t acc = walk_piece_fa<CW, MODE, false, LM>(wk, w, skip_rel, accept_lo, st_new, in_row);
             if (!LM) acc &= ~((1u << skip_rel) - 1u);          // an accepting start state does not count before the cursor
             acc &= in_row < (uint32_t)CPP ? (1u << in_row) - 1u : 0xFFFFFFFFu;
             acc = active ? acc : 0u;
             last = acc ? (int32_t)(p0 + 32u - (uint32_t)__builtin_clz(acc)) : last;
             st = active ? st_new : st;
             // (fa_dead_n: the "lengths" automaton's dead-with-a-match-pending states; 0 for every other program)
-            const bool ended = active && (st_new == 0u || st_new - a.hdr.fa_dead_lo < a.hdr.fa_dead_n || p0 + CPP >= len);
+            const bool died = MODE == MODE_SPARSE ? st_new <= wk.dead_hi : (st_new == 0u || st_new - a.hdr.fa_dead_lo < a.hdr.fa_dead_n);
+            const bool ended = active && (died || p0 + CPP >= len);
             pi += (active && !ended) ? 1u : 0u;
             if (__ballot(ended) == 0ull) continue;
             // ---- find() returns for the lanes of `ended` (:629-657)
@@ -242,7 +263,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                         st_end = cut ? st_fix : st_end;
                     }
                 }
-                const int32_t mlen = (int32_t)lds_u8(a.hdr.fa_len_off + st_end);
+                if (MODE == MODE_SPARSE) { // a live end state (the row ended) asks its END record for the D_L of its pending length
+                    const uint32_t e_st = sparse_end<CW>(wk, st_new, hit && st_new > wk.dead_hi, a.hdr.sp_end_col4);
+                    st_end = (e_st & 0xFFFFu) - a.hdr.sp_dead_row0;
+                }
+                const int32_t mlen = (int32_t)lds_u8(a.hdr.fa_len_off + (hit ? st_end : 0u));
                 const bool file = hit && count < cap;
                 if (hit && !file) *fa.more = 1;
                 done = done || (hit && !file);
@@ -468,6 +493,7 @@ static hipError_t launch_fa_m(const FindAllArgs &fa, int chb, int grid, int wave
     case MODE_TABLE16: return launch_fa_h<CW, MODE_TABLE16>(fa, chb, grid, waves, lds, s);
     case MODE_HYBRID: return launch_fa_h<CW, MODE_HYBRID>(fa, chb, grid, waves, lds, s);
     case MODE_GLOBAL: return launch_fa_h<CW, MODE_GLOBAL>(fa, chb, grid, waves, lds, s);
+    case MODE_SPARSE: return fa.lmode ? launch_fa_h<CW, MODE_SPARSE>(fa, chb, grid, waves, lds, s) : hipErrorInvalidValue; // (lengths programs only)
     default: return hipErrorInvalidValue; // (pair mode: the caller lowers the automaton without it)
     }
 }

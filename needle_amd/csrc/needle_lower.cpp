@@ -746,9 +746,11 @@ static Program lower_core(const RefTables &t, Which which, int char_width, size_
         p.hdr.lds_bytes = (uint32_t)p.blob.size();
     } else {
         // table modes: element size 1 (uint8 table, or the HBM-resident uint16 table) or 2 (uint16 table in LDS)
+        bool use_flat = false; // UTF-16 rows: the flat page map (below)
         auto build = [&](Mode m) {
             const uint32_t elem = (m == MODE_TABLE16) ? 2u : 1u;
             p.blob.clear();
+            p.hdr.flat_pages = 0;
             clear_window_header();
             if (win.ok && m != MODE_GLOBAL) {
                 // window addressing: no column maps; the table sits win_lo_e bytes above where the kernels' fixed offsets point
@@ -771,6 +773,16 @@ static Program lower_core(const RefTables &t, Which which, int char_width, size_
             if (char_width == 1) {
                 p.blob.assign(512, 0); // cmap16 at kLdsCmap1 = 0
                 for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, cm.cmap8[c] * elem);
+            } else if (use_flat && m != MODE_GLOBAL) {
+                // flat page map: a page per high byte, ptab[hi] = hi * 256 -- the scan / find-all kernels then read a char's column
+                // at pages[char] in ONE lookup (needle_walk.h piece_lookups); every other reader still goes through ptab
+                p.blob.assign(kLdsPages2Table + 65536, 0);
+                for (int hi = 0; hi < 256; ++hi) {
+                    put16(kLdsPtab2 + 2 * hi, (uint32_t)hi * 256u);
+                    for (int lo = 0; lo < 256; ++lo)
+                        p.blob[kLdsPages2Table + (size_t)hi * 256 + lo] = (uint8_t)(cm.pages[(size_t)cm.ptab[hi] * 256 + lo] * elem);
+                }
+                p.hdr.flat_pages = 1;
             } else {
                 p.blob.assign(kLdsPages2Table + cm.pages.size(), 0);
                 for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
@@ -795,7 +807,19 @@ static Program lower_core(const RefTables &t, Which which, int char_width, size_
         };
         const uint32_t elem = (mode == MODE_TABLE16) ? 2u : 1u;
         if (char_width == 2 && (uint32_t)n_cols * elem > 255u && !win.ok) mode = MODE_GLOBAL; // pages hold column * elem in a byte
-        build(mode);
+        // UTF-16 rows, plain LDS tables: the FLAT page map (64 KB) when the program then still leaves room for 16 waves x 64-byte tiles
+        // -- one column lookup per char instead of two dependent ones (C5w: the kernel is LDS-bound, 3.4 LDS instructions per char).
+        // NEEDLE_FLAT_MAP=0: the compact two-level map always (A/B, tests).
+        static const bool flat_on = !(getenv("NEEDLE_FLAT_MAP") && atoi(getenv("NEEDLE_FLAT_MAP")) == 0);
+        if (flat_on && char_width == 2 && !win.ok && (mode == MODE_TABLE8 || mode == MODE_TABLE16) && cm.pages.size() < 65536) {
+            use_flat = true;
+            build(mode);
+            if (p.blob.size() + 16u * 64u * 64u > 160u * 1024u || p.blob.size() > lds_table_budget) {
+                use_flat = false;
+                p.hdr.flat_pages = 0;
+            }
+        }
+        if (!use_flat) build(mode);
         bool sparse_done = false;
         if (mode != MODE_GLOBAL && p.blob.size() > lds_table_budget && !no_pair) { // (ml: the scan kernels' lengths form too)
             // Too big for a dense table in LDS.  First choice: the compressed whole-automaton form (MODE_SPARSE, above).

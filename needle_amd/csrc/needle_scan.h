@@ -79,6 +79,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_hi : 0u; // (the D_L states follow the sink: needle_device.h)
     wk.sp_chains = a.hdr.sp_chains;
     wk.sp_pad_ident = a.hdr.sp_pad_ident;
+    wk.flat = (CW == 2 && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16)) ? a.hdr.flat_pages : 0u;
     // (window addressing: column offsets are not rebased -- wraps are fine in 32-bit address math; the compressed form carries
     // the bias inside its image)
     wk.table_off = a.hdr.off_table - (MODE == MODE_SPARSE ? 0u : a.hdr.win_lo_e);

@@ -18,7 +18,7 @@ const Switch kSwitches[] = {
     {"NEEDLE_FIND_LENGTHS", "1", "layout", "find() by the lengths automaton (start = end - length, no backward walk): 0 never (forward + backward walks), 1 where the ordinary program is an LDS table, 2 also instead of a pair table"},
     {"NEEDLE_FIND_LENGTHS_SPARSE", "1", "layout", "0: compressed-form automata keep the two walks"},
     {"NEEDLE_FIND_LENGTHS_PAIR", "1", "layout", "0: pair-table automata keep the two walks"},
-    {"NEEDLE_FIND_ALL_LENGTHS", "1", "layout", "0: find-all reports starts by backward walks instead of the lengths automaton"},
+    {"NEEDLE_FIND_ALL_LENGTHS", "1", "layout", "find-all's starts: 0 by backward walks, 1 by the lengths automaton where it fits the LDS as a plain table, 2 also in its compressed form (big dictionaries; measured: no faster)"},
     {"NEEDLE_FIND_ALL_DEFER", "1", "layout", "0: find-all (two-walk form) finds each start as the match is found instead of deferring them to the row's end"},
     {"NEEDLE_FIND_ALL_ROUNDS", "0", "layout", "1: find-all as rounds of needle_find_next_dev (one pass over the batch per match rank) instead of the one-pass kernel"},
     {"NEEDLE_FIND_ALL_SHAPE", "(by LDS footprint)", "layout", "\"<waves>x<tile bytes>\" workgroup shape of the find-all kernel"},
@@ -26,6 +26,7 @@ const Switch kSwitches[] = {
     {"NEEDLE_SPARSE_ROOM", "98304", "size", "LDS bytes the compressed form may take"},
     {"NEEDLE_HYBRID", "1", "layout", "0: no hot-rows form either: plain HBM table"},
     {"NEEDLE_WINDOW", "1", "layout", "0: column-map lookups instead of window addressing (clamped char = column offset)"},
+    {"NEEDLE_FLAT_MAP", "1", "layout", "0: UTF-16 rows of LDS-table automata always use the compact two-level page map instead of the flat 64 KB one (one column lookup per char)"},
     {"NEEDLE_PAIR_MAX_BYTES", "98304", "size", "largest pair table ([state][col][col] uint16, two chars per lookup); 0: never"},
     {"NEEDLE_MAX_PROG_LDS", "(device limit)", "size", "LDS bytes an automaton may take (tests lower it to force the HBM-table mode)"},
     {"NEEDLE_SHAPE", "(by LDS footprint)", "layout", "\"<waves>x<tile bytes>\" workgroup shape of the tiled scan kernel"},

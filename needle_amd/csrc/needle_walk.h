@@ -150,6 +150,7 @@ struct Walk {
                             // dead-with-a-match-pending states D_L, needle_lower.h)
     uint32_t sp_chains;     // MODE_SPARSE: some state has more than one exception record (wave-uniform)
     uint32_t sp_pad_ident;  // MODE_SPARSE: PAD is the identity (matches / containedIn) rather than the way to the sink
+    uint32_t flat = 0;      // UTF-16 table modes: the page map is flat (ProgHeader::flat_pages): column = pages[char], no ptab lookup
 };
 
 template <int CW>
@@ -332,6 +333,13 @@ __device__ __forceinline__ void piece_lookups(const Walk &wk, const uint32_t (&w
         } else {
 #define NEEDLE_PG(D, K) pg[(D) * 2 + (K)] = lds_u16(shl_byte<(2 * (K) + 1) & 3>(w[D], 1) + kLdsPtab2);
 #define NEEDLE_CE(D, K) col[(D) * 2 + (K)] = lds_u8(or_byte<(2 * (K)) & 3>(pg[(D) * 2 + (K)], w[D]) + kLdsPages2Table);
+            if (wk.flat) { // wave-uniform: a 64 KB map indexed by the char itself -- one lookup per char, no fence between two levels
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    col[d * 2 + 0] = lds_u8(shl_word<0>(w[d], 0) + kLdsPages2Table);
+                    col[d * 2 + 1] = lds_u8(shl_word<1>(w[d], 0) + kLdsPages2Table);
+                }
+            } else {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 NEEDLE_PG(d, 0)
@@ -342,6 +350,7 @@ __device__ __forceinline__ void piece_lookups(const Walk &wk, const uint32_t (&w
             for (int d = 0; d < 4; ++d) {
                 NEEDLE_CE(d, 0)
                 NEEDLE_CE(d, 1)
+            }
             }
 #undef NEEDLE_PG
 #undef NEEDLE_CE

@@ -155,6 +155,17 @@ def test_c5w_multi_class_bmp_regex_utf16(ragged):
 
 
 @pytest.mark.gpu
+def test_c5w_with_the_compact_two_level_page_map():
+    """The same C5w checks with NEEDLE_FLAT_MAP=0 (read once per process: a child): ptab -> page -> column, 128-byte tiles."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_configs.py", "-x", "-q", "-m", "gpu", "-k", "c5w_multi_class"],
+                       env=dict(os.environ, NEEDLE_FLAT_MAP="0"), capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_matches_txt_rows_through_gpu_matcher():
     doc = json.load(open(os.path.join(GOLDEN, "matches.json")))
     from needle_amd.pattern import DFACompiler

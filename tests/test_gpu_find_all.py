@@ -68,16 +68,20 @@ print("FIND-ALL-OK")
                                       ({"NEEDLE_FIND_ALL_ROUNDS": "1"}, 2),
                                       ({"NEEDLE_MAX_PROG_LDS": "4096", "NEEDLE_HYBRID": "0"}, 3),
                                       ({"NEEDLE_MAX_PROG_LDS": "4096"}, 5), ({"NEEDLE_MAX_PROG_LDS": "20000", "NEEDLE_SPARSE": "0"}, 5),
+                                      ({"NEEDLE_MAX_PROG_LDS": "20000", "NEEDLE_FIND_ALL_LENGTHS": "2"}, 6),
+                                      ({"NEEDLE_MAX_PROG_LDS": "12000", "NEEDLE_WINDOW": "0", "NEEDLE_FIND_ALL_LENGTHS": "2"}, 6),
                                       ({"NEEDLE_MAX_PROG_LDS": "20000", "NEEDLE_FIND_ALL_ROUNDS": "1"}, 6),
                                       ({"NEEDLE_MAX_PROG_LDS": "12000", "NEEDLE_FIND_ALL_ROUNDS": "1", "NEEDLE_WINDOW": "0"}, 6)],
                          ids=["one-pass-lengths", "one-pass-backward-walks", "starts-at-once", "rounds", "hbm-table", "hot-rows-4k", "hot-rows-20k",
+                              "one-pass-compressed-lengths", "one-pass-compressed-lengths-cmap",
                               "rounds-compressed-automaton", "rounds-compressed-automaton-cmap"])
 def test_keyword_dictionary_every_match(env, mode):
     """A 300-keyword union (779 states, uint16 table) over 3000 rows of 256 chars: one to two matches per row, up to 8.
     Children: the one-pass kernel with start = end - the length its end state remembers (default for such a dictionary:
     needle_lower.h, MatchLengths), with the starts found by indexBackwards group by group or match by match, the round-per-match form,
-    and the automaton forced out of the LDS (whole table in HBM; hot rows in LDS + HBM table; the compressed automaton, whose
-    guarded kernels then carry the per-row cursors of the round-per-match form)."""
+    and the automaton forced out of the LDS (whole table in HBM; hot rows in LDS + HBM table; the compressed automaton -- in the
+    one-pass kernel as the compressed LENGTHS program, window addressing or column maps, and in the round-per-match form, whose
+    guarded kernels then carry the per-row cursors)."""
     r = subprocess.run([sys.executable, "-c", DICTIONARY, str(mode)], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
     assert "FIND-ALL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
