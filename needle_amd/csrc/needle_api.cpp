@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -35,7 +36,7 @@ hipError_t launch_dict(int op, const ScanArgs &a, int n_cus, hipStream_t stream)
 // needle_ngram.hip: containedIn / find behind the n-gram candidate filter
 bool ngram_shape_ok(const ScanArgs &a);
 size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng);
-hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, int n_cus, hipStream_t stream);
+hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream);
 int ngram_level(); // needle_lower.cpp (NEEDLE_PREFILTER)
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
@@ -122,6 +123,19 @@ struct DevProgram {
     Program prog;
     uint8_t *d_blob = nullptr;
     uint32_t *d_ng = nullptr; // the n-gram filter's bitmap (prog.ng.p.on)
+    // Flood watch of the n-gram filter kernel.  Text that passes the filter almost everywhere (built from the dictionary's own
+    // keyword tails: one automaton run per window) makes that kernel several times SLOWER than the ordinary scan (measured:
+    // 5.3 against 1.13 ms on the C3-sparse dictionary, scripts/r4_ngram_worstcase.py).  Every filter launch adds its candidates
+    // and KiB of text to d_ng_stats; the pair is copied to the pinned h_ng_stats behind the kernel, on its stream.  The NEXT call
+    // reads it without waiting: above 16 candidates per KiB (the break-even; the bench text has 3.3) the filter is suspended for
+    // the program's next 32 calls, doubling up to 1024 while the text stays like that.  Answers are the same either way.
+    uint32_t *d_ng_stats = nullptr;
+    volatile uint32_t *h_ng_stats = nullptr;
+    mutable std::atomic<int> ng_suspend{0}, ng_backoff{32};
+    DevProgram() = default;
+    DevProgram(DevProgram &&o) noexcept : prog(std::move(o.prog)), d_blob(o.d_blob), d_ng(o.d_ng), d_ng_stats(o.d_ng_stats), h_ng_stats(o.h_ng_stats) {
+        o.d_blob = nullptr, o.d_ng = nullptr, o.d_ng_stats = nullptr, o.h_ng_stats = nullptr;
+    }
 };
 
 struct needle_pattern {
@@ -142,6 +156,8 @@ struct needle_pattern {
         for (auto &kv : cache) {
             if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
             if (kv.second.d_ng) (void)hipFree(kv.second.d_ng);
+            if (kv.second.d_ng_stats) (void)hipFree(kv.second.d_ng_stats);
+            if (kv.second.h_ng_stats) (void)hipHostFree((void *)kv.second.h_ng_stats);
         }
     }
 };
@@ -203,11 +219,16 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
             const size_t nb = dp.prog.ng.bitmap.size() * 4;
             hipError_t ce = hipMalloc((void **)&dp.d_ng, nb);
             if (ce == hipSuccess) ce = hipMemcpy(dp.d_ng, dp.prog.ng.bitmap.data(), nb, hipMemcpyHostToDevice);
+            if (ce == hipSuccess) ce = hipMalloc((void **)&dp.d_ng_stats, 8);
+            if (ce == hipSuccess) ce = hipMemset(dp.d_ng_stats, 0, 8);
+            if (ce == hipSuccess) ce = hipHostMalloc((void **)&dp.h_ng_stats, 8, hipHostMallocDefault);
             if (ce != hipSuccess) {
                 (void)hipFree(dp.d_blob);
                 if (dp.d_ng) (void)hipFree(dp.d_ng);
+                if (dp.d_ng_stats) (void)hipFree(dp.d_ng_stats);
                 return hip_fail(ce, "hipMalloc/hipMemcpy(n-gram bitmap)");
             }
+            dp.h_ng_stats[0] = dp.h_ng_stats[1] = 0;
         }
         it = p->cache.emplace(key, std::move(dp)).first;
     }
@@ -561,8 +582,28 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // (needle_ngram_host.cpp), on containedIn() and on find() whose start is end - length (lengths programs, one-length patterns).
     if (fp->d_ng && fp->prog.ng.p.on && ngram_level() > 0 && v->char_width == 1 && op != OP_MATCHES && !skip_backward &&
         (op == OP_CONTAINED_IN || lengths_form || a.fixed_len >= 0) && ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, fp->prog.ng.p)) {
-        HIP_TRY(launch_ngram(op, a, fp->prog.ng.p, fp->d_ng, n_cus, (hipStream_t)stream));
-        return NEEDLE_OK;
+        // flood watch (DevProgram): what the last completed filter launch of this program saw
+        const uint32_t seen_cand = fp->h_ng_stats[0], seen_kib = fp->h_ng_stats[1];
+        if (seen_kib >= 1024u) {
+            fp->h_ng_stats[1] = 0;
+            if (seen_cand > 16u * (uint64_t)seen_kib) {
+                const int b = fp->ng_backoff.load();
+                fp->ng_suspend.store(b);
+                fp->ng_backoff.store(b < 1024 ? 2 * b : 1024);
+            } else {
+                fp->ng_backoff.store(32);
+            }
+        }
+        static const bool watch_on = !(getenv("NEEDLE_PREFILTER_WATCH") && atoi(getenv("NEEDLE_PREFILTER_WATCH")) == 0);
+        if (!watch_on || fp->ng_suspend.load() <= 0) {
+            HIP_TRY(launch_ngram(op, a, fp->prog.ng.p, fp->d_ng, fp->d_ng_stats, n_cus, (hipStream_t)stream));
+            // (behind the kernel on its stream; the host never waits for it.  Concurrent launches on other streams may mix their counts:
+            // the watch is a heuristic, the answers do not depend on it)
+            HIP_TRY(hipMemcpyAsync((void *)fp->h_ng_stats, fp->d_ng_stats, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+            HIP_TRY(hipMemsetAsync(fp->d_ng_stats, 0, 8, (hipStream_t)stream));
+            return NEEDLE_OK;
+        }
+        fp->ng_suspend.fetch_sub(1);
     }
     HIP_TRY(launch_scan(op, (int)v->char_width, a, n_cus, (hipStream_t)stream));
     return NEEDLE_OK;

@@ -26,6 +26,7 @@ struct NgramArgs {
     NgramParams ng;
     const uint32_t *ng_bitmap;
     NgramLayout lay;        // where the bitmap and the waves' queues sit in LDS (ngram_layout)
+    uint32_t *stats;        // optional: [0] += candidates, [1] += KiB units of text seen by this launch
     uint32_t dbg;           // measurement builds (-DNEEDLE_TUNING) only: NEEDLE_NG_DBG -- 1: candidates are dropped, 2: text gathered but
                             // no walk, 3: walk on zeros (no gather), +16: runs start as soon as 32 candidates wait; 0 in the product
     uint32_t stride_log2;   // stride_bytes is a power of two (else 0xFFFFFFFF)
@@ -120,11 +121,86 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         pf_advance();
     }
 
+    // Run the automaton for one row per lane from the start state: chars [r, ..) of row `row` of group grp, looking for a FIRST accept
+    // at indexes qn .. lim0 - 1 (after it the walk runs on until the automaton dies: the reference's lastMatch), and report to the
+    // row's slot.  A candidate: r = K chars ahead of the window's end qn, lim0 = qn + S - 1.  A whole row (the flood fallback below):
+    // r = qn = 0, lim0 = the row's length.  Text comes from memory (L2, mostly) 16 bytes at a time: the first piece wherever r is,
+    // the following ones aligned (stride % 16 == 0: inside the row), chars already walked skipped.
+    auto run_rows = [&](uint64_t grp, uint32_t row, bool valid, uint32_t qn, uint32_t r, uint32_t lim0) __attribute__((always_inline)) {
+        const uint64_t grow = (grp << 6) + row;
+        uint32_t len = a.row_len;
+        if (a.lengths) len = valid ? a.lengths[grow] : 0u;
+        valid = valid && qn <= len;
+        const uint64_t rowabs = grow * a.stride_bytes;
+        {
+            const uint64_t room = a.total_bytes - 16u - (valid ? rowabs : 0ull); // keep the 16-byte read inside the batch: an
+            r = (uint64_t)r < room ? r : (uint32_t)room;                          // EARLIER restart is as good
+        }
+        const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull);
+        uint32_t lim = lim0 < len ? lim0 : len;
+        uint32_t st = start_state, last = 0, first = 0;
+        bool found = false, over = !valid;
+        uint32_t base = valid ? r : 0u, cur = base; // the piece being walked starts at `base`; chars before `cur` are done
+        auto step = [&](uint32_t colv, uint32_t pos) __attribute__((always_inline)) {
+            const bool go = !over && pos >= cur && pos < lim;
+            const uint32_t ns = apply<MODE, 1>(wk, st, colv);
+            st = go ? ns : st;
+            const bool acc = go && st >= accept_lo && pos + 1u >= qn;
+            if (OP == OP_FIND) {
+                last = acc ? pos + 1u : last;
+                first = (acc && !found) ? pos + 1u : first;
+                lim = acc ? len : lim; // after the first accept the walk runs on until the automaton dies
+                found = found || acc;
+                over = over || (go && st <= wk.dead_hi);
+            } else {
+                found = found || acc;
+                over = over || acc;
+            }
+        };
+        for (;;) {
+            u32x4 tx = {0, 0, 0, 0};
+            if (dbg != 3u) tx = *(const u32x4_u *)(rowp + base);
+            if (dbg == 2u) over = over || tx[0] != 0x12345678u; // (the text is waited for, the walk is not taken)
+            const uint32_t w[4] = {tx[0], tx[1], tx[2], tx[3]};
+            uint32_t col[16];
+            piece_lookups<MODE, 1, false>(wk, w, 0u, 0u, 0u, col);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                step(col[k], base + (uint32_t)k);
+                if ((k >= 7 || (k & 3) == 3) && k != 15 && __ballot(!over && base + (uint32_t)k + 1u < lim) == 0ull) break; // (K + S - 1 = 9 or 10 steps is the usual run)
+            }
+            cur = base + 16u;
+            if (__ballot(!over && cur < lim) == 0ull) break; // (rare for a candidate: a match that runs past its 16 bytes)
+            base = cur & ~15u;
+        }
+        if (OP == OP_FIND) {
+            int32_t s;
+            if (a.fixed_len >= 0) {
+                s = (int32_t)last - a.fixed_len; // :640-646
+            } else {
+                uint32_t pidx = st;
+                if (MODE == MODE_SPARSE) { // (needle_scan.h finish_rows: a live stop state asks its END record)
+                    const uint32_t st_end = sparse_end<1>(wk, st, found && st > wk.dead_hi, a.hdr.sp_end_col4);
+                    pidx = (st_end & 0xFFFFu) - a.hdr.sp_dead_row0;
+                }
+                s = (int32_t)last - (int32_t)lds_u8(a.hdr.fa_len_off + (found ? pidx : 0u));
+            }
+            if (found) {
+                const uint64_t key = (uint64_t)first << 32 | (uint64_t)last << 16 | (uint64_t)(uint32_t)s;
+                __hip_atomic_fetch_min((lds_u64_t *)(uintptr_t)(sbase + row * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        } else if (found) {
+            __hip_atomic_fetch_or((lds_u64_t *)(uintptr_t)sbase, 1ull << row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    };
+
     uint32_t qhead = 0, qtail = 0; // wave-uniform
+    uint32_t n_cand = 0, n_units = 0; // what this wave saw: candidates, KiB units of text (-> A.stats: the host's flood watch)
     for (; g < n_groups; g += wave_cnt) {
         const uint32_t rows_in = (g + 1 < n_groups) ? 64u : (uint32_t)(a.n_rows - (g << 6));
         const uint32_t gbytes = rows_in * stride;
         const uint32_t units = units_of(g);
+        n_units += units;
         // ---- the group's result slots
         if (OP == OP_FIND) *(lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u) = ~0ull;
         else if (lane == 0) *(lds_u64_t *)(uintptr_t)sbase = 0ull;
@@ -161,6 +237,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
                     if (has) *(lds_u32_t *)(uintptr_t)(qbase + (((qtail + rank) & (kNgQueue - 1u)) << 2)) = e;
                     qtail += (uint32_t)__builtin_popcountll(any);
+                    n_cand += (uint32_t)__builtin_popcountll(any);
                     log &= log - 1u;
                 }
                 const bool more = __ballot(log != 0u) != 0ull;
@@ -182,83 +259,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                         if (em1 - row * stride >= stride) ++row;
                     }
                     const uint32_t qn = e - row * stride; // window [qn - 4, qn) of the row
-                    const uint64_t grow = (g << 6) + row;
-                    bool valid = act && row < rows_in && qn >= 4u;
-                    uint32_t len = a.row_len;
-                    if (a.lengths) len = valid ? a.lengths[grow] : 0u;
-                    valid = valid && qn <= len;
-                    const uint64_t rowabs = grow * a.stride_bytes;
-                    uint32_t r = qn > K ? qn - K : 0u; // the walk restarts here, in the start state
-                    {
-                        const uint64_t room = a.total_bytes - 16u - (valid ? rowabs : 0ull); // keep the 16-byte read inside the batch: an
-                        r = (uint64_t)r < room ? r : (uint32_t)room;                          // EARLIER restart is as good
-                    }
-                    const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull);
-                    u32x4 tx = {0, 0, 0, 0};
-                    if (dbg != 3u) tx = *(const u32x4_u *)(rowp + (valid ? r : 0u));
-                    const uint32_t w[4] = {tx[0], tx[1], tx[2], tx[3]};
-                    uint32_t col[16];
-                    piece_lookups<MODE, 1, false>(wk, w, 0u, 0u, 0u, col);
-                    uint32_t lim = qn + (uint32_t)S - 1u; // a FIRST accept is looked for at indexes qn .. qn + S - 1
-                    lim = lim < len ? lim : len;
-                    uint32_t st = start_state, last = 0, first = 0;
-                    bool found = false, over = !valid;
-                    if (dbg == 2u) over = over || tx[0] != 0x12345678u; // (the text is waited for, the walk is not taken)
-                    auto step = [&](uint32_t colv, uint32_t pos) __attribute__((always_inline)) {
-                        const bool go = !over && pos < lim;
-                        const uint32_t ns = apply<MODE, 1>(wk, st, colv);
-                        st = go ? ns : st;
-                        const bool acc = go && st >= accept_lo && pos + 1u >= qn;
-                        if (OP == OP_FIND) {
-                            last = acc ? pos + 1u : last;
-                            first = (acc && !found) ? pos + 1u : first;
-                            lim = acc ? len : lim; // after the first accept the walk runs on until the automaton dies
-                            found = found || acc;
-                            over = over || (go && st <= wk.dead_hi);
-                        } else {
-                            found = found || acc;
-                            over = over || acc;
-                        }
-                    };
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        step(col[k], r + (uint32_t)k);
-                        if ((k >= 7 || (k & 3) == 3) && k != 15 && __ballot(!over && r + (uint32_t)k + 1u < lim) == 0ull) break; // (K + S - 1 = 9 or 10 steps is the usual run)
-                    }
-                    // (rare) a match that runs past the 16 bytes: one char at a time from memory
-                    uint32_t pos = r + 16u;
-                    while (__ballot(!over && pos < lim) != 0ull) {
-                        uint32_t c = 0;
-                        if (!over && pos < lim) c = rowp[pos];
-                        uint32_t colv;
-                        if (wk.win_on) {
-                            colv = c << elem_shift<MODE>();
-                            colv = colv < wk.win_lo ? wk.win_lo : (colv > wk.win_hi ? wk.win_hi : colv);
-                        } else {
-                            colv = lds_u16((c << 1) + kLdsCmap1);
-                        }
-                        step(colv, pos);
-                        ++pos;
-                    }
-                    if (OP == OP_FIND) {
-                        int32_t s;
-                        if (a.fixed_len >= 0) {
-                            s = (int32_t)last - a.fixed_len; // :640-646
-                        } else {
-                            uint32_t pidx = st;
-                            if (MODE == MODE_SPARSE) { // (needle_scan.h finish_rows: a live stop state asks its END record)
-                                const uint32_t st_end = sparse_end<1>(wk, st, found && st > wk.dead_hi, a.hdr.sp_end_col4);
-                                pidx = (st_end & 0xFFFFu) - a.hdr.sp_dead_row0;
-                            }
-                            s = (int32_t)last - (int32_t)lds_u8(a.hdr.fa_len_off + (found ? pidx : 0u));
-                        }
-                        if (found) {
-                            const uint64_t key = (uint64_t)first << 32 | (uint64_t)last << 16 | (uint64_t)(uint32_t)s;
-                            __hip_atomic_fetch_min((lds_u64_t *)(uintptr_t)(sbase + row * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        }
-                    } else if (found) {
-                        __hip_atomic_fetch_or((lds_u64_t *)(uintptr_t)sbase, 1ull << row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    }
+                    run_rows(g, row, act && row < rows_in && qn >= 4u, qn, qn > K ? qn - K : 0u, qn + (uint32_t)S - 1u);
                 }
                 if (!more) break;
             }
@@ -283,6 +284,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             a.bitmap[g] = *(const lds_u64_t *)(uintptr_t)sbase;
         }
         asm volatile("" ::: "memory");
+    }
+    // what the host's flood watch reads (needle_api.cpp): candidates and KiB of text of this launch
+    if (A.stats && lane == 0) {
+        atomicAdd(&A.stats[0], n_cand);
+        atomicAdd(&A.stats[1], n_units);
     }
 }
 
@@ -322,11 +328,12 @@ bool ngram_shape_ok(const ScanArgs &a) {
            a.row_len <= 65535u;
 }
 
-hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, int n_cus, hipStream_t stream) {
+hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream) {
     NgramArgs A;
     A.a = a;
     A.ng = ng;
     A.ng_bitmap = d_bitmap;
+    A.stats = d_stats;
     const uint32_t stride = (uint32_t)a.stride_bytes;
     A.stride_log2 = 0xFFFFFFFFu;
     if ((stride & (stride - 1u)) == 0u) A.stride_log2 = (uint32_t)__builtin_ctz(stride);

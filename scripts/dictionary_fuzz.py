@@ -22,6 +22,12 @@ while len(words) < n_kw:
     if r < 0.15 and len(w) > lo: words.add(w[:rng.randint(max(2, lo - 1), len(w) - 1)])      # a proper prefix
     elif r < 0.25 and len(w) > 3: words.add(w[rng.randint(1, len(w) - 2):])                    # a proper suffix
     elif r < 0.30: words.add(w + "".join(rng.choice(alpha) for _ in range(rng.randint(1, 3))))  # an extension
+import os
+fuzz_min = int(os.environ.get("FUZZ_MIN_LEN", "0"))  # keep only keywords of at least this many chars (5: the n-gram filter's stride 2
+if fuzz_min:                                            # becomes possible, 7: stride 4) and plant near misses (keyword tails) as well
+    words = {w for w in words if len(w) >= fuzz_min}
+    while len(words) < n_kw // 2:
+        words.add("".join(rng.choice(alpha) for _ in range(rng.randint(fuzz_min, fuzz_min + 3))))
 words = sorted(words)
 rng.shuffle(words)
 rx = "|".join(words)
@@ -39,6 +45,11 @@ for r in range(0, n, 3):  # plant: anywhere, at the very end, cut by the end
     elif k == 3 and len(w) > 1: rows[r, width - len(w) + 1:] = w[:-1]
     else:
         at = int(nr.integers(0, width - len(w) + 1)); rows[r, at:at + len(w)] = w
+if fuzz_min:  # near misses: a keyword's tail behind a wrong first char (passes the filter, matches nothing -- unless it does)
+    for r in range(1, n, 3):
+        w = np.frombuffer(words[nr.integers(len(words))].encode(), dtype=np.uint8).copy()
+        w[0] = ord(alpha[nr.integers(len(alpha))])
+        at = int(nr.integers(0, width - len(w) + 1)); rows[r, at:at + len(w)] = w
 lens = nr.integers(0, width + 1, n).astype(np.uint32)
 t = torch.from_numpy(rows).cuda()
 tl = torch.from_numpy(lens.astype(np.int32)).cuda()
@@ -55,8 +66,10 @@ for l, dl in ((None, None), (lens, tl)):
         if len(a) >= 2: assert nw[i] and (ns[i], ne[i]) == a[1], ("second find", seed, i)
         else: assert not nw[i], ("second find", seed, i)
     assert (unpack_bitmap(p.contained_in_batch(t, dl), n) == o.batch_contained_in(rows, l, threads=8)).all(), ("containedIn", seed)
-print("DICT-OK seed %d: %d keywords over %d letters, %d states, mode %d, lengths form %d, %d of %d rows match" % (
-    seed, len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"], int(of.sum()), n))
+pf = p.prefilter_info("forwards")
+print("DICT-OK seed %d: %d keywords over %d letters, %d states, mode %d, lengths form %d, n-gram filter %s, %d of %d rows match" % (
+    seed, len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"],
+    ("stride %d run-up %d" % (pf["stride"], pf["warm"])) if pf["on"] and width % 64 == 0 else "off", int(of.sum()), n))
 '''
 if __name__ == "__main__":
     seed0, cnt = int(sys.argv[1]), int(sys.argv[2])

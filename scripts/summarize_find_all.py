@@ -5,11 +5,13 @@ import json
 import os
 import re
 import shutil
+import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = sys.argv[1] if len(sys.argv) > 1 else "04"
 src = os.path.join(root, "gpurun_out", "prof_fa")
 out = []
-out.append("# needle::find_all_kernel, round 3 (`scripts/profile_find_all.sh`: `rocprofv3 --kernel-trace --stats -- python scripts/find_all_probe.py <workload> 10000000 32`)\n")
+out.append("# needle::find_all_kernel, round %d (`scripts/profile_find_all.sh`: `rocprofv3 --kernel-trace --stats -- python scripts/find_all_probe.py <workload> 10000000 32`)\n" % int(RND))
 out.append("Every non-overlapping match of every row (the reference's repeated `Matcher.find()`), 10⁷ × 256-char rows resident in HBM, 32 result slots per row, "
            "outputs preallocated.  `probe ms` = host-timed call + synchronise (best of 4); `kernel µs` = rocprofv3 average of the kernel; "
            "`rounds ms` = the round-per-match form on the same rows (`NEEDLE_FIND_ALL_ROUNDS=1`: one scan of the batch and one stream synchronisation per round).\n")
@@ -24,14 +26,14 @@ for w in ("c3", "c2", "c5", "c3s"):
         if "find_all_kernel" in r["Name"]:
             k_avg += float(r["AverageNs"]) / 1e3
             calls = int(r["Calls"]) if calls is None else calls
-    shutil.copy(stats, os.path.join(root, "profiles", "r03_find_all_%s_kernel_stats.csv" % w))
+    shutil.copy(stats, os.path.join(root, "profiles", "r%s_find_all_%s_kernel_stats.csv" % (RND, w)))
     out.append("| %s | %d | %d | %.3f | %.1f (%d) | %.1f | %.0f | %.2f | %.1fx | %.2f | %.2f |" % (
         w, one["matches"], one["max_per_row"], one["ms"], k_avg, calls, one["matches"] / (k_avg * 1e-6) / 1e9,
         one["rows"] * 256 * (2 if w == "c5" else 1) / (k_avg * 1e-6) / 1e9, rnd["ms"], rnd["ms"] / one["ms"], one.get("count_ms", 0), one.get("csr_ms", 0)))
 # the dictionary with one dword per match (needle_find_all_packed16_dev)
 pk = json.loads(open(os.path.join(src, "c3_packed.json")).read().strip().splitlines()[-1])
 pk_k = sum(float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(src, "c3_packed", "t_kernel_stats.csv"))) if "find_all_kernel" in r["Name"])
-shutil.copy(os.path.join(src, "c3_packed", "t_kernel_stats.csv"), os.path.join(root, "profiles", "r03_find_all_c3_packed16_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "c3_packed", "t_kernel_stats.csv"), os.path.join(root, "profiles", "r%s_find_all_c3_packed16_kernel_stats.csv" % RND))
 pk_t = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     pk_t[c] = float(open(os.path.join(src, "packed_%s.txt" % c)).read().split()[1])
@@ -74,12 +76,15 @@ out.append("| VALU instructions per char-wave | %.1f (scan kernel, C3 find: 3.8)
 out.append("| LDS instructions per char-wave | %.2f |" % (pmc["SQ_INSTS_LDS"] / cw))
 out.append("| HBM bytes per launch / (rows + 4 B per row + 8 B per match) | %.2f |" % (
     (traffic["FETCH_SIZE"] * 2048 + traffic["WRITE_SIZE"] * 1024) / (1e7 * 260 + 8 * 46586444)))
-out.append("\nRound 3: for the dictionary (a keyword union) the program is the refined \"lengths\" automaton (DESIGN.md s3): the state a search ends in says how long "
+out.append("\nSince round 3: for the dictionary (a keyword union) the program is the refined \"lengths\" automaton (DESIGN.md s3): the state a search ends in says how long "
            "its match was, start = end - pend[state] -- no starts phase, no backward walks, and FETCH_SIZE is the batch exactly once (round 2: 6.2 GB).  The walk kernel is "
            "VALU-issue bound, not HBM bound: an iteration walks a whole 16-byte piece for every lane under the cursor guard and a tile takes as many iterations as its "
            "busiest lane.  The written bytes are several times the results, and exactly the slot arrays: with 32 slots a row's block is one 128-byte line in each of the two "
            "arrays, almost every row has a match, and a line leaves the L2 whole -- 2 x 128 B x 10^7 rows = 2.56 GB whatever the order of the stores (each line is "
            "written once: staging the stores in LDS would not change the count).  The packed form above halves it -- one array, one line per row.  c2 / c5 / c3s: patterns with unbounded match lengths, or a refined "
-           "automaton that does not fit the LDS as a plain table (c3s), keep indexBackwards at the end of every 64-row group.")
-open(os.path.join(root, "profiles", "r03_find_all.md"), "w").write("\n".join(out) + "\n")
+           "automaton that does not fit the LDS as a plain table (c3s), keep indexBackwards at the end of every 64-row group.  Round 4: the kernel is unchanged; the compressed lengths program "
+           "was built into it for c3s (`NEEDLE_FIND_ALL_LENGTHS=2`, parity-tested) and measured no faster than hot rows + backward walks (2.05 against 1.98 ms: "
+           "`profiles/r04_find_all_c3s_ab.log`) -- what a find-all costs there is the per-lane piece walk, not the 0.25 starts per row; host batches now cross PCIe in "
+           "the one-dword form (`needle_find_all_host`).")
+open(os.path.join(root, "profiles", "r%s_find_all.md" % RND), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

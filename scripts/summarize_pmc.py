@@ -22,15 +22,29 @@ def summ(d):
     return out
 
 
-RND = "03"
-sets = [("c3s find: hot rows in LDS + HBM table (round 2's mode; NEEDLE_SPARSE=0 NEEDLE_WINDOW=0)", "pmc_c3s_r3hybrid"),
-        ("c3s find: compressed automaton in LDS, column-map lookups, backward walks (NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS_SPARSE=0)", "pmc_c3s_r3sparse"),
-        ("c3s find: compressed automaton in LDS + window addressing, backward walks (NEEDLE_FIND_LENGTHS_SPARSE=0)", "pmc_c3s_r3sparsewin"),
-        ("c3s find: + the lengths automaton in the compressed form, no backward walk (shipped)", "pmc_c3s_r3sparselen"),
-        ("c3 find: LDS table u16, column-map lookups, backward walks (NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS=0)", "pmc_c3_r3cmap"),
-        ("c3 find: LDS table u16 + window addressing, backward walks (NEEDLE_FIND_LENGTHS=0)", "pmc_c3_r3window"),
-        ("c3 find: + the lengths automaton, no backward walk (shipped)", "pmc_c3_r3lengths"),
-        ("c5 find (packed functions, unchanged kernel)", "pmc_c5_r3")]
+import sys
+RND = sys.argv[1] if len(sys.argv) > 1 else "04"
+SETS = {
+    "03": [("c3s find: hot rows in LDS + HBM table (round 2's mode; NEEDLE_SPARSE=0 NEEDLE_WINDOW=0)", "pmc_c3s_r3hybrid"),
+           ("c3s find: compressed automaton in LDS, column-map lookups, backward walks (NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS_SPARSE=0)", "pmc_c3s_r3sparse"),
+           ("c3s find: compressed automaton in LDS + window addressing, backward walks (NEEDLE_FIND_LENGTHS_SPARSE=0)", "pmc_c3s_r3sparsewin"),
+           ("c3s find: + the lengths automaton in the compressed form, no backward walk (shipped)", "pmc_c3s_r3sparselen"),
+           ("c3 find: LDS table u16, column-map lookups, backward walks (NEEDLE_WINDOW=0 NEEDLE_FIND_LENGTHS=0)", "pmc_c3_r3cmap"),
+           ("c3 find: LDS table u16 + window addressing, backward walks (NEEDLE_FIND_LENGTHS=0)", "pmc_c3_r3window"),
+           ("c3 find: + the lengths automaton, no backward walk (shipped)", "pmc_c3_r3lengths"),
+           ("c5 find (packed functions, unchanged kernel)", "pmc_c5_r3")],
+    "04": [("c3s find: the scan kernel's walk of the compressed automaton (round 3's path; NEEDLE_PREFILTER=0)", "pmc_c3s_r4scan"),
+           ("c3s find: n-gram filter kernel, first form (24-bit multiply-add hash, one bit per window, bitmap behind the program)", "pmc_c3s_r4ngram"),
+           ("c3s find: n-gram filter kernel as shipped (dot2 hash, and-or address, two bits of one word per window, exact-step walk)", "pmc_c3s_r4final"),
+           ("c3s containedIn: n-gram filter kernel as shipped", "pmc_c3s_r4finalc"),
+           ("c3 find (lengths automaton, LDS table u16; unchanged kernel)", "pmc_c3_r4"),
+           ("c5 find (packed functions; unchanged kernel)", "pmc_c5_r4"),
+           ("c5w find: LDS table u8 behind the two-level page map (NEEDLE_FLAT_MAP=0)", "pmc_c5w_r4"),
+           ("c5w find: flat 64 KB page map (shipped)", "pmc_c5w_r4flat"),
+           ("c5w containedIn: two-level page map (NEEDLE_FLAT_MAP=0)", "pmc_c5w_r4contained"),
+           ("c5w containedIn: flat page map (shipped)", "pmc_c5w_r4flatc")],
+}
+sets = SETS[RND]
 keys = ["kernel_us", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
         "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
 rows = [(n, summ(d)) for n, d in sets]
@@ -49,8 +63,8 @@ def cell(r, f):
 
 
 with open(os.path.join(root, "profiles", "r%s_pmc.md" % RND), "w") as f:
-    f.write("# PMC summaries, round 3 (`rocprofv3 --kernel-trace --pmc ...`, one counter group per pass: `scripts/pmc.sh`; this table: `scripts/summarize_pmc.py`)\n\n")
-    f.write("Per launch of `needle::scan_kernel` on the 10M x 256 batch, mean over the launches of a 3-step bench run.  `GRBM_GUI_ACTIVE` is summed "
+    f.write("# PMC summaries, round %s (`rocprofv3 --kernel-trace --pmc ...`, one counter group per pass: `scripts/pmc.sh`; this table: `scripts/summarize_pmc.py`)\n\n" % int(RND))
+    f.write("Per launch of the bench kernel (`needle::scan_kernel` / `needle::ngram_kernel`) on the 10M x 256 batch, mean over the launches of a 3-step bench run.  `GRBM_GUI_ACTIVE` is summed "
             "over the 8 XCDs (÷ 8 = kernel cycles); SQ wave / wait counters are in quad-cycles; `SQ_LDS_IDX_ACTIVE` / `SQ_LDS_BANK_CONFLICT` in LDS "
             "cycles summed over all CUs.  Runs under the profiler are 3-8 % slower than the bench line.\n\n")
     f.write("| counter | " + " | ".join(n for n, _ in rows) + " |\n|---|" + "---|" * len(rows) + "\n")
@@ -66,7 +80,7 @@ with open(os.path.join(root, "profiles", "r%s_pmc.md" % RND), "w") as f:
     f.write("| scalar-cache loads per char-wave (cold table entries) | " + " | ".join(cell(r, lambda r: "%.2f" % (r["SQ_INSTS_SMEM"] / 4e7)) for _, r in rows) + " |\n")
 
 aux = os.path.join(root, "gpurun_out", "prof_aux")
-if os.path.isdir(aux):
+if os.path.isdir(aux) and RND == "03":
     for d, name in (("short16", "short_rows_16B"), ("short64", "short_rows_64B"), ("long", "long_rows_1000x1MiB")):
         shutil.copyfile(os.path.join(aux, d, "t_kernel_stats.csv"), os.path.join(root, "profiles", "r%s_%s_kernel_stats.csv" % (RND, name)))
     with open(os.path.join(root, "profiles", "r%s_aux_kernels.md" % RND), "w") as f:

@@ -80,6 +80,25 @@ for rx, words, mode, expect in cases:
     rows = torch.where(flip, torch.full_like(rows, ord("q")), rows)
     total += check(p, o, rows, None, (rx[:30], "near-miss"))
     assert total > 1000, total
+    # a flood: rows built from the keywords' own TAILS (first char replaced) -- every slot passes the filter, almost nothing matches --
+    # with real keywords planted in between: the kernel gives such groups up and walks their rows in full (needle_ngram.hip kNgFlood)
+    long_words = [w for w in words if len(w) >= 6][:512] or words
+    for stride, n in ((256, 64 * 150 + 9), (64, 64 * 200 + 3), (1024, 64 * 20 + 1)):
+        wt8 = torch.zeros((len(long_words), 8), dtype=torch.uint8, device=dev) + 32
+        for i, w in enumerate(long_words):
+            t = torch.tensor([ord(c) for c in w[-8:]], dtype=torch.uint8, device=dev)
+            t[0] = ord("q") if t[0] != ord("q") else ord("z")
+            wt8[i, 8 - len(t):] = t
+        pick = torch.randint(0, len(long_words), (n, stride // 8), device=dev, generator=g)
+        rows = wt8[pick].reshape(n, stride).clone()
+        rows[::5, 8:8 + len(kw[0])] = kw[0]
+        rows[3::7, stride - len(kw[1 % len(kw)]):] = kw[1 % len(kw)]
+        total += check(p, o, rows, None, (rx[:30], stride, "flood"))
+        lens = (torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 % (stride + 1)).to(torch.int32)
+        total += check(p, o, rows, lens, (rx[:30], stride, "flood ragged"))
+        half = rows.clone()
+        half[n // 2:] = W.keyword_batch(torch, words, 9, n - n // 2, stride, device=dev)  # quiet groups behind flooded ones
+        total += check(p, o, half, None, (rx[:30], stride, "flood then quiet"))
 print("PREFILTER-GPU-OK")
 '''
 
