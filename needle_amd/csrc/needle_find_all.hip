@@ -112,6 +112,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
     wk.win_on = 0, wk.win_lo = 0, wk.win_hi = 0; // (the find-all programs are lowered without window addressing)
     wk.sp_chains = 0, wk.sp_pad_ident = 0, wk.dead_hi = 0;
     wk.flat = (CW == 2 && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16)) ? a.hdr.flat_pages : 0u;
+    if ((MODE == MODE_TABLE8 || MODE == MODE_TABLE16) && a.hdr.win_on) { // a lengths program in window layout (needle_scan.h sets these up the same way)
+        wk.win_on = 1, wk.win_lo = a.hdr.win_lo_e, wk.win_hi = a.hdr.win_hi_e;
+        wk.table_off = a.hdr.off_table - a.hdr.win_lo_e;
+    }
     if (MODE == MODE_SPARSE) { // the scan kernels' compressed lengths program (needle_scan.h sets these up the same way)
         wk.pad_e = wk.pre_e = a.hdr.win_lo_e;
         wk.win_on = a.hdr.win_on, wk.win_lo = a.hdr.win_lo_e, wk.win_hi = a.hdr.win_hi_e;

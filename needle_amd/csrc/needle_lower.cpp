@@ -574,7 +574,9 @@ static Program lower_core(const RefTables &t, Which which, int char_width, size_
     Window win;
     {
         static const bool window_on = !(getenv("NEEDLE_WINDOW") && atoi(getenv("NEEDLE_WINDOW")) == 0);
-        if (window_on && !no_pair && lds_table_budget > 0 && mode != MODE_PACK && mode != MODE_PAIR) {
+        // (the find-all kernel's lengths program -- ml && no_pair -- takes window addressing too since round 4: NEEDLE_FIND_ALL_WINDOW=0 off)
+        static const bool fa_window = !(getenv("NEEDLE_FIND_ALL_WINDOW") && atoi(getenv("NEEDLE_FIND_ALL_WINDOW")) == 0);
+        if (window_on && (!no_pair || (ml && fa_window)) && lds_table_budget > 0 && mode != MODE_PACK && mode != MODE_PAIR) {
             auto same = [&](int a, int b) {
                 if (a == b) return true;
                 for (int st = 0; st < n_dev; ++st)

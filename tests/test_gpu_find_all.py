@@ -64,7 +64,7 @@ print("FIND-ALL-OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env,mode", [({}, 2), ({"NEEDLE_FIND_ALL_LENGTHS": "0"}, 2), ({"NEEDLE_FIND_ALL_LENGTHS": "0", "NEEDLE_FIND_ALL_DEFER": "0"}, 2),
+@pytest.mark.parametrize("env,mode", [({}, 2), ({"NEEDLE_FIND_ALL_WINDOW": "0"}, 2), ({"NEEDLE_FIND_ALL_LENGTHS": "0"}, 2), ({"NEEDLE_FIND_ALL_LENGTHS": "0", "NEEDLE_FIND_ALL_DEFER": "0"}, 2),
                                       ({"NEEDLE_FIND_ALL_ROUNDS": "1"}, 2),
                                       ({"NEEDLE_MAX_PROG_LDS": "4096", "NEEDLE_HYBRID": "0"}, 3),
                                       ({"NEEDLE_MAX_PROG_LDS": "4096"}, 5), ({"NEEDLE_MAX_PROG_LDS": "20000", "NEEDLE_SPARSE": "0"}, 5),
@@ -72,7 +72,7 @@ print("FIND-ALL-OK")
                                       ({"NEEDLE_MAX_PROG_LDS": "12000", "NEEDLE_WINDOW": "0", "NEEDLE_FIND_ALL_LENGTHS": "2"}, 6),
                                       ({"NEEDLE_MAX_PROG_LDS": "20000", "NEEDLE_FIND_ALL_ROUNDS": "1"}, 6),
                                       ({"NEEDLE_MAX_PROG_LDS": "12000", "NEEDLE_FIND_ALL_ROUNDS": "1", "NEEDLE_WINDOW": "0"}, 6)],
-                         ids=["one-pass-lengths", "one-pass-backward-walks", "starts-at-once", "rounds", "hbm-table", "hot-rows-4k", "hot-rows-20k",
+                         ids=["one-pass-lengths", "one-pass-lengths-column-maps", "one-pass-backward-walks", "starts-at-once", "rounds", "hbm-table", "hot-rows-4k", "hot-rows-20k",
                               "one-pass-compressed-lengths", "one-pass-compressed-lengths-cmap",
                               "rounds-compressed-automaton", "rounds-compressed-automaton-cmap"])
 def test_keyword_dictionary_every_match(env, mode):
