@@ -573,9 +573,10 @@ def measure(workload, args, ctx, headline):
             out["host_landed"]["packed16"] = {"ms_per_step": dtp * 1e3, "d2h_bytes_per_step": sh.per_words * 8 + 4 * n_rows,
                                               "note": "needle_find_packed16_dev (the scan stores one dword per row itself) + D2H of 4 B per row"}
             del cw_, cr_, cc_, pk
-    if rank == 0 and world == 1 and not args.no_extras and workload == "c3" and is_find:
+    if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s") and is_find:
         # EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
-        # the batch (needle_find_all.hip): counts + dense per-row slots.  Its own figure, never the `value`.
+        # the batch (needle_find_all.hip; for dictionaries behind the n-gram candidate filter -- c3s -- that kernel's find-all form,
+        # needle_ngram.hip): counts + dense per-row slots.  Its own figure, never the `value`.
         slots = 32
         fc = torch.zeros(n_rows, dtype=torch.int32, device=dev)
         fs = torch.full((n_rows, slots), -1, dtype=torch.int32, device=dev)
@@ -592,7 +593,7 @@ def measure(workload, args, ctx, headline):
         fa_bytes = n_rows * (256 * cw + 4) + 8 * n_matches
         out["find_all"] = {"ms_per_step": dt * 1e3, "matches": n_matches, "matches_per_s": n_matches / dt, "max_per_row": int(fc.max().item()),
                            "slots": slots, "more": bool(more), "GB/s": fa_bytes / dt / 1e9, "algorithmic_bytes": fa_bytes,
-                           "kernel": "needle::find_all_kernel",
+                           "kernel": "needle::ngram_kernel (find-all form)" if pre["on"] else "needle::find_all_kernel",
                            "note": "every non-overlapping match per row (repeated Matcher.find()), one pass; bytes = rows + 4 B count per row + 8 B per match"}
         # the same with each match as one dword (needle_find_all_packed16_dev: start | end << 16): one result line per row
         t = time.perf_counter()

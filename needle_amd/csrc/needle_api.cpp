@@ -37,6 +37,10 @@ hipError_t launch_dict(int op, const ScanArgs &a, int n_cus, hipStream_t stream)
 bool ngram_shape_ok(const ScanArgs &a);
 size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng);
 hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream);
+size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng);
+hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
+                                 int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
+                                 hipStream_t stream);
 int ngram_level(); // needle_lower.cpp (NEEDLE_PREFILTER)
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
@@ -321,6 +325,33 @@ static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v
     return NEEDLE_OK;
 }
 
+// Flood watch of the filter kernel (DevProgram): reads what the last completed filter launch of this program saw; false = this call
+// takes the ordinary kernel (the program is suspended, one call fewer from now).  NEEDLE_PREFILTER_WATCH=0: always true.
+static bool ngram_watch_allows(const DevProgram *fp) {
+    const uint32_t seen_cand = fp->h_ng_stats[0], seen_kib = fp->h_ng_stats[1];
+    if (seen_kib >= 1024u) {
+        fp->h_ng_stats[1] = 0;
+        if (seen_cand > 16u * (uint64_t)seen_kib) {
+            const int b = fp->ng_backoff.load();
+            fp->ng_suspend.store(b);
+            fp->ng_backoff.store(b < 1024 ? 2 * b : 1024);
+        } else {
+            fp->ng_backoff.store(32);
+        }
+    }
+    static const bool watch_on = !(getenv("NEEDLE_PREFILTER_WATCH") && atoi(getenv("NEEDLE_PREFILTER_WATCH")) == 0);
+    if (!watch_on || fp->ng_suspend.load() <= 0) return true;
+    fp->ng_suspend.fetch_sub(1);
+    return false;
+}
+// (behind the kernel on its stream; the host never waits for it.  Concurrent launches on other streams may mix their counts: the watch
+// is a heuristic, the answers do not depend on it)
+static hipError_t ngram_watch_after_launch(const DevProgram *fp, hipStream_t stream) {
+    hipError_t e = hipMemcpyAsync((void *)fp->h_ng_stats, fp->d_ng_stats, 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(fp->d_ng_stats, 0, 8, stream);
+    return e;
+}
+
 // NEEDLE_FIND_LENGTHS: 0 = find() always by forward + backward walks, 1 (default) = the "lengths" automaton where the ordinary
 // program is a plain LDS table, 2 = also instead of the pair table (measured slower: DESIGN.md s4)
 static bool find_lengths_for(uint32_t mode) {
@@ -582,28 +613,11 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // (needle_ngram_host.cpp), on containedIn() and on find() whose start is end - length (lengths programs, one-length patterns).
     if (fp->d_ng && fp->prog.ng.p.on && ngram_level() > 0 && v->char_width == 1 && op != OP_MATCHES && !skip_backward &&
         (op == OP_CONTAINED_IN || lengths_form || a.fixed_len >= 0) && ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, fp->prog.ng.p)) {
-        // flood watch (DevProgram): what the last completed filter launch of this program saw
-        const uint32_t seen_cand = fp->h_ng_stats[0], seen_kib = fp->h_ng_stats[1];
-        if (seen_kib >= 1024u) {
-            fp->h_ng_stats[1] = 0;
-            if (seen_cand > 16u * (uint64_t)seen_kib) {
-                const int b = fp->ng_backoff.load();
-                fp->ng_suspend.store(b);
-                fp->ng_backoff.store(b < 1024 ? 2 * b : 1024);
-            } else {
-                fp->ng_backoff.store(32);
-            }
-        }
-        static const bool watch_on = !(getenv("NEEDLE_PREFILTER_WATCH") && atoi(getenv("NEEDLE_PREFILTER_WATCH")) == 0);
-        if (!watch_on || fp->ng_suspend.load() <= 0) {
+        if (ngram_watch_allows(fp)) {
             HIP_TRY(launch_ngram(op, a, fp->prog.ng.p, fp->d_ng, fp->d_ng_stats, n_cus, (hipStream_t)stream));
-            // (behind the kernel on its stream; the host never waits for it.  Concurrent launches on other streams may mix their counts:
-            // the watch is a heuristic, the answers do not depend on it)
-            HIP_TRY(hipMemcpyAsync((void *)fp->h_ng_stats, fp->d_ng_stats, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
-            HIP_TRY(hipMemsetAsync(fp->d_ng_stats, 0, 8, (hipStream_t)stream));
+            HIP_TRY(ngram_watch_after_launch(fp, (hipStream_t)stream));
             return NEEDLE_OK;
         }
-        fp->ng_suspend.fetch_sub(1);
     }
     HIP_TRY(launch_scan(op, (int)v->char_width, a, n_cus, (hipStream_t)stream));
     return NEEDLE_OK;
@@ -1348,6 +1362,45 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
             if (sp && sp->prog.hdr.mode == MODE_SPARSE) fp = sp, lmode = true;
         }
         if (lmode) need_backward = false;
+    }
+    // Dictionaries whose find() runs behind the n-gram candidate filter (needle_ngram.hip): their find-all does too -- the filter
+    // kernel's find-all form files every verified candidate and each row sorts its own out against its moving cursor (dense slots,
+    // the counting pass and the compact filing alike).  NEEDLE_FIND_ALL_FILTER=0: off (A/B, tests).
+    static const bool fa_filter = !(getenv("NEEDLE_FIND_ALL_FILTER") && atoi(getenv("NEEDLE_FIND_ALL_FILTER")) == 0);
+    if (fa_filter && (count_only || d_offsets || slots) && v->char_width == 1 && ngram_level() > 0 && (p->t.fixed_len >= 0 || find_lengths_for(MODE_SPARSE))) {
+        const DevProgram *sp = nullptr;
+        int cus = 0;
+        rc = get_program(p, W_FORWARDS, 1, p->t.fixed_len >= 0 ? 0 : 7, &sp, &cus);
+        if (rc) return rc;
+        if (sp && sp->d_ng && sp->prog.ng.p.on && ngram_find_all_lds_bytes(sp->prog.hdr, sp->prog.ng.p)) {
+            ScanArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rows = (const uint8_t *)v->rows;
+            a.n_rows = v->n_rows;
+            a.stride_bytes = stride_bytes;
+            a.total_bytes = a.n_rows * a.stride_bytes;
+            a.row_len = v->row_len;
+            a.lengths = v->lengths;
+            a.prog = sp->d_blob;
+            a.hdr = sp->prog.hdr;
+            a.fixed_len = p->t.fixed_len;
+            if (ngram_shape_ok(a) && ngram_watch_allows(sp)) {
+                int32_t *d_more = nullptr;
+                HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
+                hipError_t e = hipMemsetAsync(d_more, 0, 4, stream);
+                if (e == hipSuccess) e = launch_ngram_find_all(a, sp->prog.ng.p, sp->d_ng, sp->d_ng_stats, slots, d_counts, d_start, d_end, d_packed, d_more, d_offsets, count_only, cus, stream);
+                if (e == hipSuccess) e = ngram_watch_after_launch(sp, stream);
+                int32_t m = 0;
+                if (e == hipSuccess && more) {
+                    e = hipMemcpyAsync(&m, d_more, 4, hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                }
+                (void)scratch_free(d_more, stream);
+                if (e != hipSuccess) return hip_fail(e, "find_all (filter kernel)");
+                if (more) *more = m != 0;
+                return NEEDLE_OK;
+            }
+        }
     }
     if (!lmode) rc = get_program(p, W_FORWARDS, (int)v->char_width, need_backward ? 5 : 4, &fp, &n_cus);
     if (rc) return rc;

@@ -33,6 +33,9 @@ struct NgramParams {
 // LDS of the filter kernel (needle_ngram.hip), per wave: the candidate queue + one u64 result slot per row of the group
 constexpr uint32_t kNgQueue = 128;                      // candidates a wave can hold (at most 63 wait while 64 more arrive)
 constexpr uint32_t kNgWaveLds = kNgQueue * 4 + 64 * 8;
+// ... of its find-all form: the queue + per row of the group two slots for verified candidates (8 bytes each) and a counter
+constexpr uint32_t kNgRowSlots = 2;
+constexpr uint32_t kNgWaveLdsFA = kNgQueue * 4 + 64 * kNgRowSlots * 8 + 64 * 4;
 constexpr uint32_t kNgWaves = 16;
 constexpr uint32_t kNgLdsCap = 160u * 1024u;
 
@@ -41,9 +44,9 @@ constexpr uint32_t kNgLdsCap = 160u * 1024u;
 struct NgramLayout {
     uint32_t bm_base, q_base, total;
 };
-inline bool ngram_layout(uint32_t prog_bytes, uint32_t bm_bytes, NgramLayout *out) {
+inline bool ngram_layout(uint32_t prog_bytes, uint32_t bm_bytes, NgramLayout *out, uint32_t wave_bytes = kNgWaveLds) {
     if (bm_bytes < 4096u || (bm_bytes & (bm_bytes - 1u))) return false;
-    const uint32_t p = (prog_bytes + 15u) & ~15u, qb = kNgWaves * kNgWaveLds;
+    const uint32_t p = (prog_bytes + 15u) & ~15u, qb = kNgWaves * wave_bytes;
     NgramLayout l;
     l.bm_base = (p + bm_bytes - 1u) & ~(bm_bytes - 1u);
     if (l.bm_base - p >= qb) l.q_base = p, l.total = l.bm_base + bm_bytes;

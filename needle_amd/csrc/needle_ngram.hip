@@ -16,6 +16,7 @@
 // end, start) to its row's LDS slot by a 64-bit minimum: several windows of a row may find matches, the reference's is the one
 // that accepts first.  find() takes "lengths" programs (start = end - pend[stop state], needle_lower.h) or patterns of one
 // length (DFAClassBuilder.java:640-646).
+#include <string.h>
 #include "needle_walk.h"
 #include "needle_ngram.h"
 
@@ -27,6 +28,14 @@ struct NgramArgs {
     const uint32_t *ng_bitmap;
     NgramLayout lay;        // where the bitmap and the waves' queues sit in LDS (ngram_layout)
     uint32_t *stats;        // optional: [0] += candidates, [1] += KiB units of text seen by this launch
+    // OP_NG_FIND_ALL (every non-overlapping match of every row, dense per-row slots: needle_find_all.h FindAllArgs)
+    uint32_t fa_slots;
+    uint32_t *fa_counts;
+    int32_t *fa_starts, *fa_ends;
+    uint32_t *fa_packed;
+    int32_t *fa_more;
+    const uint64_t *fa_offsets; // != nullptr: compact filing -- match k of row r at offsets[r] + k, room for offsets[r + 1] - offsets[r]
+    uint32_t fa_count_only;     // 1: nothing is filed, every match is counted
     uint32_t dbg;           // measurement builds (-DNEEDLE_TUNING) only: NEEDLE_NG_DBG -- 1: candidates are dropped, 2: text gathered but
                             // no walk, 3: walk on zeros (no gather), +16: runs start as soon as 32 candidates wait; 0 in the product
     uint32_t stride_log2;   // stride_bytes is a power of two (else 0xFFFFFFFF)
@@ -34,6 +43,7 @@ struct NgramArgs {
 };
 
 static_assert(kNgWaves == (uint32_t)kWavesPerBlock, "ngram_layout assumes the scan kernels' workgroup");
+constexpr int OP_NG_FIND_ALL = 3; // (beside OP_CONTAINED_IN / OP_FIND of needle_device.h)
 constexpr int kNgPF = 4;                                // units in flight per wave = units per batch
 
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
@@ -61,7 +71,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     wk.win_on = a.hdr.win_on;
     wk.win_lo = a.hdr.win_lo_e;
     wk.win_hi = a.hdr.win_hi_e;
-    wk.dead_hi = OP == OP_FIND ? a.hdr.fa_dead_hi : 0u;
+    constexpr bool FINDLIKE = OP != OP_CONTAINED_IN; // find() and find-all: first accept, then on until the automaton dies
+    constexpr bool FA = OP == OP_NG_FIND_ALL;
+    wk.dead_hi = FINDLIKE ? a.hdr.fa_dead_hi : 0u;
     wk.sp_chains = a.hdr.sp_chains;
     wk.sp_pad_ident = a.hdr.sp_pad_ident;
     wk.table_off = a.hdr.off_table - (MODE == MODE_SPARSE ? 0u : a.hdr.win_lo_e);
@@ -69,8 +81,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     wk.gtable = nullptr;
     wk.hot_last = 0;
     const uint32_t accept_lo = a.hdr.accept_lo, start_state = a.hdr.start;
-    const uint32_t qbase = A.lay.q_base + (uint32_t)wave * kNgWaveLds;
-    const uint32_t sbase = qbase + kNgQueue * 4u;
+    const uint32_t qbase = A.lay.q_base + (uint32_t)wave * (FA ? kNgWaveLdsFA : kNgWaveLds);
+    const uint32_t sbase = qbase + kNgQueue * 4u; // find / containedIn: the rows' slots; find-all: two candidate slots per row ...
+    const uint32_t cbase = sbase + 64u * kNgRowSlots * 8u; // ... and a counter per row
     const uint32_t mm = A.ng.m1 | A.ng.m2 << 16, amask = A.ng.addr_mask;
     const uint32_t K = A.ng.warm;
 #ifdef NEEDLE_TUNING
@@ -126,32 +139,40 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     // row's slot.  A candidate: r = K chars ahead of the window's end qn, lim0 = qn + S - 1.  A whole row (the flood fallback below):
     // r = qn = 0, lim0 = the row's length.  Text comes from memory (L2, mostly) 16 bytes at a time: the first piece wherever r is,
     // the following ones aligned (stride % 16 == 0: inside the row), chars already walked skipped.
-    auto run_rows = [&](uint64_t grp, uint32_t row, bool valid, uint32_t qn, uint32_t r, uint32_t lim0) __attribute__((always_inline)) {
+    struct Hit {
+        bool found, died; // died: the automaton died without a first accept at or after qn (it had passed an earlier match)
+        uint32_t first, last;
+        int32_t start;
+    };
+    auto walk_row = [&](uint64_t grp, uint32_t row, bool valid, uint32_t qn, uint32_t r, uint32_t lim0) __attribute__((always_inline)) -> Hit {
         const uint64_t grow = (grp << 6) + row;
         uint32_t len = a.row_len;
         if (a.lengths) len = valid ? a.lengths[grow] : 0u;
         valid = valid && qn <= len;
         const uint64_t rowabs = grow * a.stride_bytes;
-        {
-            const uint64_t room = a.total_bytes - 16u - (valid ? rowabs : 0ull); // keep the 16-byte read inside the batch: an
-            r = (uint64_t)r < room ? r : (uint32_t)room;                          // EARLIER restart is as good
-        }
         const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull);
         uint32_t lim = lim0 < len ? lim0 : len;
         uint32_t st = start_state, last = 0, first = 0;
-        bool found = false, over = !valid;
-        uint32_t base = valid ? r : 0u, cur = base; // the piece being walked starts at `base`; chars before `cur` are done
+        bool found = false, over = !valid, died = false;
+        // the piece being walked starts at `base`; chars before `cur` are not walked: the walk starts AT r, in the start state
+        // (the 16-byte read stays inside the batch: in its last 16 bytes the piece starts earlier and the first chars are skipped)
+        uint32_t cur = valid ? r : 0u, base = cur;
+        {
+            const uint64_t room = a.total_bytes - 16u - (valid ? rowabs : 0ull);
+            base = (uint64_t)base < room ? base : (uint32_t)room;
+        }
         auto step = [&](uint32_t colv, uint32_t pos) __attribute__((always_inline)) {
             const bool go = !over && pos >= cur && pos < lim;
             const uint32_t ns = apply<MODE, 1>(wk, st, colv);
             st = go ? ns : st;
             const bool acc = go && st >= accept_lo && pos + 1u >= qn;
-            if (OP == OP_FIND) {
+            if (FINDLIKE) {
                 last = acc ? pos + 1u : last;
                 first = (acc && !found) ? pos + 1u : first;
                 lim = acc ? len : lim; // after the first accept the walk runs on until the automaton dies
                 found = found || acc;
-                over = over || (go && st <= wk.dead_hi);
+                died = died || (go && st <= wk.dead_hi);
+                over = over || died;
             } else {
                 found = found || acc;
                 over = over || acc;
@@ -169,27 +190,47 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 step(col[k], base + (uint32_t)k);
                 if ((k >= 7 || (k & 3) == 3) && k != 15 && __ballot(!over && base + (uint32_t)k + 1u < lim) == 0ull) break; // (K + S - 1 = 9 or 10 steps is the usual run)
             }
-            cur = base + 16u;
+            const uint32_t done_to = base + 16u;
+            cur = cur > done_to ? cur : done_to;
             if (__ballot(!over && cur < lim) == 0ull) break; // (rare for a candidate: a match that runs past its 16 bytes)
-            base = cur & ~15u;
+            base = done_to & ~15u;
         }
-        if (OP == OP_FIND) {
-            int32_t s;
+        Hit h;
+        h.found = found, h.died = died && !found, h.first = first, h.last = last, h.start = 0;
+        if (FINDLIKE) {
             if (a.fixed_len >= 0) {
-                s = (int32_t)last - a.fixed_len; // :640-646
+                h.start = (int32_t)last - a.fixed_len; // :640-646
             } else {
                 uint32_t pidx = st;
                 if (MODE == MODE_SPARSE) { // (needle_scan.h finish_rows: a live stop state asks its END record)
                     const uint32_t st_end = sparse_end<1>(wk, st, found && st > wk.dead_hi, a.hdr.sp_end_col4);
                     pidx = (st_end & 0xFFFFu) - a.hdr.sp_dead_row0;
                 }
-                s = (int32_t)last - (int32_t)lds_u8(a.hdr.fa_len_off + (found ? pidx : 0u));
+                h.start = (int32_t)last - (int32_t)lds_u8(a.hdr.fa_len_off + (found ? pidx : 0u));
             }
-            if (found) {
-                const uint64_t key = (uint64_t)first << 32 | (uint64_t)last << 16 | (uint64_t)(uint32_t)s;
+        }
+        return h;
+    };
+    // A candidate (find / containedIn): its run reports to the row's slot.  find-all: runs that found a match are filed with their row
+    // {window end, first - end | last, length} -- the first two of a row in its slots, all of them counted; the rows sort them out at
+    // the group's end.
+    auto run_rows = [&](uint64_t grp, uint32_t row, bool valid, uint32_t qn, uint32_t r, uint32_t lim0) __attribute__((always_inline)) {
+        const Hit h = walk_row(grp, row, valid, qn, r, lim0);
+        if (FA) {
+            // (a run whose automaton died on the way to its window -- it crossed an earlier match, after which the reference restarts
+            // and this run did not -- knows nothing about the window: filed as such, the row runs it again from its cursor)
+            if (h.found || h.died) {
+                const uint32_t ord = __hip_atomic_fetch_add((lds_u32_t *)(uintptr_t)(cbase + row * 4u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const uint64_t ent = (uint64_t)qn << 48 | (uint64_t)(h.found ? h.first - qn : 0xFFu) << 32 | (uint64_t)(h.last & 0xFFFFu) << 16 |
+                                     (uint64_t)((uint32_t)((int32_t)h.last - h.start) & 0xFFFFu);
+                if (ord < kNgRowSlots) *(lds_u64_t *)(uintptr_t)(sbase + (row * kNgRowSlots + ord) * 8u) = ent;
+            }
+        } else if (OP == OP_FIND) {
+            if (h.found) {
+                const uint64_t key = (uint64_t)h.first << 32 | (uint64_t)h.last << 16 | (uint64_t)(uint32_t)h.start;
                 __hip_atomic_fetch_min((lds_u64_t *)(uintptr_t)(sbase + row * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
-        } else if (found) {
+        } else if (h.found) {
             __hip_atomic_fetch_or((lds_u64_t *)(uintptr_t)sbase, 1ull << row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
@@ -202,7 +243,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         const uint32_t units = units_of(g);
         n_units += units;
         // ---- the group's result slots
-        if (OP == OP_FIND) *(lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u) = ~0ull;
+        if (FA) *(lds_u32_t *)(uintptr_t)(cbase + (uint32_t)lane * 4u) = 0u;
+        else if (OP == OP_FIND) *(lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u) = ~0ull;
         else if (lane == 0) *(lds_u64_t *)(uintptr_t)sbase = 0ull;
         uint32_t carry = 0; // (the window reaching back from a row's first bytes is dropped below: what it holds does not matter)
         for (uint32_t u0 = 0; u0 < units; u0 += kNgPF) {
@@ -266,7 +308,71 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         }
         // ---- the group's verdicts: lane = row
         asm volatile("" ::: "memory");
-        if (OP == OP_FIND) {
+        if (FA) {
+            // Every non-overlapping match of the row, as the reference's repeated find() reports them (DFAClassBuilder.java:616-659): after
+            // a match the search restarts AT its end.  A filed candidate's run started K chars ahead of its window: where that is at or
+            // after the row's cursor it IS the reference's walk (the run-up argument of needle_ngram_host.cpp) and its match is the next
+            // one; where it is not -- two matches within K chars of each other, a match overlapping the one before -- the window is run
+            // again from the cursor, and so is a window whose run died on the way (it crossed an earlier match).  (A window whose run
+            // stayed alive and found nothing has nothing from the cursor either: both walks are in the same state by then.)  Rows with more
+            // than two filed candidates are searched from the cursor match by match -- exact, slow, rare on the text the filter is for.
+            const bool row_ok = (uint32_t)lane < rows_in;
+            const uint32_t n_mine = *(const lds_u32_t *)(uintptr_t)(cbase + (uint32_t)lane * 4u);
+            uint64_t e0 = ~0ull, e1 = ~0ull; // this row's filed candidates, by window end
+            if (n_mine >= 1u) e0 = *(const lds_u64_t *)(uintptr_t)(sbase + ((uint32_t)lane * kNgRowSlots) * 8u);
+            if (n_mine >= 2u) e1 = *(const lds_u64_t *)(uintptr_t)(sbase + ((uint32_t)lane * kNgRowSlots + 1u) * 8u);
+            if (e1 < e0) {
+                const uint64_t t = e0;
+                e0 = e1, e1 = t;
+            }
+            bool slow = row_ok && n_mine > kNgRowSlots;
+            uint32_t cursor = 0, cnt = 0;
+            bool more_f = false;
+            uint64_t out0 = ((g << 6) + lane) * (uint64_t)A.fa_slots;
+            uint32_t cap = A.fa_count_only ? 0xFFFFFFFFu : A.fa_slots;
+            if (A.fa_offsets) {
+                out0 = row_ok ? A.fa_offsets[(g << 6) + lane] : 0ull;
+                cap = row_ok ? (uint32_t)(A.fa_offsets[(g << 6) + lane + 1] - out0) : 0u;
+            }
+            auto emit = [&](bool hit, uint32_t last, int32_t start) __attribute__((always_inline)) {
+                const bool file = hit && cnt < cap;
+                more_f = more_f || (hit && !file);
+                if (file && !A.fa_count_only) {
+                    const uint64_t o = out0 + cnt;
+                    if (A.fa_packed) {
+                        A.fa_packed[o] = (uint32_t)start | (last << 16);
+                    } else {
+                        A.fa_starts[o] = start;
+                        A.fa_ends[o] = (int32_t)last;
+                    }
+                }
+                cnt += file ? 1u : 0u;
+                cursor = file ? last : cursor;
+            };
+#pragma unroll 1
+            for (int j = 0; j < (int)kNgRowSlots; ++j) { // (a loop, not unrolled: one copy of the re-run)
+                const uint64_t x = e0;
+                e0 = e1, e1 = ~0ull;
+                const bool have = row_ok && !slow && !more_f && x != ~0ull;
+                const uint32_t e = (uint32_t)(x >> 48), last = (uint32_t)((x >> 16) & 0xFFFFu), mlen = (uint32_t)(x & 0xFFFFu);
+                const bool unknown = ((x >> 32) & 0xFFu) == 0xFFu;
+                const uint32_t r0 = e > K ? e - K : 0u;
+                const bool exact = have && !unknown && r0 >= cursor;
+                const bool again = have && !exact && e + (uint32_t)S - 1u > cursor;
+                Hit h2;
+                h2.found = false, h2.died = false, h2.first = 0, h2.last = 0, h2.start = 0;
+                if (__ballot(again) != 0ull) h2 = walk_row(g, (uint32_t)lane, again, e > cursor ? e : cursor + 1u, cursor, e + (uint32_t)S - 1u);
+                emit(exact || (again && h2.found), exact ? last : h2.last, exact ? (int32_t)(last - mlen) : h2.start);
+            }
+            while (__ballot(slow && !more_f) != 0ull) { // the reference's loop, one find() at a time, for the rows that need it
+                const bool todo = slow && !more_f;
+                const Hit h = walk_row(g, (uint32_t)lane, todo, cursor, cursor, 0xFFFFFFFFu);
+                emit(todo && h.found, h.last, h.start);
+                slow = todo && h.found && !more_f;
+            }
+            if (row_ok && A.fa_counts) A.fa_counts[(g << 6) + lane] = cnt;
+            if (__ballot(more_f) != 0ull && lane == 0) *A.fa_more = 1;
+        } else if (OP == OP_FIND) {
             const uint64_t key = *(const lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u);
             const bool row_ok = (uint32_t)lane < rows_in;
             const bool res = row_ok && key != ~0ull;
@@ -328,8 +434,36 @@ bool ngram_shape_ok(const ScanArgs &a) {
            a.row_len <= 65535u;
 }
 
+static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
+                                   const NgramArgs *fa);
+
 hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream) {
+    return launch_ngram_any(op, a, ng, d_bitmap, d_stats, n_cus, stream, nullptr);
+}
+
+// LDS of the find-all form; 0 = does not fit
+size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
+    NgramLayout l;
+    return ngram_layout(h.lds_bytes, ng.bm_bytes, &l, kNgWaveLdsFA) ? l.total : 0;
+}
+
+// Every non-overlapping match of every row behind the filter (dense per-row slots, compact filing or counting only; needle_find_all.h FindAllArgs): `a` carries the
+// rows and the lengths program, the outputs are the find-all ones.
+hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
+                                 int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
+                                 hipStream_t stream) {
+    NgramArgs F;
+    memset(&F, 0, sizeof(F));
+    F.fa_slots = slots, F.fa_counts = counts, F.fa_starts = starts, F.fa_ends = ends, F.fa_packed = packed, F.fa_more = more;
+    F.fa_offsets = offsets, F.fa_count_only = count_only ? 1u : 0u;
+    return launch_ngram_any(OP_NG_FIND_ALL, a, ng, d_bitmap, d_stats, n_cus, stream, &F);
+}
+
+static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
+                                   const NgramArgs *fa) {
     NgramArgs A;
+    memset(&A, 0, sizeof(A));
+    if (fa) A = *fa;
     A.a = a;
     A.ng = ng;
     A.ng_bitmap = d_bitmap;
@@ -338,13 +472,14 @@ hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const 
     A.stride_log2 = 0xFFFFFFFFu;
     if ((stride & (stride - 1u)) == 0u) A.stride_log2 = (uint32_t)__builtin_ctz(stride);
     A.stride_recip = (uint32_t)((1ull << 32) / stride);
-    if (!ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay) || ng.addr_shift != 24u) return hipErrorInvalidValue;
+    if (!ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay, op == OP_NG_FIND_ALL ? kNgWaveLdsFA : kNgWaveLds) || ng.addr_shift != 24u) return hipErrorInvalidValue;
     A.dbg = 0;
 #ifdef NEEDLE_TUNING
     static const uint32_t dbg_env = getenv("NEEDLE_NG_DBG") ? (uint32_t)atoi(getenv("NEEDLE_NG_DBG")) : 0u;
     A.dbg = dbg_env;
 #endif
     const size_t lds = A.lay.total;
+    if (op == OP_NG_FIND_ALL) return launch_ng_m<OP_NG_FIND_ALL>(A, n_cus, lds, stream);
     return op == OP_FIND ? launch_ng_m<OP_FIND>(A, n_cus, lds, stream) : launch_ng_m<OP_CONTAINED_IN>(A, n_cus, lds, stream);
 }
 

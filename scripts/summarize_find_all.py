@@ -23,7 +23,7 @@ for w in ("c3", "c2", "c5", "c3s"):
     k_avg, calls = 0.0, None
     stats = os.path.join(src, w, "t_kernel_stats.csv")
     for r in csv.DictReader(open(stats)):
-        if "find_all_kernel" in r["Name"]:
+        if "find_all_kernel" in r["Name"] or "ngram_kernel" in r["Name"]:  # (c3s since round 4: the filter kernel's find-all form)
             k_avg += float(r["AverageNs"]) / 1e3
             calls = int(r["Calls"]) if calls is None else calls
     shutil.copy(stats, os.path.join(root, "profiles", "r%s_find_all_%s_kernel_stats.csv" % (RND, w)))
@@ -84,7 +84,10 @@ out.append("\nSince round 3: for the dictionary (a keyword union) the program is
            "written once: staging the stores in LDS would not change the count).  The packed form above halves it -- one array, one line per row.  c2 / c5 / c3s: patterns with unbounded match lengths, or a refined "
            "automaton that does not fit the LDS as a plain table (c3s), keep indexBackwards at the end of every 64-row group.  Round 4: the kernel is unchanged; the compressed lengths program "
            "was built into it for c3s (`NEEDLE_FIND_ALL_LENGTHS=2`, parity-tested) and measured no faster than hot rows + backward walks (2.05 against 1.98 ms: "
-           "`profiles/r04_find_all_c3s_ab.log`) -- what a find-all costs there is the per-lane piece walk, not the 0.25 starts per row; host batches now cross PCIe in "
-           "the one-dword form (`needle_find_all_host`).")
+           "`profiles/r04_find_all_c3s_ab.log`) -- what a find-all costs there is the per-lane piece walk, not the 0.25 starts per row.  "
+           "What c3s takes now is NOT this kernel: dictionaries whose find() runs behind the n-gram candidate filter have their find-all there too "
+           "(`needle::ngram_kernel<3, ...>`, needle_ngram.hip: every verified candidate filed with its row, the rows sort theirs out against the moving cursor) -- the c3s "
+           "line above is that kernel (`NEEDLE_FIND_ALL_FILTER=0`: 1.99-2.04 ms, count pass 1.75, compact form 3.8).  Host batches cross PCIe in the one-dword form "
+           "(`needle_find_all_host`).")
 open(os.path.join(root, "profiles", "r%s_find_all.md" % RND), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

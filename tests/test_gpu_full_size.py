@@ -276,3 +276,39 @@ def test_c5w_full_size_properties():
     for j, i in enumerate(idx):
         mm = cre.search("".join(map(chr, host[j])))
         assert ((True, mm.start(), mm.end()) if mm else (False, -1, -1)) == (bool(f_bits[i]), int(hs[i]), int(he[i])), i
+
+
+@pytest.mark.gpu
+def test_c3s_find_all_behind_the_filter_full_size():
+    """C3-sparse at 10^7 rows: every match of every row through the n-gram filter kernel's find-all form: slot 0 == find() on every
+    row (another kernel path), counts == the counting pass, matches ordered and disjoint, every match spells a keyword (torch gather on
+    a slab), the oracle's repeated find() on rows sampled over the whole batch."""
+    import torch
+    from needle_amd.pattern import unpack_bitmap
+    p, rows, words = make("c3s")
+    assert p.prefilter_info("forwards")["on"] == 1
+    n, slots = rows.shape[0], 4
+    counts, st, en, more = p.find_all_dense(rows, slots)
+    assert not more
+    fw, fs, fe = p.find_batch(rows)
+    matched = torch.from_numpy(unpack_bitmap(fw, n)).cuda()
+    assert bool(((counts > 0) == matched).all())
+    assert bool((st[:, 0] == fs).all()) and bool((en[:, 0] == fe).all())
+    assert bool((p.count_matches_batch(rows) == counts).all())
+    filed = torch.arange(slots, device="cuda")[None, :] < counts[:, None]
+    assert bool(((en > st) | ~filed).all()) and bool(((st[:, 1:] >= en[:, :-1]) | ~filed[:, 1:]).all())
+    assert bool((st[~filed] == -1).all())
+    kw = set(words)
+    idx = sample_rows(n, k=4000, seed=23)
+    hc, hs, he = counts[idx].cpu().numpy(), st[idx].cpu().numpy(), en[idx].cpu().numpy()
+    host = rows[torch.from_numpy(idx).cuda()].cpu().numpy()
+    o = oracle_of(p)
+    total = 0
+    for i in range(len(idx)):
+        got = [(int(hs[i, j]), int(he[i, j])) for j in range(int(hc[i]))]
+        for a, b in got:
+            assert bytes(host[i, a:b]).decode() in kw
+        if i % 4 == 0:
+            assert got == o.find_all(host[i]), idx[i]
+        total += len(got)
+    assert total > 800

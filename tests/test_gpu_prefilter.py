@@ -41,6 +41,31 @@ def check(p, o, rows, lens, tag):
     bs = np.nonzero((fs.cpu().numpy() != ofs) | (fe.cpu().numpy() != ofe))[0]
     assert bs.size == 0, (tag, "start/end", bs[:5], fs.cpu().numpy()[bs[:5]], ofs[bs[:5]], fe.cpu().numpy()[bs[:5]], ofe[bs[:5]])
     assert (unpack_bitmap(cw, n) == oc).all(), (tag, "containedIn")
+    # every match of every row (the filter kernel's find-all form: needle_find_all_dev behind the filter) against the oracle's repeated
+    # find() on every 3rd row, the one-dword form against the two arrays on all of them; 3 slots: rows with more set `more`
+    want = {i: o.find_all(host[i] if hl is None else host[i, :hl[i]]) for i in range(0, n, 3)}
+    most = max([len(w) for w in want.values()] + [1])
+    for slots in (most + 1, 2):
+        counts, st, en, more = p.find_all_dense(rows, slots, lens)
+        c2, se, more2 = p.find_all_dense_packed16(rows, slots, lens)
+        torch.cuda.synchronize()
+        counts, st, en = counts.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+        assert (c2.cpu().numpy() == counts).all() and more2 == more, (tag, "find-all packed counts")
+        sev = se.cpu().numpy().view(np.uint32)
+        filed = np.arange(slots)[None, :] < counts[:, None]
+        assert ((sev & 0xFFFF)[filed] == st[filed]).all() and ((sev >> 16)[filed] == en[filed]).all(), (tag, "find-all packed")
+        for i, w in want.items():
+            k = min(len(w), slots)
+            assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == w[:k], (tag, "find-all", i, counts[i], st[i], en[i], w[:6])
+        if slots > most:
+            assert counts[::3].sum() == sum(len(w) for w in want.values())
+            # the counting pass and the compact (CSR) filing through the same kernel
+            cnt = p.count_matches_batch(rows, lens).cpu().numpy()
+            assert (cnt == counts).all(), (tag, "count pass")
+            offs, s1, e1 = p.find_all_csr(rows, lens)
+            offs, s1, e1 = offs.cpu().numpy(), s1.cpu().numpy(), e1.cpu().numpy()
+            assert (np.diff(offs) == counts).all() and offs[-1] == counts.sum() == len(s1), (tag, "csr offsets")
+            assert (s1 == st[filed]).all() and (e1 == en[filed]).all(), (tag, "csr matches")
     return int(of.sum())
 for rx, words, mode, expect in cases:
     p = DFACompiler.compile(rx, "t", 0)
