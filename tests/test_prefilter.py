@@ -28,7 +28,7 @@ def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
         i = p.prefilter_info(which)
         assert i["on"] == 1 and i["mode"] == 6 and i["stride"] == 2 and i["warm"] == 8 and i["min_len"] == 6, i
         assert 1500 <= i["n_windows"] <= 2000 and i["bitmap_bytes"] == 32768, i
-    rows = W.keyword_batch(np, words, 11, 160, 256)
+    rows = W.keyword_batch(np, words, 11, 72, 256)
     rows[::7, 256 - len(words[3]):] = [ord(c) for c in words[3]]        # a keyword that ends with the row
     rows[3::7, 256 - len(words[4]) + 1:] = [ord(c) for c in words[4]][:-1]  # ... and one the row's end cuts
     rows[5::7, :len(words[9])] = [ord(c) for c in words[9]]              # ... and one at the very start
@@ -46,7 +46,7 @@ def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
         if k % 8 == 0:  # every window a candidate: the restart K chars ahead alone
             want = o.find_all(row)[:1]
             assert sim.filtered(p, "find", row, all_windows=True, info=fi) == ((True,) + want[0] if want else (False, -1, -1))
-    assert n_match > 60
+    assert n_match > 25
 
 
 @pytest.mark.parametrize("regex,why", [("[0-9]+", ""), ("abc", ""), ("a.*bcdefg", ""), ("(abcdef)+x", "")])
@@ -94,7 +94,7 @@ for rx, want_f, want_c in CASES:
     n_on += 1
     # texts built from pieces of the regex's own literals, so that near misses, overlaps and matches at both row ends are common
     lits = [w for w in rx.replace("(", "|").replace(")", "|").replace("?", "|").replace("[", "|").replace("]", "|").split("|") if w.isalnum()]
-    for trial in range(250):
+    for trial in range(100):
         parts = []
         while sum(map(len, parts)) < 60:
             k = rng.integers(0, 4)
