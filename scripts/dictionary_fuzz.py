@@ -66,6 +66,18 @@ for l, dl in ((None, None), (lens, tl)):
         if len(a) >= 2: assert nw[i] and (ns[i], ne[i]) == a[1], ("second find", seed, i)
         else: assert not nw[i], ("second find", seed, i)
     assert (unpack_bitmap(p.contained_in_batch(t, dl), n) == o.batch_contained_in(rows, l, threads=8)).all(), ("containedIn", seed)
+    # every match of every row (dense slots, then the count pass) against the oracle's repeated find() on sampled rows
+    want = {i: o.find_all(rows[i] if l is None else rows[i, :l[i]]) for i in range(0, n, 7)}
+    most = max([len(w) for w in want.values()] + [1])
+    for slots in (most + 2, 2):
+        cnt, ast, aen, more = p.find_all_dense(t, slots, dl)
+        cnt, ast, aen = cnt.cpu().numpy(), ast.cpu().numpy(), aen.cpu().numpy()
+        for i, w in want.items():
+            k = min(len(w), slots)
+            assert cnt[i] == k and list(zip(ast[i, :k].tolist(), aen[i, :k].tolist())) == w[:k], ("find-all", seed, i, cnt[i], ast[i].tolist(), aen[i].tolist(), w[:6])
+    cc = p.count_matches_batch(t, dl).cpu().numpy()
+    for i, w in want.items():
+        assert cc[i] == len(w), ("count pass", seed, i)
 pf = p.prefilter_info("forwards")
 print("DICT-OK seed %d: %d keywords over %d letters, %d states, mode %d, lengths form %d, n-gram filter %s, %d of %d rows match" % (
     seed, len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"],
