@@ -187,6 +187,31 @@ public final class GpuPattern implements Pattern, AutoCloseable {
     }
 
     /**
+     * find() with start() / end() of every row as ONE int, {@code start | end << 16} ({@code -1}: no match; rows of at most 65 534
+     * chars): needle_find_packed16_host -- the scan kernel stores that form itself.  Returns the match bitmap.
+     */
+    public long[] findBatchPacked(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen, ByteBuffer lengths, int[] startEnd) {
+        long[] bitmap = new long[(int) ((nRows + 63) / 64)];
+        check(Native.findPacked16Host(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, bitmap, startEnd), null);
+        return bitmap;
+    }
+
+    /**
+     * Whether find() of this pattern runs behind the n-gram candidate filter on batches of 8-bit rows (the table-level form of the
+     * reference's prefix / first-byte narrowing, DFAClassBuilder.java:365-376, :420-426); the reason when it does not.
+     */
+    public String prefilterWhyNot() {
+        int[] info = new int[7];
+        String why = Native.prefilterInfo(handle, 2, info);
+        return info[0] != 0 ? "" : why;
+    }
+
+    /** The library's NEEDLE_* environment switches (needle_tuning_info). */
+    public static String tuningInfo() {
+        return Native.tuningInfo();
+    }
+
+    /**
      * find() over an array of haystacks: the strings are flattened to one char buffer + offsets (no per-string
      * Matcher objects, SURVEY.md s8 a9) and cross the boundary once.  Returns the match bitmap.
      */

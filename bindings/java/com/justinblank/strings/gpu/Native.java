@@ -70,6 +70,26 @@ final class Native {
     static native int findCompactHost(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
                                       java.nio.ByteBuffer lengths, long[] bitmap, int[] records, long[] nMatched);
 
+    /**
+     * needle_find_packed16_host: find() with start / end of every row as ONE int, start | end << 16 (0xFFFFFFFF = no match; rows of
+     * at most 65 534 chars): the scan kernel stores that form itself, 4 result bytes per row on the device and over PCIe.
+     */
+    static native int findPacked16Host(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
+                                       java.nio.ByteBuffer lengths, long[] bitmap, int[] startEnd);
+
+    /** needle_tuning_info: the library's NEEDLE_* environment switches, tab-separated lines (name, default, current, scope, effect). */
+    static native String tuningInfo();
+
+    /** needle_trim_scratch: hand the library's free scratch memory beyond keepBytes back to the driver. */
+    static native int trimScratch(long keepBytes);
+
+    /**
+     * needle_pattern_prefilter_info: whether containedIn (which = 1) / find (which = 2) of this pattern run behind the n-gram
+     * candidate filter on batches of 8-bit rows -- info[0] on, [1] kernel mode, [2] stride, [3] run-up, [4] shortest match,
+     * [5] windows, [6] bitmap bytes; returns the reason when there is no filter ("" otherwise).
+     */
+    static native String prefilterInfo(long handle, int which, int[] info);
+
     /** needle_pattern_serialize / needle_pattern_deserialize: the precompiled-pattern blob (Precompile's analogue). */
     static native byte[] serialize(long handle);
 

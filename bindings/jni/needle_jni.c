@@ -9,6 +9,7 @@
  * The same entry points are exercised without a JVM by tests/ through ctypes (needle_amd/_lib.py).
  */
 #include <jni.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include "needle_hip.h"
@@ -202,6 +203,41 @@ NATIVE(jint, findCompactHost)(JNIEnv *env, jclass c, jlong h, jobject rows, jint
     (*env)->ReleaseLongArrayElements(env, bitmap, bm, 0);
     if (rec) (*env)->ReleaseIntArrayElements(env, records, rec, 0);
     return rc;
+}
+
+NATIVE(jint, findPacked16Host)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jlongArray bitmap, jintArray startEnd) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    if (!long_room(env, bitmap, (n + 63) / 64) || !int_room(env, startEnd, n)) return NEEDLE_ERR_INVALID;
+    jlong *bm = (*env)->GetLongArrayElements(env, bitmap, NULL);
+    jint *se = (*env)->GetIntArrayElements(env, startEnd, NULL);
+    int rc = needle_find_packed16_host((const needle_pattern *)(intptr_t)h, &v, (uint64_t *)bm, (uint32_t *)se);
+    (*env)->ReleaseLongArrayElements(env, bitmap, bm, 0);
+    (*env)->ReleaseIntArrayElements(env, startEnd, se, 0);
+    return rc;
+}
+
+NATIVE(jstring, tuningInfo)(JNIEnv *env, jclass c) {
+    size_t need = 0;
+    if (needle_tuning_info(NULL, 0, &need) != NEEDLE_OK || need == 0) return (*env)->NewStringUTF(env, "");
+    char *buf = (char *)malloc(need);
+    if (!buf) return (*env)->NewStringUTF(env, "");
+    (void)needle_tuning_info(buf, need, NULL);
+    jstring s = (*env)->NewStringUTF(env, buf);
+    free(buf);
+    return s;
+}
+
+NATIVE(jint, trimScratch)(JNIEnv *env, jclass c, jlong keepBytes) { return needle_trim_scratch(keepBytes < 0 ? 0 : (size_t)keepBytes); }
+
+NATIVE(jstring, prefilterInfo)(JNIEnv *env, jclass c, jlong h, jint which, jintArray info) {
+    needle_prefilter_info pi;
+    if (needle_pattern_prefilter_info((const needle_pattern *)(intptr_t)h, which, &pi, NULL) != NEEDLE_OK) return (*env)->NewStringUTF(env, needle_last_error());
+    if (int_room(env, info, 7)) {
+        const jint v[7] = {pi.on, pi.mode, pi.stride, pi.warm, pi.min_len, pi.n_windows, pi.bitmap_bytes};
+        (*env)->SetIntArrayRegion(env, info, 0, 7, v);
+    }
+    return (*env)->NewStringUTF(env, pi.why);
 }
 
 NATIVE(jint, packedHost)(JNIEnv *env, jclass c, jlong h, jint op, jcharArray data, jlongArray offsets, jlongArray bitmap, jintArray start, jintArray end) {
