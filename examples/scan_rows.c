@@ -101,6 +101,31 @@ int main(void) {
         for (k = 0; k < (int)offsets[ROWS]; ++k) printf(" (%d,%d)", csr_s[k], csr_e[k]);
         printf("\n");
     }
+    /* find() with a row's start / end as ONE dword, start | end << 16, stored by the scan kernel itself (0xFFFFFFFF = no match) */
+    {
+        uint32_t se[ROWS];
+        void *d_se;
+        hipMalloc(&d_se, sizeof(se));
+        if (needle_find_packed16_dev(p, &v, (uint64_t *)d_bm, (uint32_t *)d_se, NULL) != NEEDLE_OK) {
+            printf("packed find failed: %s\n", needle_last_error());
+            return 1;
+        }
+        hipMemcpy(se, d_se, sizeof(se), hipMemcpyDeviceToHost);
+        printf("packed:");
+        for (r = 0; r < ROWS; ++r) {
+            if (se[r] == 0xFFFFFFFFu) printf(" -");
+            else printf(" (%u,%u)", se[r] & 0xFFFFu, se[r] >> 16);
+        }
+        printf("\n");
+        hipFree(d_se);
+    }
+    /* the library's environment switches, as the library lists them */
+    {
+        size_t need = 0;
+        char head[64];
+        if (needle_tuning_info(NULL, 0, &need) != NEEDLE_OK || needle_tuning_info(head, sizeof(head), NULL) != NEEDLE_OK) return 1;
+        printf("tuning info: %u bytes, header \"%.33s\"\n", (unsigned)(need > 1000), head);
+    }
     needle_pattern_destroy(p);
     return 0;
 }

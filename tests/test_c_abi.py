@@ -50,3 +50,5 @@ def test_c_example_runs(tmp_path):
     assert 'row 4 "2024-01-31": found=1 first=(0,4) all=(0,4)(5,7)(8,10)' in out
     assert "more=0" in out
     assert "csr total=7 more=0: (6,8) (1,2) (3,5) (6,9) (0,4) (5,7) (8,10)" in out
+    assert "packed: (6,8) -" in out and out.split("packed:")[1].split("\n")[0].split()[3:] == ["(1,2)", "(0,4)"]
+    assert 'tuning info: 1 bytes, header "name\tdefault\tcurrent\tscope\teffect"' in out
