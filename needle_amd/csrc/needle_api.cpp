@@ -153,6 +153,13 @@ struct needle_pattern {
     //          7 the same for find() in the scan kernels
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
+    // needle_pattern_prefilter_info answers (lowering a big dictionary takes seconds): per `which`, filled once
+    struct PrefilterCache {
+        bool have = false;
+        needle_prefilter_info info;
+        std::vector<uint32_t> bitmap;
+    } pf_cache[4];
+    std::mutex pf_mu;
     std::mutex ml_mu;       // guards the one-time match-length analysis only: scans of programs that exist already do not wait for it
     int ml_state = 0;       // 0: not analysed yet, 1: find-all can report starts as end - length (ml), -1: it cannot
     MatchLengths ml;
@@ -1125,9 +1132,25 @@ int needle_pattern_program_info(const needle_pattern *p, int which, int char_wid
 
 // The n-gram candidate filter (needle_ngram_host.h) of the program containedIn() (which = 1) / find() (which = 2) runs on 8-bit
 // rows, as run_dev chooses it: whether there is one, its parameters, why not, and (bitmap != NULL) the bitmap itself.
-int needle_pattern_prefilter_info(const needle_pattern *p, int which, needle_prefilter_info *o, uint32_t *bitmap) {
+static int prefilter_info_uncached(const needle_pattern *p, int which, needle_prefilter_info *o, std::vector<uint32_t> *bitmap_out);
+
+int needle_pattern_prefilter_info(const needle_pattern *cp, int which, needle_prefilter_info *o, uint32_t *bitmap) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
     if (which != W_CONTAINED_IN && which != W_FORWARDS) return fail(NEEDLE_ERR_INVALID, "which must be 1 (contained_in) or 2 (forwards)");
+    std::lock_guard<std::mutex> lk(p->pf_mu);
+    needle_pattern::PrefilterCache &c = p->pf_cache[which];
+    if (!c.have) {
+        const int rc = prefilter_info_uncached(p, which, &c.info, &c.bitmap);
+        if (rc) return rc;
+        c.have = true;
+    }
+    *o = c.info;
+    if (bitmap && c.info.on) memcpy(bitmap, c.bitmap.data(), c.bitmap.size() * 4);
+    return NEEDLE_OK;
+}
+
+static int prefilter_info_uncached(const needle_pattern *p, int which, needle_prefilter_info *o, std::vector<uint32_t> *bitmap_out) {
     memset(o, 0, sizeof(*o));
     const bool backward = which == W_FORWARDS && p->t.fixed_len < 0;
     Program pr = lower(p->t, (Which)which, 1, max_prog_lds(), false, backward);
@@ -1154,7 +1177,7 @@ int needle_pattern_prefilter_info(const needle_pattern *p, int which, needle_pre
     o->bitmap_bytes = (int32_t)f.p.bm_bytes;
     o->m1 = f.p.m1, o->m2 = f.p.m2, o->addr_shift = f.p.addr_shift, o->addr_mask = f.p.addr_mask;
     snprintf(o->why, sizeof(o->why), "%s", f.p.on ? "" : (f.why.empty() ? (ngram_level() > 0 ? "not a mode the filter is built for" : "NEEDLE_PREFILTER=0") : f.why.c_str()));
-    if (bitmap && f.p.on) memcpy(bitmap, f.bitmap.data(), f.bitmap.size() * 4);
+    if (f.p.on) *bitmap_out = f.bitmap;
     return NEEDLE_OK;
 }
 
