@@ -97,7 +97,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     const uint64_t wave_cnt = (uint64_t)gridDim.x * n_waves;
     uint64_t g = (uint64_t)blockIdx.x * n_waves + wave;
     if (g >= n_groups) return;
-    const uint32_t units_full = (64u * stride) >> 10; // a multiple of kNgPF (stride % 64 == 0)
+    // a group is stride / 16 units; batches are kNgPF units: where that does not divide, a group's last batch reaches into the next
+    // group's text (read, masked, not used -- ngram_shape_ok bounds the waste)
+    const uint32_t units_full = (((64u * stride) >> 10) + (uint32_t)(kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
     auto units_of = [&](uint64_t grp) -> uint32_t {
         if (grp + 1 < n_groups) return units_full;
         const uint32_t rows_in = (uint32_t)(a.n_rows - (grp << 6));
@@ -428,10 +430,12 @@ size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
     return ngram_layout(h.lds_bytes, ng.bm_bytes, &l) ? l.total : 0;
 }
 
-// Whether this batch shape can take the filter kernel at all (8-bit rows of 64 .. 4096 bytes apart, whole KiB units).
+// Whether this batch shape can take the filter kernel at all: 8-bit rows 64 .. 4096 bytes apart in steps of 16 (a 64-row group is then
+// stride / 16 KiB units), where rounding a group up to whole batches of kNgPF units wastes at most a quarter of the reads.
 bool ngram_shape_ok(const ScanArgs &a) {
-    return a.stride_bytes % 64 == 0 && a.stride_bytes <= 4096 && a.total_bytes >= 16384 && a.from == nullptr && a.end_state == nullptr &&
-           a.row_len <= 65535u;
+    const uint64_t units = a.stride_bytes / 16, rounded = (units + (kNgPF - 1)) & ~(uint64_t)(kNgPF - 1);
+    return a.stride_bytes % 16 == 0 && a.stride_bytes >= 64 && a.stride_bytes <= 4096 && rounded * 4 <= units * 5 && a.total_bytes >= 16384 &&
+           a.from == nullptr && a.end_state == nullptr && a.row_len <= 65535u;
 }
 
 static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,

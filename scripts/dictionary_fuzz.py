@@ -81,7 +81,7 @@ for l, dl in ((None, None), (lens, tl)):
 pf = p.prefilter_info("forwards")
 print("DICT-OK seed %d: %d keywords over %d letters, %d states, mode %d, lengths form %d, n-gram filter %s, %d of %d rows match" % (
     seed, len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"],
-    ("stride %d run-up %d" % (pf["stride"], pf["warm"])) if pf["on"] and width % 64 == 0 else "off", int(of.sum()), n))
+    ("stride %d run-up %d" % (pf["stride"], pf["warm"])) if pf["on"] else "off", int(of.sum()), n))
 '''
 if __name__ == "__main__":
     seed0, cnt = int(sys.argv[1]), int(sys.argv[2])

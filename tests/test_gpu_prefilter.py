@@ -79,7 +79,8 @@ for rx, words, mode, expect in cases:
         assert fi["mode"] == mode, fi
     kw = [torch.tensor([ord(c) for c in w], dtype=torch.uint8, device=dev) for w in words[:8]]
     total = 0
-    for stride, n in ((256, 64 * 700 + 13), (64, 64 * 900 + 7), (192, 64 * 300 + 63), (1024, 64 * 60 + 1), (256, 70)):
+    for stride, n in ((256, 64 * 700 + 13), (64, 64 * 900 + 7), (192, 64 * 300 + 63), (1024, 64 * 60 + 1), (256, 70),
+                      (112, 64 * 500 + 9), (272, 64 * 200 + 33), (208, 64 * 150 + 1)):  # (groups that are not whole batches of units)
         rows = W.keyword_batch(torch, words, 3, n, stride, device=dev)
         k0, k1, k2 = kw[0], kw[1 % len(kw)], kw[2 % len(kw)]
         rows[::11, stride - len(k0):] = k0                  # a keyword that ends with the row
