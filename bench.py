@@ -269,7 +269,8 @@ def measure(workload, args, ctx, headline):
     # N > 1, find: start / end cross the links as one dword per row (rows are 256 chars: two 16-bit halves), written by the scan
     # straight into the send buffer
     sh = ShardedScan(scan, total_rows, world, rank, is_find, dev, n_buffers=args.buffers, comm=ctx.comm, overlap=args.overlap == "on",
-                     pack16=use_dist and is_find, max_row_len=rows.shape[1], scan_packed=scan_packed if is_find else None)
+                     pack16=(use_dist or getattr(args, "force_pack16", False)) and is_find, max_row_len=rows.shape[1],
+                     scan_packed=scan_packed if is_find else None)
     for _ in range(2):  # first launches: program upload, kernel attributes (never part of a captured graph)
         sh.scan_only()
     torch.cuda.synchronize()
@@ -416,7 +417,8 @@ def measure(workload, args, ctx, headline):
                        "" if world == 1 else (", row-sharded over %d GPUs (%d rows per GPU)" % (world, n_rows))),
                    "rows_total": total_rows, "rows_per_gpu": n_rows, "row_chars": 256, "char_bytes": cw,
                    "parallelism": "row-shard x%d" % world,
-                   "result": "bitmap" + (("+start/end int32" + (" (on the links: one dword per row, two 16-bit halves)" if use_dist else "")) if is_find else ""),
+                   "result": "bitmap" + ((("+start|end<<16, one dword per row (needle_find_packed16_dev)" if sh.scan_packed is not None else "+start/end int32") +
+                                          (" (on the links: one dword per row, two 16-bit halves)" if use_dist else "")) if is_find else ""),
                    "automaton": {"states": inf["n_states"][which], "classes": inf["stride"],
                                  "kernel_mode": mode_names.get(inf["kernel_mode"][which], str(inf["kernel_mode"][which])),
                                  "prefilter": ({"windows": pre["n_windows"], "stride": pre["stride"], "run_up": pre["warm"], "bitmap_bytes": pre["bitmap_bytes"]}
@@ -708,12 +710,14 @@ def main():
         import copy
         small = copy.copy(args)
         small.rows, small.steps, small.warmup, small.no_extras, small.no_cpu_baseline = 1_250_000, 200, 10, True, True
+        small.force_pack16 = True  # find(): the form a shard's scan stores on an N > 1 run -- one dword per row, written by the kernel itself
         out["c4_shard_step"] = {}
         for w in [args.workload] + [x for x in ("c3",) if x != args.workload]:
             try:
                 r, _ = measure(w, small, ctx, False)
                 out["c4_shard_step"][w] = {"rows": small.rows, "ms_per_step": r["ms_per_step"], "kernel_ms": r["roofline"]["kernel_ms"],
                                            "overhead_frac": r["ms_per_step"] / r["roofline"]["kernel_ms"] - 1.0,
+                                           "result": r["config"]["result"],
                                            "host_issue_us_per_step": r["host_issue_us_per_step"]}
             except Exception as e:  # noqa: BLE001
                 out["c4_shard_step"][w] = {"error": "%s: %s" % (type(e).__name__, e)}

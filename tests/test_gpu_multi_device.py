@@ -175,7 +175,7 @@ def test_bench_two_ranks_on_one_gpu(workload):
     # the gather is checked against what the ranks computed (popcount of the gathered bitmap; find: a position-weighted
     # checksum of the gathered start / end) -- a mis-ordered gather must not print a clean line
     assert d2["gather_verified"] is True and d2["gather_check"]["popcount_gathered"] == d2["gather_check"]["popcount_ranks"]
-    if d2["config"]["result"].startswith("bitmap+start/end"):
+    if d2["config"]["result"].startswith("bitmap+start"):
         assert d2["gather_check"]["checksum_gathered"] == d2["gather_check"]["checksum_ranks"]
     assert "gather_verified" not in d1 and d1["cold"]["ms_per_step"] > 0 and d1["steady"]["steps_effective"] >= 3
 
@@ -218,7 +218,8 @@ def test_c4_rehearsal_eight_ranks_full_batch_on_one_gpu():
         k1, k8 = d1["roofline"]["kernel_ms"], 8 * ds["roofline"]["kernel_ms"]
         # measured (profiles/r04_c4_rehearsal.md): c2 +13 % (0.405 -> 8 x 0.0572 ms), c3 +28 % (0.404 -> 8 x 0.0647 ms: a 65 us launch of
         # the big-table find kernel pays the program's staging into LDS and 4.8 groups per wave -- 5 on some, 4 on others -- in full)
-        assert abs(k8 / k1 - 1.0) < (0.15 if workload == "c2" else 0.35), (workload, k1, k8)
+        # (boxes differ: c2 came out at +13 % and +17 % on two of them; the bounds leave that room)
+        assert abs(k8 / k1 - 1.0) < (0.25 if workload == "c2" else 0.40), (workload, k1, k8)
         assert d8["solo_kernel_ms"]["max_over_ranks"] >= 0.8 * ds["roofline"]["kernel_ms"], (d8["solo_kernel_ms"], ds["roofline"]["kernel_ms"])
         print("C4 rehearsal %s: N=1 kernel %.4f ms, 8 x shard kernel %.4f ms, 8-process solo x8 %.4f ms, step %.4f ms (scan %.4f + gather %.4f)" % (
             workload, k1, k8, d8["solo_kernel_ms"]["x_ranks"], d8["ms_per_step"], d8["scan_ms"], d8["gather_ms"]))
