@@ -572,8 +572,19 @@ def measure(workload, args, ctx, headline):
                 hb.copy_(cw_, non_blocking=True)
                 hpk.copy_(pk, non_blocking=True)
             dtp = per_step(landed_packed)
+            # ... and that scan alone, device only (HIP events): the same kernel as the headline's with 4 result bytes per row instead of 8
+            pev = []
+            for _ in range(max(3, args.steps)):
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                pattern.find_packed16_batch(rows, out=(cw_, pk))
+                b_.record()
+                pev.append((a_, b_))
+            torch.cuda.synchronize()
             out["host_landed"]["packed16"] = {"ms_per_step": dtp * 1e3, "d2h_bytes_per_step": sh.per_words * 8 + 4 * n_rows,
-                                              "note": "needle_find_packed16_dev (the scan stores one dword per row itself) + D2H of 4 B per row"}
+                                              "scan_kernel_ms": sum(x.elapsed_time(y) for x, y in pev) / len(pev),
+                                              "note": "needle_find_packed16_dev (the scan stores one dword per row itself) + D2H of 4 B per row; "
+                                                      "scan_kernel_ms: that scan alone on the device"}
             del cw_, cr_, cc_, pk
     if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s") and is_find:
         # EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
