@@ -31,6 +31,24 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def _deps(path, seen=None):
+    """`path` and every file it #includes with quotes, transitively (resolved next to the includer, then in include/)."""
+    import re
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path, errors="replace") as f:
+        for inc in re.findall(r'^\s*#\s*include\s*"([^"]+)"', f.read(), flags=re.M):
+            for base in (os.path.dirname(path), os.path.join(HERE, "..", "include")):
+                cand = os.path.join(base, inc)
+                if os.path.exists(cand):
+                    _deps(cand, seen)
+                    break
+    return seen
+
+
 def build(force=False, verbose=False):
     build_probe(force)
     if not force and not _stale():
@@ -43,6 +61,8 @@ def build(force=False, verbose=False):
     for src in SOURCES:  # one hipcc per translation unit, all at once (the scan kernel's 96 instantiations dominate)
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(f) for f in _deps(os.path.join(CSRC, src))):
+            continue  # (the object is newer than its source and every header it includes, transitively)
         cmd = flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -505,7 +505,9 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
 #else
     constexpr int dict_env = 0;
 #endif
-    if (d_packed && (dict_env > 0 || v->row_stride * v->char_width >= 8 * (uint64_t)kStripeBytes)) {
+    // (NEEDLE_LONG_ROWS=1 forces the stripe paths for any stride: they only know the int32 arrays)
+    static const bool long_rows_forced = getenv("NEEDLE_LONG_ROWS") && atoi(getenv("NEEDLE_LONG_ROWS")) == 1;
+    if (d_packed && (dict_env > 0 || long_rows_forced || v->row_stride * v->char_width >= 8 * (uint64_t)kStripeBytes)) {
         int32_t *tmp = nullptr;
         HIP_TRY(scratch_malloc((void **)&tmp, (size_t)v->n_rows * 8, (hipStream_t)stream));
         rc = run_dev(cp, op, v, d_bitmap, tmp, tmp + v->n_rows, stream, d_from, d_end_state, no_backward, nullptr);

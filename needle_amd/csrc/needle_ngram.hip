@@ -143,6 +143,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     // the following ones aligned (stride % 16 == 0: inside the row), chars already walked skipped.
     struct Hit {
         bool found, died; // died: the automaton died without a first accept at or after qn (it had passed an earlier match)
+        bool crossed;     // find-all: the run passed through an accepting state BEFORE qn -- it crossed an earlier match, where the reference
+                          // restarts (and its search automaton prunes the restart threads: DFA_SEARCH keeps the higher-priority longer
+                          // alternative only) -- so what it says about its window is not the reference's walk
         uint32_t first, last;
         int32_t start;
     };
@@ -155,19 +158,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull);
         uint32_t lim = lim0 < len ? lim0 : len;
         uint32_t st = start_state, last = 0, first = 0;
-        bool found = false, over = !valid, died = false;
+        bool found = false, over = !valid, died = false, crossed = false;
         // the piece being walked starts at `base`; chars before `cur` are not walked: the walk starts AT r, in the start state
-        // (the 16-byte read stays inside the batch: in its last 16 bytes the piece starts earlier and the first chars are skipped)
+        // (EVERY 16-byte read stays inside the batch: in its last 16 bytes a piece starts earlier and the chars before `cur` are
+        // skipped -- also for the lanes that are over and only ride along while others walk on)
         uint32_t cur = valid ? r : 0u, base = cur;
-        {
-            const uint64_t room = a.total_bytes - 16u - (valid ? rowabs : 0ull);
-            base = (uint64_t)base < room ? base : (uint32_t)room;
-        }
+        const uint64_t room = a.total_bytes - 16u - (valid ? rowabs : 0ull);
+        base = (uint64_t)base < room ? base : (uint32_t)room;
         auto step = [&](uint32_t colv, uint32_t pos) __attribute__((always_inline)) {
             const bool go = !over && pos >= cur && pos < lim;
             const uint32_t ns = apply<MODE, 1>(wk, st, colv);
             st = go ? ns : st;
-            const bool acc = go && st >= accept_lo && pos + 1u >= qn;
+            const bool acc_any = go && st >= accept_lo;
+            const bool acc = acc_any && pos + 1u >= qn;
+            if (FA) crossed = crossed || (acc_any && !acc);
             if (FINDLIKE) {
                 last = acc ? pos + 1u : last;
                 first = (acc && !found) ? pos + 1u : first;
@@ -196,9 +200,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             cur = cur > done_to ? cur : done_to;
             if (__ballot(!over && cur < lim) == 0ull) break; // (rare for a candidate: a match that runs past its 16 bytes)
             base = done_to & ~15u;
+            base = (uint64_t)base < room ? base : (uint32_t)room;
         }
         Hit h;
-        h.found = found, h.died = died && !found, h.first = first, h.last = last, h.start = 0;
+        h.found = found, h.died = died && !found, h.crossed = crossed, h.first = first, h.last = last, h.start = 0;
         if (FINDLIKE) {
             if (a.fixed_len >= 0) {
                 h.start = (int32_t)last - a.fixed_len; // :640-646
@@ -221,9 +226,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         if (FA) {
             // (a run whose automaton died on the way to its window -- it crossed an earlier match, after which the reference restarts
             // and this run did not -- knows nothing about the window: filed as such, the row runs it again from its cursor)
-            if (h.found || h.died) {
+            // (so does a run that CROSSED an accept before its window and lived on: in a post-accept state the search automaton has
+            // dropped the restart threads, e.g. `international|inter|nation` on "internationa..": the run for "tion" passes "inter",
+            // stays alive for "international" and never sees "nation")
+            if (h.found || h.died || h.crossed) {
                 const uint32_t ord = __hip_atomic_fetch_add((lds_u32_t *)(uintptr_t)(cbase + row * 4u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                const uint64_t ent = (uint64_t)qn << 48 | (uint64_t)(h.found ? h.first - qn : 0xFFu) << 32 | (uint64_t)(h.last & 0xFFFFu) << 16 |
+                const uint64_t ent = (uint64_t)qn << 48 | (uint64_t)((h.found && !h.crossed) ? h.first - qn : 0xFFu) << 32 | (uint64_t)(h.last & 0xFFFFu) << 16 |
                                      (uint64_t)((uint32_t)((int32_t)h.last - h.start) & 0xFFFFu);
                 if (ord < kNgRowSlots) *(lds_u64_t *)(uintptr_t)(sbase + (row * kNgRowSlots + ord) * 8u) = ent;
             }
@@ -362,9 +370,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 const bool exact = have && !unknown && r0 >= cursor;
                 const bool again = have && !exact && e + (uint32_t)S - 1u > cursor;
                 Hit h2;
-                h2.found = false, h2.died = false, h2.first = 0, h2.last = 0, h2.start = 0;
+                h2.found = false, h2.died = false, h2.crossed = false, h2.first = 0, h2.last = 0, h2.start = 0;
                 if (__ballot(again) != 0ull) h2 = walk_row(g, (uint32_t)lane, again, e > cursor ? e : cursor + 1u, cursor, e + (uint32_t)S - 1u);
-                emit(exact || (again && h2.found), exact ? last : h2.last, exact ? (int32_t)(last - mlen) : h2.start);
+                // (a re-run from the cursor IS the reference's search; should it accept before this window -- a match whose own window
+                // was never filed -- the row is searched match by match below: exact whatever the filter missed)
+                const bool lost = again && h2.crossed;
+                slow = slow || lost;
+                emit(exact || (again && h2.found && !lost), exact ? last : h2.last, exact ? (int32_t)(last - mlen) : h2.start);
             }
             while (__ballot(slow && !more_f) != 0ull) { // the reference's loop, one find() at a time, for the rows that need it
                 const bool todo = slow && !more_f;

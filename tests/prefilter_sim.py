@@ -105,3 +105,79 @@ def filtered(p, op, text, all_windows=False, info=None):
     if best is None:
         return (False, -1, -1)
     return (True, best[2], best[1]) if op != "contained_in" else (True, -1, -1)
+
+
+# ---- find-all behind the filter (needle_ngram.hip, ngram_kernel<OP_NG_FIND_ALL>) ------------------------------------------------
+def walk_row_sim(au, text, qn, r, lim0, fixed_len):
+    """needle_ngram.hip walk_row: the automaton from the start state at char r, a FIRST accept counted at end indexes >= qn and
+    < lim0 + 1, then on until it dies -> dict(found, died, crossed, first, last, start).  crossed: an accepting state BEFORE qn."""
+    n = len(text)
+    lim = min(lim0, n)
+    st, pos, first, last, died, crossed = 0, r, None, None, False, False
+    while pos < lim:
+        st = au.step(st, int(text[pos]))
+        pos += 1
+        if st >= 0 and au.acc[st]:
+            if pos >= qn:
+                if first is None:
+                    first, lim = pos, n
+                last = pos
+            else:
+                crossed = True
+        if au.dead(st):
+            died = True
+            break
+    h = dict(found=first is not None, died=died and first is None, crossed=crossed, first=first, last=last, start=None)
+    if h["found"]:
+        if fixed_len is not None:
+            h["start"] = last - fixed_len
+        else:
+            L = int(au.pend[st]) if st > 0 else 0
+            assert L > 0
+            h["start"] = last - L
+    return h
+
+
+def filtered_find_all(p, text, info=None, all_windows=False, row_slots=2, with_crossed=True):
+    """Every match of one row by the filter kernel's find-all logic: verified candidates are filed with their row (found, or died /
+    crossed an earlier accept on the way: "unknown"), and the row resolves them in window order against its moving cursor; rows with
+    more than row_slots entries, and re-runs that cross an unfiled match, take the exact match-by-match loop.  with_crossed=False: the
+    round-4 logic (kept to show the case it loses)."""
+    info = info or p.prefilter_info("forwards", with_bitmap=True)
+    assert info["on"], info
+    au, fixed = from_pattern(p, "find")
+    S, K = info["stride"], info["warm"]
+    t = np.asarray(text).astype(np.int64)
+    entries = []
+    for e in range(S, len(t) + 1, S):
+        if e < 4:
+            continue
+        x = int(t[e - 4] | (t[e - 3] << 8) | (t[e - 2] << 16) | (t[e - 1] << 24))
+        if not all_windows and not window_passes(info, info["bitmap"], x):
+            continue
+        h = walk_row_sim(au, t, e, max(e - K, 0), e + S - 1, fixed)
+        crossed = h["crossed"] and with_crossed
+        if h["found"] or h["died"] or crossed:
+            entries.append((e, (not h["found"]) or crossed, h["last"], h["start"]))
+    out, cursor = [], 0
+    slow = len(entries) > row_slots
+    if not slow:
+        for e, unknown, last, start in entries:
+            if not unknown and max(e - K, 0) >= cursor:
+                out.append((start, last))
+                cursor = last
+            elif e + S - 1 > cursor:
+                h = walk_row_sim(au, t, max(e, cursor + 1), cursor, e + S - 1, fixed)
+                if h["crossed"] and with_crossed:
+                    slow = True
+                    break
+                if h["found"]:
+                    out.append((h["start"], h["last"]))
+                    cursor = h["last"]
+    while slow:
+        h = walk_row_sim(au, t, cursor, cursor, 1 << 30, fixed)
+        if not h["found"]:
+            break
+        out.append((h["start"], h["last"]))
+        cursor = h["last"]
+    return out

@@ -125,6 +125,24 @@ for rx, words, mode, expect in cases:
         half = rows.clone()
         half[n // 2:] = W.keyword_batch(torch, words, 9, n - n // 2, stride, device=dev)  # quiet groups behind flooded ones
         total += check(p, o, half, None, (rx[:30], stride, "flood then quiet"))
+if level == 2:
+    # ADVICE r4: a candidate run that CROSSES an earlier accept and lives on (the search automaton keeps the higher-priority longer
+    # alternative, the restart threads are pruned) knows nothing about its window: `nation` right behind `inter` inside `internationa..`
+    rx = "international|inter|nation|qrstuvwxyzab"
+    p = DFACompiler.compile(rx, "t", 0)
+    o, _ = oracle_for(rx, 0)
+    assert p.prefilter_info("forwards")["on"]
+    pieces = ["international", "inter", "nation", "internation", "internationa", "nationa", " ", "x", "qrstuvwxyzab", "tion", "internationwide"]
+    rng = np.random.default_rng(11)
+    for stride, n in ((256, 64 * 120 + 5), (64, 64 * 200 + 9)):
+        host = np.full((n, stride), 32, dtype=np.uint8)
+        for r in range(n):
+            s_ = "".join(pieces[k] for k in rng.integers(0, len(pieces), size=stride // 3))[:stride]
+            host[r, :len(s_)] = np.frombuffer(s_.encode(), dtype=np.uint8)
+        rows = torch.from_numpy(host).to(dev)
+        check(p, o, rows, None, ("crossing", stride))
+        lens = (torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 % (stride + 1)).to(torch.int32)
+        check(p, o, rows, lens, ("crossing ragged", stride))
 print("PREFILTER-GPU-OK")
 '''
 
