@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libneedle_hip.so")
 SOURCES = ["needle_scan_find1.hip", "needle_scan_find2.hip", "needle_scan_contained.hip", "needle_scan_matches.hip", "needle_kernels.hip",
-           "needle_stripe.hip", "needle_find_all.hip", "needle_compact.hip", "needle_ngram.hip", "needle_ngram_host.cpp", "needle_api.cpp", "needle_tuning.cpp", "needle_multi.cpp", "needle_lower.cpp", "needle_regex.cpp"]
+           "needle_stripe.hip", "needle_find_all.hip", "needle_find_all_ls.hip", "needle_compact.hip", "needle_ngram.hip", "needle_ngram_host.cpp", "needle_api.cpp", "needle_tuning.cpp", "needle_multi.cpp", "needle_lower.cpp", "needle_regex.cpp"]
 HEADERS = ["needle_device.h", "needle_walk.h", "needle_scan.h", "needle_find_all.h", "needle_lower.h", "needle_regex.h", "needle_ngram.h", "needle_ngram_host.h", "needle_unicode_tables.h", os.path.join("..", "..", "include", "needle_hip.h")]
 
 

@@ -21,6 +21,7 @@ namespace needle {
 hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hipStream_t stream);
 bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows);
 hipError_t launch_find_all(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream); // needle_find_all.hip
+hipError_t launch_find_all_lockstep(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream); // needle_find_all_ls.hip
 hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, const int32_t *s, const int32_t *e, int32_t *cursor,
                                    uint32_t *counts, int32_t *starts, int32_t *ends, int32_t *any_hit, int n_cus, hipStream_t stream);
 hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipStream_t stream);
@@ -151,6 +152,7 @@ struct needle_pattern {
     //          4 / 5 as 0 / 2 without the pair table (the one-pass find-all kernel)
     //          6 the find-all "lengths" automaton (W_FORWARDS only; absent when the pattern does not allow it)
     //          7 the same for find() in the scan kernels
+    //          8 the find-all transducer (lock-step find-all, needle_find_all_ls.hip; absent when the pattern does not allow it)
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
     // needle_pattern_prefilter_info answers (lowering a big dictionary takes seconds): per `which`, filled once
@@ -195,7 +197,7 @@ static const MatchLengths *pattern_ml(const needle_pattern *cp) {
 static int get_program(needle_pattern *p, int which, int cw, int variant, const DevProgram **out, int *n_cus) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    const MatchLengths *ml67 = (variant == 6 || variant == 7) ? pattern_ml(p) : nullptr; // (before p->mu: see ml_mu)
+    const MatchLengths *ml67 = (variant == 6 || variant == 7 || variant == 8) ? pattern_ml(p) : nullptr; // (before p->mu: see ml_mu)
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->cus.count(dev)) {
         hipDeviceProp_t prop;
@@ -207,13 +209,15 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        if (variant == 6 || variant == 7) { // "lengths" form: the refined forward automaton + pend[] (needle_lower.h);
-                                            // 6: the find-all kernel's plain layout, 7: the scan kernels' (window addressing)
+        if (variant == 6 || variant == 7 || variant == 8) { // "lengths" form: the refined forward automaton + pend[] (needle_lower.h);
+                                            // 6: the find-all kernel's plain layout, 7: the scan kernels' (window addressing);
+                                            // 8: the find-all transducer built on it
             if (!ml67) {
                 *out = nullptr;
                 return NEEDLE_OK;
             }
-            dp.prog = lower_match_lengths(p->t, *ml67, cw, max_prog_lds(), variant == 6);
+            dp.prog = variant == 8 ? lower_find_all_transducer(p->t, *ml67, cw, max_prog_lds())
+                                   : lower_match_lengths(p->t, *ml67, cw, max_prog_lds(), variant == 6);
             if (dp.prog.blob.empty()) { // (does not fit the LDS as a plain table: the ordinary program with backward walks)
                 p->cache.emplace(key, DevProgram());
                 *out = nullptr;
@@ -1207,6 +1211,28 @@ int needle_pattern_match_lengths(const needle_pattern *cp, int32_t *available, i
     return NEEDLE_OK;
 }
 
+// The find-all transducer's device program (needle_lower.h), for inspection and CPU-side tests that walk the blob the way the kernel
+// does.  info[0..11] = n_states, n_cols, pad_col, start, win_on, win_lo_e, win_hi_e, off_table, ft_codes_off, lds_bytes, n_pages, 0.
+int needle_pattern_find_all_transducer(const needle_pattern *cp, int char_width, int32_t *available, int32_t *info, void *blob, size_t cap,
+                                       size_t *needed) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p || !available || (char_width != 1 && char_width != 2)) return fail(NEEDLE_ERR_INVALID, "bad argument");
+    *available = 0;
+    const MatchLengths *ml = pattern_ml(p);
+    if (!ml) return NEEDLE_OK;
+    const Program pr = lower_find_all_transducer(p->t, *ml, char_width, max_prog_lds());
+    if (pr.blob.empty() || !pr.hdr.ft_on) return NEEDLE_OK;
+    *available = 1;
+    if (info) {
+        const ProgHeader &h = pr.hdr;
+        const uint32_t v[12] = {h.n_states, h.n_cols, h.pad_col, h.start, h.win_on, h.win_lo_e, h.win_hi_e, h.off_table, h.ft_codes_off, h.lds_bytes, h.n_pages, 0};
+        for (int i = 0; i < 12; ++i) info[i] = (int32_t)v[i];
+    }
+    if (needed) *needed = pr.blob.size();
+    if (blob && cap >= pr.blob.size()) memcpy(blob, pr.blob.data(), pr.blob.size());
+    return NEEDLE_OK;
+}
+
 int needle_pattern_get_class_map(const needle_pattern *p, uint8_t *cm) {
     if (!p || !cm) return fail(NEEDLE_ERR_INVALID, "NULL argument");
     memcpy(cm, p->t.class_map.data(), 65536);
@@ -1425,6 +1451,50 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
                 if (more) *more = m != 0;
                 return NEEDLE_OK;
             }
+        }
+    }
+    // Patterns with a find-all transducer (needle_lower.h: bounded match lengths, no match inside a longer live one) are walked in
+    // LOCK-STEP: one table lookup per char, every lane at the same char, the restarts folded into the automaton (needle_find_all_ls.hip).
+    // NEEDLE_FIND_ALL_LOCKSTEP=0: off (A/B, tests: the per-lane one-pass kernel below).
+    static const bool lockstep_on = !(getenv("NEEDLE_FIND_ALL_LOCKSTEP") && atoi(getenv("NEEDLE_FIND_ALL_LOCKSTEP")) == 0);
+    if (lockstep_on && lengths_on) {
+        const DevProgram *tp = nullptr;
+        int cus = 0;
+        rc = get_program(p, W_FORWARDS, (int)v->char_width, 8, &tp, &cus);
+        if (rc) return rc;
+        if (tp) {
+            FindAllArgs fl;
+            memset(&fl, 0, sizeof(fl));
+            fl.s.rows = (const uint8_t *)v->rows;
+            fl.s.n_rows = v->n_rows;
+            fl.s.stride_bytes = stride_bytes;
+            fl.s.total_bytes = fl.s.n_rows * fl.s.stride_bytes;
+            fl.s.row_len = v->row_len;
+            fl.s.lengths = v->lengths;
+            fl.s.prog = tp->d_blob;
+            fl.s.hdr = tp->prog.hdr;
+            fl.s.fixed_len = -1;
+            fl.slots = slots;
+            fl.offsets = d_offsets;
+            fl.count_only = count_only ? 1u : 0u;
+            fl.counts = d_counts;
+            fl.starts = d_start;
+            fl.ends = d_end;
+            fl.packed = d_packed;
+            int32_t *d_more = nullptr;
+            HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
+            hipError_t e = hipMemsetAsync(d_more, 0, 4, stream);
+            fl.more = d_more;
+            if (e == hipSuccess) e = launch_find_all_lockstep((int)v->char_width, fl, cus, stream);
+            int32_t m = 0;
+            if (e == hipSuccess && more) { // the only synchronisation: the caller asked whether its slots sufficed
+                e = hipMemcpyAsync(&m, d_more, 4, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            }
+            (void)scratch_free(d_more, stream);
+            if (e != hipSuccess) return hip_fail(e, "find_all (lock-step kernel)");
+            if (more) *more = m != 0;
+            return NEEDLE_OK;
         }
     }
     if (!lmode) rc = get_program(p, W_FORWARDS, (int)v->char_width, need_backward ? 5 : 4, &fp, &n_cus);

@@ -1238,4 +1238,164 @@ Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char
     return lower(t, W_FORWARDS, char_width, lds_table_budget, false, false, plain, &ml);
 }
 
+
+// ---- the find-all transducer (needle_lower.h) -------------------------------------------------------------------------------------
+Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget) {
+    Program p;
+    memset(&p.hdr, 0, sizeof(p.hdr));
+    memset(&p.ng.p, 0, sizeof(p.ng.p));
+    p.hdr.mode = MODE_GLOBAL; // (= not available, with the empty blob)
+    if (!ml.ok) return p;
+    static const bool dbg = getenv("NEEDLE_ML_DEBUG") != nullptr;
+    const RefDfa &d = ml.dfa;
+    const int N = t.stride, OVER = N, PAD = N + 1, NC = N + 2, K = ml.n_dead;
+    auto step = [&](int m, int c) -> int { return c == OVER ? (int)ml.over[m] : (int)d.table[(size_t)m * N + c]; };
+    auto is_dead = [&](int m) { return m >= 1 && m <= K; };
+    // states: {m, s, k}; s = -2: no match pending (a plain state of the lengths automaton); s = -1: the shadow has died
+    std::map<std::array<int, 3>, int> ids;
+    std::vector<std::array<int, 3>> keys(1, std::array<int, 3>{-1, -1, -1}); // 0 = dead
+    auto tid = [&](int m, int s, int k) -> int {
+        const std::array<int, 3> key = {m, s, k};
+        auto it = ids.find(key);
+        if (it != ids.end()) return it->second;
+        const int id = (int)keys.size();
+        ids.emplace(key, id);
+        keys.push_back(key);
+        return id;
+    };
+    std::map<std::pair<int, int>, int> codes; // (length, k) -> 1 .. 15
+    bool ok = true;
+    auto code_of = [&](int L, int k) -> int {
+        auto it = codes.find({L, k});
+        if (it != codes.end()) return it->second;
+        const int c = (int)codes.size() + 1;
+        if (c > 15 || L > 255 || k > 255) ok = false;
+        codes.emplace(std::make_pair(L, k), c);
+        return c;
+    };
+    // after a transition that leaves plain state m2 of the lengths automaton current: dead, accepting (a match pending from here on:
+    // its shadow starts in the start state) or plain
+    auto enter = [&](int m2) -> int { return m2 < 0 ? 0 : d.accepting[m2] ? tid(m2, 0, 0) : tid(m2, -2, 0); };
+    std::vector<uint16_t> tab; // [state][NC]: target << 4 | code
+    tab.assign(NC, 0);         // the dead state's row
+    if (d.accepting[0] || ml.pend[0]) return p;
+    tid(0, -2, 0); // the start state: id 1
+    for (size_t i = 1; i < keys.size() && ok; ++i) {
+        if (keys.size() > 4095) { ok = false; break; }
+        const int m = keys[i][0], s = keys[i][1], k = keys[i][2];
+        tab.resize((i + 1) * NC, 0);
+        for (int c = 0; c < NC; ++c) {
+            uint32_t tgt = 0, code = 0;
+            if (s == -2) { // nothing pending
+                if (c != PAD) {
+                    const int m2 = step(m, c);
+                    if (m2 >= 0 && is_dead(m2)) { ok = false; break; } // (cannot be: nothing is pending)
+                    tgt = (uint32_t)enter(m2);
+                }
+            } else if (c == PAD) { // the row ends with a match pending
+                code = (uint32_t)code_of(ml.pend[m], k);
+            } else {
+                const int m2 = step(m, c), s2 = s >= 0 ? step(s, c) : -1;
+                if (m2 < 0) { ok = false; break; } // (cannot be: a state with a match pending dies into its D_L)
+                if (d.accepting[m2]) {
+                    tgt = (uint32_t)tid(m2, 0, 0); // a later accept of the same search: the shadow starts over
+                } else if (is_dead(m2)) {
+                    code = (uint32_t)code_of(ml.pend[m], k);
+                    if (s2 >= 0 && is_dead(s2)) { ok = false; break; } // (cannot be: the shadow has not accepted)
+                    tgt = (uint32_t)enter(s2); // the restarted search, already past the chars since the match's end
+                } else {
+                    if (s2 >= 0 && d.accepting[s2]) { // the restarted search would accept while this one still lives: a shadow of a
+                        if (dbg) fprintf(stderr, "[ft] shadow accepts under a live match: state (%d,%d,%d) column %d\n", m, s, k, c); // shadow
+                        ok = false;
+                        break;
+                    }
+                    if (k + 1 > 250) { ok = false; break; }
+                    tgt = (uint32_t)tid(m2, s2 < 0 ? -1 : s2, k + 1);
+                }
+            }
+            tab[i * NC + c] = (uint16_t)(tgt << 4 | code);
+        }
+    }
+    if (!ok || keys.size() > 4095) {
+        if (dbg) fprintf(stderr, "[ft] no transducer (%zu states, %zu codes)\n", keys.size(), codes.size());
+        return p;
+    }
+    const int n_t = (int)keys.size();
+    // entries were written with ids that may exceed what existed when a row was made -- all ids are final now; nothing to patch
+    const ColumnMaps cm = column_maps(t, d, char_width);
+    Window win;
+    {
+        static const bool window_on = !(getenv("NEEDLE_WINDOW") && atoi(getenv("NEEDLE_WINDOW")) == 0);
+        if (window_on) {
+            auto same = [&](int a, int b) {
+                if (a == b) return true;
+                for (int st = 0; st < n_t; ++st)
+                    if (tab[(size_t)st * NC + a] != tab[(size_t)st * NC + b]) return false;
+                return true;
+            };
+            win = find_window(cm, char_width, same);
+            const size_t bytes_w = (size_t)n_t * (win.W + 1) * 2, bytes_c = (size_t)n_t * NC * 2;
+            if (win.ok && !(bytes_w <= bytes_c * 5 / 4 || bytes_w <= (16u << 10))) win.ok = false;
+        }
+    }
+    auto put16 = [&](size_t off, uint32_t v) { p.blob[off] = (uint8_t)(v & 255); p.blob[off + 1] = (uint8_t)(v >> 8); };
+    std::vector<uint16_t> out;
+    if (win.ok) {
+        const int nw = win.W + 1; // the window's chars, then PAD ("char ch + 1": column offsets are not rebased)
+        out.resize((size_t)n_t * nw);
+        for (int st = 0; st < n_t; ++st) {
+            for (int j = 0; j < win.W; ++j) out[(size_t)st * nw + j] = tab[(size_t)st * NC + win.cols[j]];
+            out[(size_t)st * nw + win.W] = tab[(size_t)st * NC + PAD];
+        }
+        p.hdr.win_on = 1;
+        p.hdr.win_lo_e = (uint32_t)win.cl * 2u;
+        p.hdr.win_hi_e = (uint32_t)win.ch * 2u;
+        p.hdr.n_cols = (uint32_t)nw;
+        p.hdr.pad_col = (uint32_t)(win.cl + win.W);
+        if (char_width == 1) {
+            p.blob.assign(kLdsTable1 + p.hdr.win_lo_e, 0);
+            p.hdr.off_table = kLdsTable1;
+        } else {
+            p.blob.assign(16, 0);
+            p.hdr.off_table = 16;
+        }
+    } else {
+        out = tab;
+        p.hdr.n_cols = (uint32_t)NC;
+        p.hdr.pad_col = (uint32_t)PAD;
+        if (char_width == 1) {
+            p.blob.assign(512, 0); // cmap16 at kLdsCmap1 = 0
+            for (int c = 0; c < 256; ++c) put16(kLdsCmap1 + 2 * c, cm.cmap8[c] * 2u);
+            p.hdr.off_table = kLdsTable1;
+        } else {
+            if ((uint32_t)NC * 2u > 255u) return p; // (the pages hold column * 2 in a byte)
+            p.blob.assign(kLdsPages2Table + cm.pages.size(), 0);
+            for (int hi = 0; hi < 256; ++hi) put16(kLdsPtab2 + 2 * hi, (uint32_t)cm.ptab[hi] * 256u);
+            for (size_t i = 0; i < cm.pages.size(); ++i) p.blob[kLdsPages2Table + i] = (uint8_t)(cm.pages[i] * 2u);
+            while (p.blob.size() % 16) p.blob.push_back(0);
+            p.hdr.off_table = (uint32_t)p.blob.size();
+        }
+    }
+    p.hdr.n_pages = (uint32_t)(cm.pages.size() / 256);
+    {
+        const uint8_t *b = (const uint8_t *)out.data();
+        p.blob.insert(p.blob.end(), b, b + out.size() * 2);
+    }
+    uint16_t ct[16] = {0};
+    for (const auto &kv : codes) ct[kv.second] = (uint16_t)(kv.first.first | kv.first.second << 8);
+    p.hdr.ft_codes_off = append(p.blob, ct, sizeof(ct));
+    while (p.blob.size() % 16) p.blob.push_back(0);
+    if (p.blob.size() > lds_table_budget || p.blob.size() + 4u * 64u * 64u > 160u * 1024u) { // (no room beside even 4 waves of tiles)
+        p.blob.clear();
+        return p;
+    }
+    p.hdr.mode = MODE_TABLE16;
+    p.hdr.ft_on = 1;
+    p.hdr.n_states = (uint32_t)n_t;
+    p.hdr.start = 1;
+    p.hdr.accept_lo = (uint32_t)n_t; // (no accepting states as far as any other reader is concerned)
+    p.hdr.lds_bytes = (uint32_t)p.blob.size();
+    return p;
+}
+
 } // namespace needle

@@ -71,4 +71,21 @@ MatchLengths match_length_automaton(const RefTables &t);
 // D_L states -- "the search is over" is state <= fa_dead_n.  plain: for the find-all kernel (no window addressing).
 Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget, bool plain = true);
 
+
+// ---- find-all in LOCK-STEP (needle_find_all_ls.hip): the find-all transducer -------------------------------------------
+// The reference's repeated find() (DFAClassBuilder.java:616-659) restarts the search automaton AT the end of every match -- on chars
+// the walk has already consumed while it waited for the automaton to die.  The one-pass kernel (needle_find_all.hip) does that
+// restart per lane, so its lanes leave lock-step.  Here the restart is folded into the AUTOMATON: a state of the transducer is
+// either a state m of the lengths automaton above with no match pending, or a triple (m, s, k) -- m has a match pending, whose last
+// accepting char lies k chars back, and s is the "shadow": where a search restarted at that match's end stands by now.  When m dies
+// the transition EMITS the match (code = which (length, k): end = index of the killing char - k, start = end - length) and leads
+// to the shadow's successor, which IS the reference's restarted search, already past the chars in between.  One table lookup per
+// char, every lane at the same char.  Exact when a shadow never accepts while its main walk still lives with a match pending
+// (checked transition by transition while the product is built: `international|inter|nation` is refused -- "nation" accepts
+// inside a live "international") and the codes fit 4 bits, the states 12: table entry = state << 4 | code.
+// Column layout of the rows: the reference classes, OVER, PAD (the row's end: emits what is pending; leads to the dead state 0).
+// empty blob: not available (the one-pass kernel stays).  hdr: mode MODE_TABLE16, ft_on = 1, ft_codes_off = LDS offset of
+// uint16 codes[16] = length | k << 8, start = the start state, pad_col, window addressing as for the scan kernels' tables.
+Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget);
+
 } // namespace needle

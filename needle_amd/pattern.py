@@ -216,6 +216,23 @@ class Pattern:
         return {"n_states": n.value, "n_dead": nd.value, "max_char": mc.value, "table": table.reshape(n.value, stride + 1),
                 "accepting": acc.astype(bool), "pend": pend}
 
+    def find_all_transducer(self, char_width=1):
+        """The device program of the find-all transducer (needle_pattern_find_all_transducer: lock-step find-all), or None when the
+        pattern has none -> {"n_states", "n_cols", "pad_col", "start", "window", "win_lo_e", "win_hi_e", "off_table", "codes_off",
+        "lds_bytes", "n_pages", "blob": uint8[lds_bytes]}."""
+        L = _lib.lib()
+        avail, need = ctypes.c_int32(0), ctypes.c_size_t(0)
+        info = (ctypes.c_int32 * 12)()
+        _check(L.needle_pattern_find_all_transducer(self._h, int(char_width), ctypes.byref(avail), info, None, 0, ctypes.byref(need)))
+        if not avail.value:
+            return None
+        blob = np.zeros(need.value, dtype=np.uint8)
+        _check(L.needle_pattern_find_all_transducer(self._h, int(char_width), ctypes.byref(avail), info, blob.ctypes.data, blob.size, ctypes.byref(need)))
+        keys = ["n_states", "n_cols", "pad_col", "start", "window", "win_lo_e", "win_hi_e", "off_table", "codes_off", "lds_bytes", "n_pages"]
+        out = {k: int(info[i]) for i, k in enumerate(keys)}
+        out["blob"] = blob
+        return out
+
     def tables(self):
         """The pattern's tables in the reference layout (class map, stride, 4 x (table, accepting, max_char))."""
         inf = self.info()

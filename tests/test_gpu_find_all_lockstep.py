@@ -1,0 +1,114 @@
+"""SURVEY.md s8f-1 on the device, in LOCK-STEP: needle_find_all_* / needle_count_matches_dev through the find-all transducer
+(needle_amd/csrc/needle_find_all_ls.hip, needle_lower.h) against the CPU oracle's repeated find() (oracle/walker.py find_all: the
+reference's Matcher.find() with its nextStart cursor, DFAClassBuilder.java:616-659) -- bit-exact counts, starts, ends and `more`
+flag, in every result form (two arrays, one dword per match, counting pass, compact filing), on full and ragged rows, strides that
+are and are not whole tiles, batches that end inside a 64-row group, 8- and 16-bit rows, matches pending at the row's end.
+NEEDLE_FIND_ALL_LOCKSTEP is read once per process: the same checks run with it off (the per-lane one-pass kernel) in a child."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from needle_amd import workload as W
+from needle_amd.pattern import DFACompiler
+from test_compile_matches_txt import oracle_for
+lockstep = int(sys.argv[1])
+dev = "cuda"
+def check(p, o, rows, lens, tag, every=1):
+    n = rows.shape[0]
+    host = rows.cpu().numpy()
+    if host.dtype == np.int16:
+        host = host.view(np.uint16)
+    hl = None if lens is None else lens.cpu().numpy()
+    idx = list(range(0, n, every))
+    want = {i: o.find_all(host[i] if hl is None else host[i, :hl[i]]) for i in idx}
+    most = max([len(w) for w in want.values()] + [1])
+    total = 0
+    for slots in (most + 1, 2):
+        counts, st, en, more = p.find_all_dense(rows, slots, lens)
+        c2, se, more2 = p.find_all_dense_packed16(rows, slots, lens)
+        torch.cuda.synchronize()
+        counts, st, en = counts.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+        assert (c2.cpu().numpy() == counts).all() and more2 == more, (tag, "packed counts")
+        sev = se.cpu().numpy().view(np.uint32)
+        filed = np.arange(slots)[None, :] < counts[:, None]
+        assert ((sev & 0xFFFF)[filed] == st[filed]).all() and ((sev >> 16)[filed] == en[filed]).all(), (tag, "packed form")
+        assert (st[~filed] == -1).all() and (en[~filed] == -1).all(), (tag, "slots beyond the count are untouched")
+        for i, w in want.items():
+            k = min(len(w), slots)
+            assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == w[:k], (tag, slots, i, counts[i], st[i].tolist(), en[i].tolist(), w[:8])
+        if every == 1:
+            assert bool(more) == (most > slots), (tag, more, most, slots)
+        if slots > most:
+            total = int(counts.sum())
+            cnt = p.count_matches_batch(rows, lens).cpu().numpy()
+            assert (cnt == counts).all(), (tag, "count pass")
+            offs, s1, e1 = p.find_all_csr(rows, lens)
+            offs, s1, e1 = offs.cpu().numpy(), s1.cpu().numpy(), e1.cpu().numpy()
+            assert (np.diff(offs) == counts).all() and offs[-1] == counts.sum() == len(s1), (tag, "csr offsets")
+            assert (s1 == st[filed]).all() and (e1 == en[filed]).all(), (tag, "csr matches")
+    return total
+total = 0
+# ---- the bench dictionary (C3: 1000 keywords of 3..5 chars; the transducer is 1464 states in window layout)
+words = W.keywords(1000)
+rx = "|".join(words)
+p = DFACompiler.compile(rx, "t", 0)
+o, _ = oracle_for(rx, 0)
+assert p.find_all_transducer(1) is not None and p.find_all_transducer(2) is not None
+kw = [torch.tensor([ord(c) for c in w], dtype=torch.uint8, device=dev) for w in words[:4]]
+for stride, n in ((256, 64 * 40 + 13), (64, 64 * 50 + 7), (192, 64 * 20 + 63), (1040, 64 * 6 + 1), (256, 70), (16, 64 * 30 + 5), (80, 64 * 9)):
+    rows = W.keyword_batch(torch, words, 3, n, stride, device=dev)
+    rows[::11, stride - len(kw[0]):] = kw[0]          # a keyword that ends with the row: pending at the row's end
+    rows[5::11, stride - len(kw[1]) + 1:] = kw[1][:-1]  # one the row's end cuts
+    rows[7::11, :len(kw[2])] = kw[2]                    # one at the very start
+    total += check(p, o, rows, None, ("c3", stride, n, "full"), every=3)
+    lens = (torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 % (stride + 1)).to(torch.int32)
+    total += check(p, o, rows, lens, ("c3", stride, n, "ragged"), every=3)
+    if stride >= 64:
+        total += check(p, o, rows.to(torch.int16), None, ("c3 utf16", stride, n), every=7)
+assert total > 20000, total
+# ---- small patterns: several match lengths, matches that stay pending while a longer alternative lives (codes with k > 0),
+# adjacent and overlapping candidates, one-length patterns; random text over the pattern's own letters
+rng = np.random.default_rng(3)
+for rx in ["abc|bcd|cdefg|a|xyzzy|zzy", "(foo|foobar|bar|barbaz|baz)x?", "ab|abcd|cdx|dxyz", "Sherlock|Holmes|Watson|Irene|Adler|John|Baker",
+           "abcdef|bcd|cdefgh|f", "Sherlock", "aab|ab|b", "[ab]c|a[bc]d|[abc]{4}", "abcdefgh|abcd", "a.c|ab"]:
+    p = DFACompiler.compile(rx, "t", 0)
+    o, _ = oracle_for(rx, 0)
+    assert p.find_all_transducer(1) is not None, rx
+    alpha = np.array(sorted(set(ord(c) for c in rx if c.isalnum())) + [32, 10, 200], dtype=np.uint8)
+    for stride, n in ((128, 64 * 6 + 3), (48, 64 * 4 + 9), (320, 130)):
+        host = alpha[rng.integers(0, len(alpha), size=(n, stride))]
+        rows = torch.from_numpy(host).to(dev)
+        total += check(p, o, rows, None, (rx, stride, "full"), every=2)
+        lens = torch.from_numpy(rng.integers(0, stride + 1, size=n).astype(np.int32)).to(dev)
+        total += check(p, o, rows, lens, (rx, stride, "ragged"), every=2)
+        if stride != 48:
+            total += check(p, o, rows.to(torch.int16), lens, (rx, stride, "utf16 ragged"), every=5)
+# ---- a pattern WITHOUT a transducer keeps the one-pass kernel whatever the switch says
+rx = "international|inter|nation|qrstuvwxyzab"
+p = DFACompiler.compile(rx, "t", 0)
+o, _ = oracle_for(rx, 0)
+assert p.find_all_transducer(1) is None
+pieces = ["international", "inter", "nation", "internationa", " ", "x", "tion"]
+host = np.full((300, 128), 32, dtype=np.uint8)
+for r in range(300):
+    s_ = "".join(pieces[k] for k in rng.integers(0, len(pieces), size=40))[:128]
+    host[r, :len(s_)] = np.frombuffer(s_.encode(), dtype=np.uint8)
+total += check(p, o, torch.from_numpy(host).to(dev), None, ("no transducer",))
+print("LOCKSTEP-FIND-ALL-OK", lockstep, total)
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"NEEDLE_FIND_ALL_LOCKSTEP": "0"}, {"NEEDLE_WINDOW": "0"}, {"NEEDLE_FIND_ALL_SHAPE": "8x64"}],
+                         ids=["lock-step", "off: one-pass kernel", "lock-step, column maps", "lock-step, 8 waves"])
+def test_find_all_every_form_vs_oracle(env):
+    on = env.get("NEEDLE_FIND_ALL_LOCKSTEP", "1")
+    r = subprocess.run([sys.executable, "-c", CODE, on], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert "LOCKSTEP-FIND-ALL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
