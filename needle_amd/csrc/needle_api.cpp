@@ -22,6 +22,7 @@ hipError_t launch_scan(int op, int char_width, const ScanArgs &a, int n_cus, hip
 bool shape_for_program(const ProgHeader &h, int char_width, int *waves, int *chb, int *tiles_in_f_rows);
 hipError_t launch_find_all(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream); // needle_find_all.hip
 hipError_t launch_find_all_lockstep(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream); // needle_find_all_ls.hip
+bool find_all_lockstep_shape_ok(const FindAllArgs &fa);
 hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, const int32_t *s, const int32_t *e, int32_t *cursor,
                                    uint32_t *counts, int32_t *starts, int32_t *ends, int32_t *any_hit, int n_cus, hipStream_t stream);
 hipError_t launch_long_rows(int char_width, const StripeArgs &a, int n_cus, hipStream_t stream);
@@ -1457,7 +1458,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     // LOCK-STEP: one table lookup per char, every lane at the same char, the restarts folded into the automaton (needle_find_all_ls.hip).
     // NEEDLE_FIND_ALL_LOCKSTEP=0: off (A/B, tests: the per-lane one-pass kernel below).
     static const bool lockstep_on = !(getenv("NEEDLE_FIND_ALL_LOCKSTEP") && atoi(getenv("NEEDLE_FIND_ALL_LOCKSTEP")) == 0);
-    if (lockstep_on && lengths_on) {
+    if (lockstep_on && lengths_on && slots < (1u << 23) && stride_bytes < (1ull << 23)) { // (find_all_lockstep_shape_ok)
         const DevProgram *tp = nullptr;
         int cus = 0;
         rc = get_program(p, W_FORWARDS, (int)v->char_width, 8, &tp, &cus);

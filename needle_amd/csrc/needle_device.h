@@ -106,9 +106,11 @@ struct ProgHeader {
                          // then 64 KB and a char's column is ONE lookup at the char itself; the two-level lookup still gives
                          // the same answer, so kernels that do not know the flag stay correct)
     // find-all transducer programs (needle_lower.h lower_find_all_transducer; walked by needle_find_all_ls.hip): table entries are
-    // state << 4 | code, code != 0 = "this transition ends a match"; codes[code] = length | k << 8 (uint16, LDS at ft_codes_off):
-    // end = index of the char that took the transition - k, start = end - length.  State 0 = dead (row finished).
-    uint32_t ft_on, ft_codes_off;
+    // state << 4 | code, code != 0 = "this transition ends a match"; codes[code] = (k + length) | k << 16 (uint32, LDS at ft_codes_off):
+    // end = index of the char that took the transition - k, start = end - length.  State 0 = dead (row finished).  ft_odd: at most 8
+    // codes, numbered 1, 3, .. 15 (bit 0 of an entry = "a match ends here").
+    // ft_direct: every code has k = 0 and is its own length (1 .. 15): no table lookup when a match is filed.
+    uint32_t ft_on, ft_codes_off, ft_odd, ft_direct;
     uint32_t off_bpack;  // != 0: the backward automaton has <= 5 states and rides along as packed functions: 8-bit rows
                          // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)
                          // followed by its F area.  The backward walk then needs no state-dependent lookup.

@@ -101,10 +101,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
 
     // ---- per-group (per-row) state
     uint64_t my_row = 0;
-    bool row_ok = false, more_f = false;
-    uint32_t len = 0, n_chunks = 1, e = 0, count = 0;
-    uint64_t out0 = 0; // index of this row's first result slot (dense: row * slots; compact: offsets[row])
-    uint32_t cap = 0;  // matches this row may file
+    bool row_ok = false;
+    uint32_t len = 0, n_chunks = 1, e = 0;
+    uint32_t count = 0; // matches of this row so far -- ALL of them; the first `cap` are filed
+    uint32_t cap = 0;   // matches this row may file
+    // Result addressing: a wave-uniform 64-bit base per group (SGPRs: the group's first slot) + a 32-bit byte offset per lane --
+    // the stores take the saddr form, one VALU op per match for the address (launch_find_all_lockstep keeps the shapes whose
+    // per-group offsets could outgrow 32 bits on the one-pass kernel)
+    uint64_t gbase = 0; // index of the group's first result slot (dense: first row * slots; compact: offsets[first row])
+    uint32_t voff = 0;  // (this row's first slot - gbase) * 4
 
     auto begin_group = [&](uint64_t grp) __attribute__((always_inline)) {
         my_row = (grp << 6) + lane;
@@ -117,48 +122,67 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
         if (n_chunks == 0) n_chunks = 1;
         e = row_ok ? e_start : 0u;
         count = 0;
-        out0 = my_row * fa.slots;
+        gbase = (grp << 6) * fa.slots;
+        voff = (uint32_t)lane * fa.slots * 4u;
         cap = fa.count_only ? 0xFFFFFFFFu : fa.slots;
         if (fa.offsets) {
-            out0 = row_ok ? fa.offsets[my_row] : 0;
-            cap = row_ok ? (uint32_t)(fa.offsets[my_row + 1] - out0) : 0u;
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cap)); // (as for len above: no vmcnt wait inside the walk)
+            const uint64_t o0 = row_ok ? fa.offsets[my_row] : 0ull;
+            const uint64_t o1 = row_ok ? fa.offsets[my_row + 1] : 0ull;
+            gbase = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(o0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o0);
+            voff = (uint32_t)(o0 - gbase) * 4u; // (lane 0 is the group's first row: always there)
+            cap = (uint32_t)(o1 - o0);
         }
     };
-    // One match (the lanes of `hit`): the reference's find() returned true with these start() / end() (:640-657)
-    auto file = [&](bool hit, uint32_t start, uint32_t end) __attribute__((always_inline)) {
-        const bool f = hit && count < cap;
-        more_f = more_f || (hit && !f);
-        if (f && !fa.count_only) {
+    // One match (the lanes of `hit`): the reference's find() returned true with start() = pos - (d & 0xFFFF), end() = pos - (d >> 16)
+    // (:640-657).  d = codes[code] = (k + length) | k << 16 (needle_device.h).  Stores in the saddr form: uniform base + 32-bit lane offset.
+    auto store32 = [&](const void *base, uint32_t off, uint32_t val) __attribute__((always_inline)) {
+        asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(val), "s"(base) : "memory");
+    };
+    auto file = [&](bool hit, uint32_t pos, uint32_t d) __attribute__((always_inline)) {
+        if (hit && count < cap && !fa.count_only) {
+            const uint32_t off = voff + count * 4u;
             if (fa.packed) {
-                fa.packed[out0 + count] = start | (end << 16);
+                store32(fa.packed + gbase, off, __umul24(pos, 0x10001u) - d); // start | end << 16
             } else {
-                fa.starts[out0 + count] = (int32_t)start;
-                fa.ends[out0 + count] = (int32_t)end;
+                store32(fa.starts + gbase, off, pos - (d & 0xFFFFu));
+                store32(fa.ends + gbase, off, pos - (d >> 16));
             }
         }
-        count += f ? 1u : 0u;
+        count += hit ? 1u : 0u;
     };
     // The match codes of 8 consecutive chars (char j of them in nibble j of h; pos0 = row index of char 0)
+    const bool direct_codes = a.hdr.ft_direct != 0u; // wave-uniform: codes are lengths (k = 0)
+    const bool odd_codes = a.hdr.ft_odd != 0u; // wave-uniform: at most 8 codes, all odd -- bit 0 of a nibble = "a match ends here"
     auto decode = [&](uint32_t h, uint32_t pos0) __attribute__((always_inline)) {
         if (__ballot(h != 0u) == 0ull) return;
-        if (fa.count_only) { // wave-uniform: nothing is filed, no limit
-            uint32_t t = h | (h >> 1);
+        uint32_t t = h; // bit 4j: char j ends a match
+        if (!odd_codes) {
+            t |= t >> 1;
             t |= t >> 2;
-            count += (uint32_t)__builtin_popcount(t & 0x11111111u);
+        }
+        t &= 0x11111111u;
+        if (fa.count_only) { // wave-uniform: nothing is filed, no limit
+            count += (uint32_t)__builtin_popcount(t);
+            return;
+        }
+        if (direct_codes) { // wave-uniform: the code is the match's length, k = 0 -- no lookup on the filing chain
+            do {
+                const bool has = t != 0u;
+                uint32_t b; // bit index of the next match's nibble (lanes that have none: 0xFFFFFFFF -- nothing filed)
+                asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"(t));
+                t &= t - 1u;
+                file(has, pos0 + (b >> 2), __builtin_amdgcn_ubfe(h, b, 4));
+            } while (__ballot(t != 0u) != 0ull);
             return;
         }
         do {
-            const bool has = h != 0u;
-            uint32_t t = h | (h >> 1);
-            t |= t >> 2;
-            const uint32_t b = (uint32_t)__builtin_ctz((t & 0x11111111u) | 0x10000000u); // bit index of the lowest non-zero nibble
-            const uint32_t code = (h >> b) & 15u;
-            h &= ~(15u << b);
-            const uint32_t lk = lds_u16(codes_off + code * 2u); // length | k << 8
-            const uint32_t end = pos0 + (b >> 2) - (lk >> 8);
-            file(has, end - (lk & 255u), end);
-        } while (__ballot(h != 0u) != 0ull);
+            const bool has = t != 0u;
+            uint32_t b;
+            asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"(t));
+            t &= t - 1u;
+            const uint32_t d = lds_u32(codes_off + (__builtin_amdgcn_ubfe(h, b, 4) << 2));
+            file(has, pos0 + (b >> 2), d);
+        } while (__ballot(t != 0u) != 0ull);
     };
 
     // Walk the tile in LDS: chars [ck * CHB / CW, ..) of every row of the group.  Returns the lanes still alive.
@@ -189,14 +213,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
         // there and sit in the dead state, whose PAD entry is 0)
         const uint32_t ee = lds_u16(__umul24(e >> 4, wk.ncols_e) + wk.pad_e + tbase);
         const uint32_t code = ee & 15u;
-        if (__ballot(code != 0u) != 0ull) {
-            const uint32_t lk = lds_u16(codes_off + code * 2u);
-            const uint32_t end = len - (lk >> 8);
-            file(code != 0u, end - (lk & 255u), end);
-        }
-        if (row_ok && fa.counts) fa.counts[my_row] = count;
-        if (__ballot(more_f) != 0ull && lane == 0) *fa.more = 1;
-        more_f = false;
+        if (__ballot(code != 0u) != 0ull) file(code != 0u, len, lds_u32(codes_off + (code << 2)));
+        if (row_ok && fa.counts) fa.counts[my_row] = count < cap ? count : cap;
+        if (__ballot(count > cap) != 0ull && lane == 0) *fa.more = 1;
     };
 
     uint64_t last_group = n_groups - 1; // first group handled by the clamped tail below (as in scan_kernel)
@@ -269,10 +288,16 @@ static hipError_t launch_ls_h(const FindAllArgs &fa, int chb, int grid, int wave
     return chb == 128 ? launch_ls<CW, GUARD, 128>(fa, grid, waves, lds, s) : launch_ls<CW, GUARD, 64>(fa, grid, waves, lds, s);
 }
 
+// The kernel forms a match's result address as (uniform 64-bit group base) + (32-bit byte offset of the lane's row inside the group):
+// dense slots: 64 rows x slots x 4 B; compact filing: the group's matches x 4 B -- at most one match per char.
+bool find_all_lockstep_shape_ok(const FindAllArgs &fa) {
+    return (uint64_t)fa.slots < (1ull << 23) && fa.s.stride_bytes < (1ull << 23);
+}
+
 // One persistent workgroup per CU; the shape (waves x tile bytes) follows the transducer's LDS footprint.
 hipError_t launch_find_all_lockstep(int char_width, const FindAllArgs &fa, int n_cus, hipStream_t stream) {
     if (fa.s.n_rows == 0) return hipSuccess;
-    if (!fa.s.hdr.ft_on) return hipErrorInvalidValue;
+    if (!fa.s.hdr.ft_on || !find_all_lockstep_shape_ok(fa)) return hipErrorInvalidValue;
     const size_t p = (fa.s.hdr.lds_bytes + 15u) & ~15u, cap = 160u * 1024u;
     static const int cand[7][2] = {{16, 128}, {16, 64}, {14, 64}, {12, 64}, {10, 64}, {8, 64}, {4, 64}};
     int waves = 0, chb = 0;

@@ -1381,8 +1381,28 @@ Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, in
         const uint8_t *b = (const uint8_t *)out.data();
         p.blob.insert(p.blob.end(), b, b + out.size() * 2);
     }
-    uint16_t ct[16] = {0};
-    for (const auto &kv : codes) ct[kv.second] = (uint16_t)(kv.first.first | kv.first.second << 8);
+    // codes[code] = (k + length) | k << 16: a match filed at char index pos is [pos - (k + length), pos - k) -- in the one-dword form
+    // pos * 0x10001 - codes[code].  With at most 8 codes they are numbered 1, 3, .. 15: bit 0 of a log nibble then says "a match
+    // ends here" and the kernel finds its next one with one and + one find-first-bit (ft_odd).
+    // ft_direct: every code has k = 0 and a length below 16 (keyword unions whose accepting states die on every char): the code IS
+    // the length -- the kernel files a match without a table lookup.
+    bool direct = true;
+    for (const auto &kv : codes) direct = direct && kv.first.second == 0 && kv.first.first >= 1 && kv.first.first <= 15;
+    const bool odd = !direct && codes.size() <= 8;
+    uint32_t ct[16] = {0};
+    auto renum = [&](int c, int L) { return direct ? L : odd ? 2 * c - 1 : c; };
+    std::vector<int> code_to(16, 0);
+    for (const auto &kv : codes) {
+        code_to[kv.second] = renum(kv.second, kv.first.first);
+        ct[code_to[kv.second]] = (uint32_t)(kv.first.first + kv.first.second) | (uint32_t)kv.first.second << 16;
+    }
+    {
+        uint16_t *cells = (uint16_t *)(p.blob.data() + (p.blob.size() - out.size() * 2));
+        for (size_t i = 0; i < out.size(); ++i)
+            if (cells[i] & 15u) cells[i] = (uint16_t)((cells[i] & ~15u) | (uint32_t)code_to[cells[i] & 15u]);
+    }
+    p.hdr.ft_odd = odd ? 1u : 0u;
+    p.hdr.ft_direct = direct ? 1u : 0u;
     p.hdr.ft_codes_off = append(p.blob, ct, sizeof(ct));
     while (p.blob.size() % 16) p.blob.push_back(0);
     if (p.blob.size() > lds_table_budget || p.blob.size() + 4u * 64u * 64u > 160u * 1024u) { // (no room beside even 4 waves of tiles)

@@ -85,7 +85,7 @@ Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char
 // inside a live "international") and the codes fit 4 bits, the states 12: table entry = state << 4 | code.
 // Column layout of the rows: the reference classes, OVER, PAD (the row's end: emits what is pending; leads to the dead state 0).
 // empty blob: not available (the one-pass kernel stays).  hdr: mode MODE_TABLE16, ft_on = 1, ft_codes_off = LDS offset of
-// uint16 codes[16] = length | k << 8, start = the start state, pad_col, window addressing as for the scan kernels' tables.
+// uint32 codes[16] = (k + length) | k << 16 (ft_odd: at most 8 codes, numbered 1, 3, .. 15), start = the start state, pad_col, window addressing as for the scan kernels' tables.
 Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget);
 
 } // namespace needle

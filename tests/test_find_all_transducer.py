@@ -26,9 +26,8 @@ def walk_blob(ft, text, cw=1):
             return u16(2 * c)  # cmap16 at 0
         return int(b[512 + u16(2 * (c >> 8)) + (c & 255)])  # ptab16 at 0 (page * 256), pages at 512 (column * 2)
     def emit(code, pos, out):
-        lk = u16(ft["codes_off"] + 2 * code)
-        end = pos - (lk >> 8)
-        out.append((end - (lk & 255), end))
+        d = u16(ft["codes_off"] + 4 * code) | u16(ft["codes_off"] + 4 * code + 2) << 16  # (k + length) | k << 16
+        out.append((pos - (d & 0xFFFF), pos - (d >> 16)))
     e, out = ft["start"] << 4, []
     for pos, c in enumerate(text):
         e = u16(tbase + (e >> 4) * ncols_e + col_of(int(c)))
@@ -74,8 +73,8 @@ def test_transducer_of_the_bench_dictionary(oracle_lib):
     ft = p.find_all_transducer(1)
     ml = p.match_length_automaton()
     assert ft is not None and ft["window"] == 1 and ft["n_states"] <= ml["n_states"] and ft["lds_bytes"] + 16 * 64 * 64 <= 160 * 1024
-    codes = [int(ft["blob"][ft["codes_off"] + 2 * c]) | int(ft["blob"][ft["codes_off"] + 2 * c + 1]) << 8 for c in range(1, 16)]
-    assert sorted(c for c in codes if c) == [3, 4, 5]
+    codes = [int(ft["blob"][ft["codes_off"] + 4 * c]) | int(ft["blob"][ft["codes_off"] + 4 * c + 1]) << 8 for c in range(16)]
+    assert sorted(c for c in codes if c) == [3, 4, 5] and all(codes[c] in (0, c) for c in range(16))  # (k = 0 throughout: a code IS its length)
     o, _ = oracle_for("|".join(words), 0)
     rows = W.keyword_batch(np, words, 5, 200, 256)
     lens = (np.arange(len(rows)) * 37 % 257)

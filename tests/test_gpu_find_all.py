@@ -64,7 +64,8 @@ print("FIND-ALL-OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env,mode", [({}, 2), ({"NEEDLE_FIND_ALL_WINDOW": "0"}, 2), ({"NEEDLE_FIND_ALL_LENGTHS": "0"}, 2), ({"NEEDLE_FIND_ALL_LENGTHS": "0", "NEEDLE_FIND_ALL_DEFER": "0"}, 2),
+@pytest.mark.parametrize("env,mode", [({}, 2), ({"NEEDLE_WINDOW": "0"}, 2),
+                                      ({"NEEDLE_FIND_ALL_LOCKSTEP": "0"}, 2), ({"NEEDLE_FIND_ALL_LOCKSTEP": "0", "NEEDLE_FIND_ALL_WINDOW": "0"}, 2), ({"NEEDLE_FIND_ALL_LENGTHS": "0"}, 2), ({"NEEDLE_FIND_ALL_LENGTHS": "0", "NEEDLE_FIND_ALL_DEFER": "0"}, 2),
                                       ({"NEEDLE_FIND_ALL_ROUNDS": "1"}, 2),
                                       ({"NEEDLE_MAX_PROG_LDS": "4096", "NEEDLE_HYBRID": "0"}, 3),
                                       ({"NEEDLE_MAX_PROG_LDS": "4096"}, 5), ({"NEEDLE_MAX_PROG_LDS": "20000", "NEEDLE_SPARSE": "0"}, 5),
@@ -72,13 +73,14 @@ print("FIND-ALL-OK")
                                       ({"NEEDLE_MAX_PROG_LDS": "12000", "NEEDLE_WINDOW": "0", "NEEDLE_FIND_ALL_LENGTHS": "2"}, 6),
                                       ({"NEEDLE_MAX_PROG_LDS": "20000", "NEEDLE_FIND_ALL_ROUNDS": "1"}, 6),
                                       ({"NEEDLE_MAX_PROG_LDS": "12000", "NEEDLE_FIND_ALL_ROUNDS": "1", "NEEDLE_WINDOW": "0"}, 6)],
-                         ids=["one-pass-lengths", "one-pass-lengths-column-maps", "one-pass-backward-walks", "starts-at-once", "rounds", "hbm-table", "hot-rows-4k", "hot-rows-20k",
+                         ids=["lock-step", "lock-step-column-maps", "one-pass-lengths", "one-pass-lengths-column-maps", "one-pass-backward-walks", "starts-at-once", "rounds", "hbm-table", "hot-rows-4k", "hot-rows-20k",
                               "one-pass-compressed-lengths", "one-pass-compressed-lengths-cmap",
                               "rounds-compressed-automaton", "rounds-compressed-automaton-cmap"])
 def test_keyword_dictionary_every_match(env, mode):
     """A 300-keyword union (779 states, uint16 table) over 3000 rows of 256 chars: one to two matches per row, up to 8.
-    Children: the one-pass kernel with start = end - the length its end state remembers (default for such a dictionary:
-    needle_lower.h, MatchLengths), with the starts found by indexBackwards group by group or match by match, the round-per-match form,
+    Children: the lock-step kernel on the find-all transducer (the default for such a dictionary: needle_find_all_ls.hip; window
+    addressing or column maps), the per-lane one-pass kernel with start = end - the length its end state remembers (needle_lower.h,
+    MatchLengths), with the starts found by indexBackwards group by group or match by match, the round-per-match form,
     and the automaton forced out of the LDS (whole table in HBM; hot rows in LDS + HBM table; the compressed automaton -- in the
     one-pass kernel as the compressed LENGTHS program, window addressing or column maps, and in the round-per-match form, whose
     guarded kernels then carry the per-row cursors)."""
