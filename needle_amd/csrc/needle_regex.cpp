@@ -30,12 +30,14 @@
 #include "needle_unicode_tables.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <climits>
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <thread>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -813,19 +815,53 @@ struct StateSet { // StateSet.java
     std::vector<SItem> items; // insertion order of the `states` HashSet
     JOrder jo;
     bool seen_accepting = false;
-    std::vector<int> slot; // key -> index in items (-1), sized lazily
-    int universe = 0;
-    explicit StateSet(int n) : universe(n) {}
-    int find(int k) const { return slot.empty() ? -1 : slot[k]; }
+    // key -> index in items: a small open-addressing table sized by the SET, not by the program (a 3000-keyword dictionary's search
+    // automaton has 12 000 states x 28 ranges, each a fresh set over a 25 000-instruction program: an array per set indexed by
+    // instruction was 100 GB of memset per compile)
+    std::vector<int32_t> ht; // index + 1; 0 = empty; size a power of two
+    uint64_t hsum = 0, hxor = 0; // order-independent fingerprint of the key set (SubsetBuilder::lookup)
+    explicit StateSet(int) {}
+    static uint64_t mix(uint64_t k) {
+        k += 0x9E3779B97F4A7C15ull;
+        k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull;
+        k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
+        return k ^ (k >> 31);
+    }
+    int find(int k) const {
+        if (ht.empty()) return -1;
+        const size_t mask = ht.size() - 1;
+        for (size_t h = (size_t)mix((uint64_t)k) & mask;; h = (h + 1) & mask) {
+            const int32_t v = ht[h];
+            if (v == 0) return -1;
+            if (items[v - 1].key == k) return v - 1;
+        }
+    }
+    void rehash(size_t cap) {
+        ht.assign(cap, 0);
+        const size_t mask = cap - 1;
+        for (size_t i = 0; i < items.size(); ++i) {
+            size_t h = (size_t)mix((uint64_t)items[i].key) & mask;
+            while (ht[h]) h = (h + 1) & mask;
+            ht[h] = (int32_t)i + 1;
+        }
+    }
     void add(int k, int dist, int prio) { // :16-27
-        if (slot.empty()) slot.assign(universe, -1);
-        const int i = slot[k];
+        const int i = find(k);
         if (i >= 0) {
             if (items[i].dist < dist) { items[i].dist = dist; items[i].prio = prio; }
             return;
         }
-        slot[k] = (int)items.size();
         items.push_back(SItem{k, dist, prio});
+        const uint64_t m = mix((uint64_t)k);
+        hsum += m;
+        hxor ^= mix(m);
+        if (items.size() * 2 > ht.size()) rehash(ht.empty() ? 16 : ht.size() * 4);
+        else {
+            const size_t mask = ht.size() - 1;
+            size_t h = (size_t)m & mask;
+            while (ht[h]) h = (h + 1) & mask;
+            ht[h] = (int32_t)items.size();
+        }
         jo.on_insert();
     }
     bool prune(int accepting_state, int boundary, int priority) { // :37-53
@@ -834,13 +870,17 @@ struct StateSet { // StateSet.java
         for (const SItem &it : items) {
             if (it.key != accepting_state && (it.dist < boundary || priority < it.prio)) {
                 removed = true;
-                slot[it.key] = -1;
+                const uint64_t m = mix((uint64_t)it.key);
+                hsum -= m;
+                hxor ^= mix(m);
                 jo.on_remove();
             } else keep.push_back(it);
         }
         if (removed) {
             items.swap(keep);
-            for (size_t i = 0; i < items.size(); ++i) slot[items[i].key] = (int)i;
+            size_t cap = 16;
+            while (cap < items.size() * 2) cap *= 2;
+            rehash(cap);
         }
         return removed;
     }
@@ -857,6 +897,7 @@ class SubsetBuilder { // NFAToDFACompiler.java
     explicit SubsetBuilder(const std::vector<Instr> &p) : prog(p), n((int)p.size()), closure_cache(p.size()), closure_done(p.size(), 0) {}
     Dfa compile(ConvMode mode) {
         Dfa dfa;
+        if (mode != BASIC) make_root_template(); // (before the first store(): has_root of the initial set)
         StateSet init(n);
         init.add(0, 0, 1);
         StateSet states = epsilon_closure(init);
@@ -867,31 +908,62 @@ class SubsetBuilder { // NFAToDFACompiler.java
         std::vector<StateSet> pending;
         pending.push_back(std::move(states));
         std::vector<int> order, scratch;
+        double T[8] = {0};
+        long dbg_n[3] = {0, 0, 0};
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        static const bool timing = getenv("NEEDLE_COMPILE_TIMING") != nullptr;
         while (!pending.empty()) {
+            double ta = now();
+            auto lap = [&](int k) { if (timing) { const double tb = now(); T[k] += tb - ta; ta = tb; } };
             StateSet cur = std::move(pending.back());
             pending.pop_back();
             const int dfa_id = lookup(cur);
             if (dfa_id < 0) throw CompileError("internal: popped state set without a DFA state");
             StateSet ec = epsilon_closure(cur);
+            lap(0);
             const bool accepting = ec.seen_accepting;
             if (accepting && mode == CONTAINED_IN) continue;
             if (mode == CONTAINED_IN || (!accepting && mode == DFA_SEARCH)) ec.add(0, 0, 1);
             // findCharRanges over the set in HashSet order, then the coverings
             java_order(ec.items, ec.jo.cap, [](const SItem &s) { return s.key; }, order, scratch);
+            // (exact duplicates dropped, first occurrences kept in order: minimalCovering's output does not depend on them -- a
+            // later copy of a range is covered when its turn comes and clips nothing its original did not -- and a dictionary's
+            // root closure holds thousands of copies of 26 letters: its inner loop is quadratic in the list)
             std::vector<CR> crs;
-            for (int i : order) {
-                const Instr &in = prog[ec.items[i].key];
-                if (in.op == OP_CHAR) crs.push_back(CR{in.start, in.end});
+            {
+                std::map<std::pair<int, int>, char> seen_cr;
+                for (int i : order) {
+                    const Instr &in = prog[ec.items[i].key];
+                    if (in.op == OP_CHAR && seen_cr.emplace(std::make_pair(in.start, in.end), 1).second) crs.push_back(CR{in.start, in.end});
+                }
             }
             const std::vector<CR> ranges = cover_all_chars(minimal_covering(crs));
-            for (const CR &r : ranges) {
-                StateSet tr(n); // transition(epsilonClosure, range.getStart()) :168-178
-                for (int i : order) {
-                    const SItem &it = ec.items[i];
-                    const Instr &in = prog[it.key];
-                    if (in.op == OP_CHAR && in.start <= r.start && in.end >= r.start) tr.add(it.key + 1, it.dist + 1, in.priority);
+            lap(1);
+            // which items move on which range: the ranges partition the chars (sorted, contiguous), a CHAR instruction covers a run of
+            // them -- filed per range in `order` (= the order the reference's loop over the set visits them), instead of testing
+            // every item against every range
+            std::vector<std::vector<int>> movers(ranges.size());
+            for (int i : order) {
+                const Instr &in = prog[ec.items[i].key];
+                if (in.op != OP_CHAR) continue;
+                size_t lo = 0, hi = ranges.size(); // first range whose start >= in.start
+                while (lo < hi) {
+                    const size_t mid = (lo + hi) / 2;
+                    if (ranges[mid].start < in.start) lo = mid + 1;
+                    else hi = mid;
                 }
+                for (size_t k = lo; k < ranges.size() && ranges[k].start <= in.end; ++k) movers[k].push_back(i);
+            }
+            for (size_t ri = 0; ri < ranges.size(); ++ri) {
+                const CR &r = ranges[ri];
+                StateSet tr(n); // transition(epsilonClosure, range.getStart()) :168-178
+                for (int i : movers[ri]) {
+                    const SItem &it = ec.items[i];
+                    tr.add(it.key + 1, it.dist + 1, prog[it.key].priority);
+                }
+                lap(2);
                 StateSet post = epsilon_closure(tr);
+                lap(3);
                 if (!post.seen_accepting) post.seen_accepting = ec.seen_accepting || has_accepting(post);
                 if (post.seen_accepting && (mode == CONTAINED_IN || mode == DFA_SEARCH)) {
                     // prune around the (single) MATCH instruction until nothing is removed :92-106
@@ -902,11 +974,18 @@ class SubsetBuilder { // NFAToDFACompiler.java
                         if (!post.prune(acc, post.items[ai].dist, post.items[ai].prio)) break;
                     }
                 }
+                lap(4);
+                int target = -2;
                 if (!post.seen_accepting && (mode == CONTAINED_IN || mode == DFA_SEARCH)) {
                     post.add(0, 0, 1);
-                    post = epsilon_closure(post);
+                    // (most of these sets exist already: looked up as "the root's closure + these few" without being built)
+                    target = lookup_root_plus(post);
+                    if (timing) { ++dbg_n[0]; dbg_n[1] += target != -2; dbg_n[2] += target >= 0; }
+                    if (target < 0) post = epsilon_closure(post);
                 }
-                int target = lookup(post);
+                lap(5);
+                if (target < 0) target = lookup(post);
+                lap(6);
                 if (target < 0) {
                     target = (int)dfa.st.size();
                     dfa.st.emplace_back();
@@ -915,9 +994,12 @@ class SubsetBuilder { // NFAToDFACompiler.java
                     pending.push_back(std::move(post));
                 }
                 add_transition(dfa.st[dfa_id], r, target);
+                lap(7);
             }
             if (dfa.st.size() > 40000) throw CompileError("Can't compile DFAs with more than 16383 states");
         }
+        if (timing) fprintf(stderr, "[compile]     root sets %ld fast path %ld found %ld\n", dbg_n[0], dbg_n[1], dbg_n[2]);
+        if (timing) fprintf(stderr, "[compile]     closure(cur) %.2f ranges %.2f transition %.2f closure(tr) %.2f prune %.2f root+closure %.2f lookup %.2f store %.2f\n", T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7]);
         return dfa;
     }
 
@@ -925,17 +1007,50 @@ class SubsetBuilder { // NFAToDFACompiler.java
     const std::vector<Instr> &prog;
     int n;
     struct Stored { bool seen_accepting; int dfa; };
-    std::map<std::vector<int>, std::vector<Stored>> sets; // HashMap<StateSet, List<Pair<StateSet, DFA>>>
+    // HashMap<StateSet, List<Pair<StateSet, DFA>>>: looked up by an order-independent fingerprint of the key set (no sort per
+    // lookup); a fingerprint hit is VERIFIED key by key against the stored set before it counts
+    struct SetEntry { std::vector<int> keys; std::vector<Stored> list; bool has_root; };
+    struct Fp {
+        uint64_t a, b;
+        size_t n;
+        bool operator<(const Fp &o) const { return a != o.a ? a < o.a : b != o.b ? b < o.b : n < o.n; }
+    };
+    std::map<Fp, std::vector<SetEntry>> sets;
+    static Fp fp_of(const StateSet &s) { return Fp{s.hsum, s.hxor, s.items.size()}; }
+    static bool same_keys(const StateSet &s, const std::vector<int> &keys) {
+        if (keys.size() != s.items.size()) return false;
+        for (int k : keys)
+            if (s.find(k) < 0) return false;
+        return true;
+    }
     std::vector<std::vector<int>> closure_cache;          // nfa.epsilonClosure(state) in HashSet iteration order
     std::vector<char> closure_done;
 
     bool has_accepting(const StateSet &s) const { return s.find(n - 1) >= 0; }
-    void store(const StateSet &s, int dfa) { sets[s.sorted_keys()].push_back(Stored{s.seen_accepting, dfa}); }
+    void store(const StateSet &s, int dfa) {
+        std::vector<SetEntry> &bucket = sets[fp_of(s)];
+        for (SetEntry &e : bucket)
+            if (same_keys(s, e.keys)) {
+                e.list.push_back(Stored{s.seen_accepting, dfa});
+                return;
+            }
+        SetEntry ne{s.sorted_keys(), {Stored{s.seen_accepting, dfa}}, false};
+        if (root_template_ok) { // (lookup_root_plus: does this set hold the whole closure of the root?)
+            ne.has_root = ne.keys.size() >= root_template.items.size();
+            for (size_t i = 0; ne.has_root && i < root_template.items.size(); ++i)
+                ne.has_root = std::binary_search(ne.keys.begin(), ne.keys.end(), root_template.items[i].key);
+        }
+        bucket.push_back(std::move(ne));
+    }
     int lookup(const StateSet &s) { // getDFA :124-135
-        auto it = sets.find(s.sorted_keys());
+        auto it = sets.find(fp_of(s));
         if (it == sets.end()) return -1;
-        for (const Stored &p : it->second)
-            if (s.items.size() == 1 || s.seen_accepting == p.seen_accepting) return p.dfa;
+        for (const SetEntry &e : it->second) {
+            if (!same_keys(s, e.keys)) continue;
+            for (const Stored &p : e.list)
+                if (s.items.size() == 1 || s.seen_accepting == p.seen_accepting) return p.dfa;
+            return -1;
+        }
         return -1;
     }
     const std::vector<int> &nfa_closure(int state) { // NFA.epsilonClosure :239-266
@@ -965,6 +1080,56 @@ class SubsetBuilder { // NFAToDFACompiler.java
         closure_cache[state] = std::move(out);
         closure_done[state] = 1;
         return closure_cache[state];
+    }
+    // Every non-accepting state of the search automata is epsilon_closure(a closed set + the root, instruction 0), and the root's
+    // closure is the same few thousand instructions every time (a dictionary: the first char of every keyword).  Most of those sets
+    // exist already; lookup_root_plus finds them by fingerprint without building them.  root_template: the root's closure as a set.
+    StateSet root_template{0};
+    std::vector<char> in_root_closure;
+    bool root_template_ok = false, root_template_tried = false;
+    void make_root_template() {
+        if (!root_template_tried) {
+            root_template_tried = true;
+            const std::vector<int> &rc = nfa_closure(0);
+            in_root_closure.assign(n, 0);
+            root_template_ok = true;
+            for (int e : rc) {
+                in_root_closure[e] = 1;
+                if (e == n - 1) root_template_ok = false; // (a nullable pattern: the general path keeps seen_accepting right)
+                root_template.add(e, 0, prog[0].priority);
+            }
+            if (!rc.empty() && rc.size() == 1 && rc[0] == 0) root_template_ok = false; // (instruction 0 is a CHAR: nothing to gain)
+        }
+    }
+    // getDFA for epsilon_closure(states), states = a closed set + the root just added, WITHOUT building that closure: as a SET it
+    // is the root's closure plus the items of `states` that are not in it (iteration order plays no part in set equality), so its
+    // fingerprint is the template's plus those few items'; a stored set of that size which holds the root's whole closure and every
+    // one of the items IS that set.  -1: not there yet (the caller builds it, the exact way); -2: the shortcut does not apply.
+    int lookup_root_plus(const StateSet &states) {
+        make_root_template();
+        if (!root_template_ok) return -2;
+        Fp fp{root_template.hsum, root_template.hxor, root_template.items.size()};
+        for (const SItem &it : states.items) {
+            if (it.key == 0 || in_root_closure[it.key]) continue;
+            if (prog[it.key].op == OP_SPLIT || prog[it.key].op == OP_JUMP || it.key == n - 1) return -2;
+            const uint64_t m = StateSet::mix((uint64_t)it.key);
+            fp.a += m;
+            fp.b ^= StateSet::mix(m);
+            ++fp.n;
+        }
+        auto it = sets.find(fp);
+        if (it == sets.end()) return -1;
+        for (const SetEntry &e : it->second) {
+            if (!e.has_root || e.keys.size() != fp.n) continue;
+            bool all = true;
+            for (const SItem &x : states.items)
+                if (x.key != 0 && !std::binary_search(e.keys.begin(), e.keys.end(), x.key)) { all = false; break; }
+            if (!all) continue;
+            for (const Stored &p : e.list)
+                if (fp.n == 1 || !p.seen_accepting) return p.dfa; // (the set's seen_accepting is false here: no MATCH beside the root)
+            return -1;
+        }
+        return -1;
     }
     StateSet epsilon_closure(const StateSet &states) { // getEpsilonClosure :137-155
         StateSet c(n);
@@ -1172,10 +1337,17 @@ void fill_ref_dfa(const Dfa &d, const ByteClasses &bc, int stride, RefDfa &out) 
 }
 
 Dfa build(const std::vector<Instr> &prog, ConvMode mode) { // NFAToDFACompiler.compile :24-32
+    static const bool timing = getenv("NEEDLE_COMPILE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     SubsetBuilder sb(prog);
     Dfa d = sb.compile(mode);
+    const double t1 = now();
     prune_dead(d);
-    return minimize(d);
+    const double t2 = now();
+    Dfa m = minimize(d);
+    if (timing) fprintf(stderr, "[compile]   subset %.3f s (%zu states)  prune %.3f s  minimise %.3f s (%zu states)\n", t1 - t0, d.st.size(), t2 - t1, now() - t2, m.st.size());
+    return m;
 }
 
 } // namespace
@@ -1199,10 +1371,34 @@ int compile_regex(const std::u16string &regex, int flags, RefTables &out, std::s
             }
         }
         Dfa dfas[4];
-        dfas[W_MATCHES] = build(fwd, BASIC);
-        dfas[W_CONTAINED_IN] = build(fwd, CONTAINED_IN);
-        dfas[W_BACKWARDS] = build(rev, BASIC);
-        dfas[W_FORWARDS] = build(fwd, DFA_SEARCH);
+        static const bool timing = getenv("NEEDLE_COMPILE_TIMING") != nullptr; // developer aid: where a big dictionary's compile time goes
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t0 = now();
+        auto lap = [&](const char *what) {
+            if (timing) fprintf(stderr, "[compile] %-14s %.3f s\n", what, now() - t0);
+            t0 = now();
+        };
+        // the four automata are independent: the two search-mode ones (each state set carries the root's closure: the heavy ones
+        // for a dictionary) are built side by side
+        std::exception_ptr err_ci;
+        std::thread t_ci([&] {
+            try {
+                dfas[W_CONTAINED_IN] = build(fwd, CONTAINED_IN);
+            } catch (...) {
+                err_ci = std::current_exception();
+            }
+        });
+        try {
+            dfas[W_MATCHES] = build(fwd, BASIC);
+            dfas[W_BACKWARDS] = build(rev, BASIC);
+            dfas[W_FORWARDS] = build(fwd, DFA_SEARCH);
+        } catch (...) {
+            t_ci.join();
+            throw;
+        }
+        t_ci.join();
+        if (err_ci) std::rethrow_exception(err_ci);
+        lap("four automata");
         for (const Dfa &d : dfas) // DFACompiler.checkForOverLongDFAs :76-83
             if ((int)d.st.size() > 16383) throw CompileError("Can't compile DFAs with more than 16383 states");
         const ByteClasses bc = byte_classes(dfas[W_FORWARDS]); // DFAClassBuilder.java:66-76: classes of dfaSearch for all four

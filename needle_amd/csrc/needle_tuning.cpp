@@ -48,6 +48,7 @@ const Switch kSwitches[] = {
     {"NEEDLE_SCRATCH_KEEP_MB", "512", "size", "freed scratch memory the library's pool keeps for the next call (needle_trim_scratch hands back the rest)"},
     {"NEEDLE_SPARSE_DEBUG", "(unset)", "debug", "prints the compressed form's sizing to stderr"},
     {"NEEDLE_ML_DEBUG", "(unset)", "debug", "prints why a pattern has no lengths automaton"},
+    {"NEEDLE_COMPILE_TIMING", "(unset)", "debug", "prints where needle_compile's time goes (subset construction, pruning, minimisation per automaton)"},
     {"NEEDLE_DEBUG_NFA", "(unset)", "debug", "dumps the forward Thompson program of needle_compile"},
     {"NEEDLE_DICT", "0", "measurement build", "two 64-row sets per wave for big automata (needle_dict.hip): 1 compressed form, 2 also uint16 tables"},
     {"NEEDLE_NG_DBG", "0", "measurement build", "n-gram filter kernel time breakdown (drops candidates / skips walks: timing only)"},
