@@ -65,6 +65,10 @@ def make_pattern(workload):
         words = W.keywords(1000, min_len=6, max_len=8)
         return (DFACompiler.compile("|".join(words), "Keywords1kSparse"),
                 "union-of-1k-keywords, sparse-match variant (6..8 chars: only the planted 25 % of the rows match) find()", words)
+    if workload == "c3x":
+        words = W.keywords(3000, min_len=6, max_len=8)
+        return (DFACompiler.compile("|".join(words), "Keywords3k"),
+                "union-of-3k-keywords at the reference's state limit (6..8 chars: 12 270 states <= 16 383, DFACompiler.java:76-83; no LDS form fits) find()", words)
     if workload == "c5":
         return DFACompiler.compile(W.script_regex(), "ScriptRuns"), "BMP char-class regex find() over UTF-16", None
     if workload == "c5w":
@@ -84,7 +88,7 @@ def make_rows(workload, words, row0, n_rows, device):
         n = min(slab, n_rows - s)
         if workload == "c2":
             out[s:s + n] = W.digits_batch(torch, row0 + s, n, 256, device=device)
-        elif workload in ("c3", "c3s"):
+        elif workload in ("c3", "c3s", "c3x"):
             out[s:s + n] = W.keyword_batch(torch, words, row0 + s, n, 256, device=device)
         elif workload == "c5w":
             out[s:s + n] = W.scriptseq_batch(torch, row0 + s, n, 256, device=device)
@@ -630,7 +634,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c5", "c5w"], help="the headline workload")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w"], help="the headline workload")
     ap.add_argument("--also", default=None, help="comma list of further workloads measured into \"workloads\" "
                     "(default: c3,c3s,c5,c5w at 1 GPU, c3 at N > 1; 'none' for profiling runs)")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")

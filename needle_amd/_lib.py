@@ -56,7 +56,8 @@ class ProgramInfo(ctypes.Structure):
 
 class PrefilterInfo(ctypes.Structure):
     _fields_ = ([(k, ctypes.c_int32) for k in ("on", "mode", "stride", "warm", "min_len", "n_windows", "bitmap_bytes")] +
-                [(k, ctypes.c_uint32) for k in ("m1", "m2", "addr_shift", "addr_mask")] + [("why", ctypes.c_char * 96)])
+                [(k, ctypes.c_uint32) for k in ("m1", "m2", "addr_shift", "addr_mask")] + [("why", ctypes.c_char * 96)] +
+                [(k, ctypes.c_int32) for k in ("on2", "n_windows2", "bitmap2_bytes")] + [(k, ctypes.c_uint32) for k in ("m3", "addr_mask2")])
 
 
 _lib = None

@@ -154,6 +154,8 @@ struct needle_pattern {
     //          6 the find-all "lengths" automaton (W_FORWARDS only; absent when the pattern does not allow it)
     //          7 the same for find() in the scan kernels
     //          8 the find-all transducer (lock-step find-all, needle_find_all_ls.hip; absent when the pattern does not allow it)
+    //          9 the filter program of an automaton that fits the LDS in no form (lower_filter_hbm: HBM-table layout + n-gram filter;
+    //            W_CONTAINED_IN, or W_FORWARDS in the lengths form / for one-length patterns; absent when no filter can be built)
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
     // needle_pattern_prefilter_info answers (lowering a big dictionary takes seconds): per `which`, filled once
@@ -198,7 +200,8 @@ static const MatchLengths *pattern_ml(const needle_pattern *cp) {
 static int get_program(needle_pattern *p, int which, int cw, int variant, const DevProgram **out, int *n_cus) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    const MatchLengths *ml67 = (variant == 6 || variant == 7 || variant == 8) ? pattern_ml(p) : nullptr; // (before p->mu: see ml_mu)
+    const bool wants_ml = variant == 6 || variant == 7 || variant == 8 || (variant == 9 && which == W_FORWARDS && p->t.fixed_len < 0);
+    const MatchLengths *ml67 = wants_ml ? pattern_ml(p) : nullptr; // (before p->mu: see ml_mu)
     std::lock_guard<std::mutex> lk(p->mu);
     if (!p->cus.count(dev)) {
         hipDeviceProp_t prop;
@@ -210,7 +213,18 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        if (variant == 6 || variant == 7 || variant == 8) { // "lengths" form: the refined forward automaton + pend[] (needle_lower.h);
+        if (variant == 9) {
+            if (wants_ml && !ml67) {
+                *out = nullptr;
+                return NEEDLE_OK;
+            }
+            dp.prog = lower_filter_hbm(p->t, (Which)which, ml67);
+            if (dp.prog.blob.empty() || !dp.prog.ng.p.on) { // (no filter: the ordinary program is what runs)
+                p->cache.emplace(key, DevProgram());
+                *out = nullptr;
+                return NEEDLE_OK;
+            }
+        } else if (variant == 6 || variant == 7 || variant == 8) { // "lengths" form: the refined forward automaton + pend[] (needle_lower.h);
                                             // 6: the find-all kernel's plain layout, 7: the scan kernels' (window addressing);
                                             // 8: the find-all transducer built on it
             if (!ml67) {
@@ -232,9 +246,10 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
             return hip_fail(ce, "hipMemcpy(program blob)");
         }
         if (dp.prog.ng.p.on) {
-            const size_t nb = dp.prog.ng.bitmap.size() * 4;
-            hipError_t ce = hipMalloc((void **)&dp.d_ng, nb);
+            const size_t nb = dp.prog.ng.bitmap.size() * 4, nb2 = dp.prog.ng.p.on2 ? dp.prog.ng.bitmap2.size() * 4 : 0; // (the second level's follows)
+            hipError_t ce = hipMalloc((void **)&dp.d_ng, nb + nb2 + 16);
             if (ce == hipSuccess) ce = hipMemcpy(dp.d_ng, dp.prog.ng.bitmap.data(), nb, hipMemcpyHostToDevice);
+            if (ce == hipSuccess && nb2) ce = hipMemcpy((uint8_t *)dp.d_ng + nb, dp.prog.ng.bitmap2.data(), nb2, hipMemcpyHostToDevice);
             if (ce == hipSuccess) ce = hipMalloc((void **)&dp.d_ng_stats, 8);
             if (ce == hipSuccess) ce = hipMemset(dp.d_ng_stats, 0, 8);
             if (ce == hipSuccess) ce = hipHostMalloc((void **)&dp.h_ng_stats, 8, hipHostMallocDefault);
@@ -543,6 +558,37 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // rows of tens of megabytes and more
     if (v->row_stride * v->char_width >= (1ull << 26))
         return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more are only supported on the stripe paths (automata of at most 5 states, or ones that re-synchronise; not with NEEDLE_LONG_ROWS=0, per-row cursors or empty-matching patterns)");
+    // An automaton that fits the LDS in no form (hot rows + HBM table, or the HBM table alone): containedIn() / find() behind the
+    // n-gram candidate filter with the verify walks out of HBM / L2 (lower_filter_hbm) -- the per-char walk of such an automaton
+    // collapses on text that leaves the hot states (near-miss rows: 20 ms on the 10M-row batch), the filter's does not.
+    if ((fp->prog.hdr.mode == MODE_HYBRID || fp->prog.hdr.mode == MODE_GLOBAL) && v->char_width == 1 && op != OP_MATCHES && !d_from && !d_end_state &&
+        !no_backward && ngram_level() > 0 && dict_env == 0) {
+        const DevProgram *tp = nullptr;
+        rc = get_program(p, which, 1, 9, &tp, nullptr);
+        if (rc) return rc;
+        if (tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0)) {
+            ScanArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rows = (const uint8_t *)v->rows;
+            a.n_rows = v->n_rows;
+            a.stride_bytes = v->row_stride * v->char_width;
+            a.total_bytes = a.n_rows * a.stride_bytes;
+            a.row_len = v->row_len;
+            a.lengths = v->lengths;
+            a.prog = tp->d_blob;
+            a.hdr = tp->prog.hdr;
+            a.fixed_len = op == OP_FIND ? p->t.fixed_len : -1;
+            a.bitmap = d_bitmap;
+            a.start = d_start;
+            a.end = d_end;
+            a.packed = d_packed;
+            if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(tp)) {
+                HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream));
+                HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
+                return NEEDLE_OK;
+            }
+        }
+    }
     // find() whose pattern allows it: the "lengths" automaton -- the state the walk stops in remembers how long the match was,
     // start = end - pend[state], no indexBackwards, no text snapshots (needle_lower.h).  Taken where the ordinary program is a
     // plain LDS table (the modes pend[] can be indexed in).  NEEDLE_FIND_LENGTHS=0: off (A/B, tests).
@@ -1170,6 +1216,14 @@ static int prefilter_info_uncached(const needle_pattern *p, int which, needle_pr
             if (!lp.blob.empty() && !pair_lost) pr = std::move(lp), usable = true;
         }
     }
+    if ((pr.hdr.mode == MODE_HYBRID || pr.hdr.mode == MODE_GLOBAL) && ngram_level() > 0) {
+        // an automaton that fits the LDS in no form: the filter program walks its table out of HBM / L2 (lower_filter_hbm)
+        const MatchLengths *ml = backward ? pattern_ml(p) : nullptr;
+        if (!backward || ml) {
+            Program hp = lower_filter_hbm(p->t, (Which)which, ml);
+            if (!hp.blob.empty() && hp.hdr.mode == MODE_GLOBAL) pr = std::move(hp), usable = true;
+        }
+    }
     const NgramFilter &f = pr.ng;
     o->mode = (int32_t)pr.hdr.mode;
     if (!usable) {
@@ -1183,8 +1237,13 @@ static int prefilter_info_uncached(const needle_pattern *p, int which, needle_pr
     o->n_windows = (int32_t)f.p.n_grams;
     o->bitmap_bytes = (int32_t)f.p.bm_bytes;
     o->m1 = f.p.m1, o->m2 = f.p.m2, o->addr_shift = f.p.addr_shift, o->addr_mask = f.p.addr_mask;
+    o->on2 = (int32_t)(o->on && f.p.on2 ? 1 : 0);
+    if (o->on2) o->n_windows2 = (int32_t)f.p.n_grams2, o->bitmap2_bytes = (int32_t)f.p.bm2_bytes, o->m3 = f.p.m3, o->addr_mask2 = f.p.addr_mask2;
     snprintf(o->why, sizeof(o->why), "%s", f.p.on ? "" : (f.why.empty() ? (ngram_level() > 0 ? "not a mode the filter is built for" : "NEEDLE_PREFILTER=0") : f.why.c_str()));
-    if (f.p.on) *bitmap_out = f.bitmap;
+    if (f.p.on) {
+        *bitmap_out = f.bitmap;
+        if (o->on2) bitmap_out->insert(bitmap_out->end(), f.bitmap2.begin(), f.bitmap2.end()); // (the second level's right behind)
+    }
     return NEEDLE_OK;
 }
 
@@ -1424,6 +1483,10 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
         int cus = 0;
         rc = get_program(p, W_FORWARDS, 1, p->t.fixed_len >= 0 ? 0 : 7, &sp, &cus);
         if (rc) return rc;
+        if (!(sp && sp->d_ng && sp->prog.ng.p.on)) { // an automaton that fits the LDS in no form: the filter with its walks out of HBM / L2
+            rc = get_program(p, W_FORWARDS, 1, 9, &sp, &cus);
+            if (rc) return rc;
+        }
         if (sp && sp->d_ng && sp->prog.ng.p.on && ngram_find_all_lds_bytes(sp->prog.hdr, sp->prog.ng.p)) {
             ScanArgs a;
             memset(&a, 0, sizeof(a));

@@ -427,6 +427,7 @@ struct LowerAux {
     std::vector<uint16_t> next;
     std::vector<uint8_t> cmap8;
     int n_dev = 0, n_cols = 0, start = 0, accept_lo = 0, dead_hi = 0;
+    bool ml_in_hbm = false; // lower_filter_hbm: a lengths program may keep the HBM-table layout (pend[] then rides behind the table, in HBM)
 };
 } // namespace
 static Program lower_core(const RefTables &t, Which which, int char_width, size_t lds_table_budget, bool global_walk,
@@ -452,6 +453,22 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
     if (!mode_ok) return p;
     p.ng = build_ngram_filter(aux.next.data(), aux.n_dev, aux.n_cols, aux.cmap8.data(), aux.start, aux.accept_lo, aux.dead_hi,
                               which == W_CONTAINED_IN, p.hdr.lds_bytes);
+    return p;
+}
+
+// The n-gram candidate filter in front of an automaton that fits the LDS in NO form (a dictionary at the reference's limit of 16 383
+// states, DFACompiler.java:76-83: 3000 keywords of 6..8 chars = 12 270 states, 690 KB as a table).  The filter kernel then keeps only
+// the Bloom bitmap (and the 512-byte column map) in LDS and verifies its candidates -- ~3 per KiB of text, ~10 steps each -- by
+// walking the plain uint16 table out of HBM / L2.  which: W_CONTAINED_IN, or W_FORWARDS with ml (start = end - pend[stop state]) or
+// for one-length patterns.  8-bit rows.  ng.p.on = 0: no filter (the blob is still a valid HBM-table program).
+Program lower_filter_hbm(const RefTables &t, Which which, const MatchLengths *ml) {
+    LowerAux aux;
+    aux.ml_in_hbm = true;
+    Program p = lower_core(t, which, 1, 0, false, false, false, ml, &aux);
+    memset(&p.ng.p, 0, sizeof(p.ng.p));
+    if (p.blob.empty() || p.hdr.mode != MODE_GLOBAL || ngram_level() <= 0) return p;
+    p.ng = build_ngram_filter(aux.next.data(), aux.n_dev, aux.n_cols, aux.cmap8.data(), aux.start, aux.accept_lo, aux.dead_hi, which == W_CONTAINED_IN,
+                              p.hdr.lds_bytes);
     return p;
 }
 
@@ -1013,6 +1030,18 @@ static Program lower_core(const RefTables &t, Which which, int char_width, size_
             p.blob.insert(p.blob.end(), pend_rows.begin(), pend_rows.end());
             while (p.blob.size() % 16) p.blob.push_back(0);
             p.hdr.lds_bytes = (uint32_t)p.blob.size();
+            p.hdr.fa_dead_lo = 1;
+            p.hdr.fa_dead_n = (uint32_t)ml->n_dead;
+            return p;
+        }
+        if (mode == MODE_GLOBAL && aux && aux->ml_in_hbm) {
+            // the filter kernel's verify walk out of HBM / L2 (lower_filter_hbm): plain device numbering, pend[] by device state BEHIND the
+            // table -- read from memory once per verified candidate, not staged in LDS
+            std::vector<uint8_t> pend_dev(n_dev, 0);
+            for (int s = 0; s < n_ref; ++s) pend_dev[dev[s]] = ml->pend[s];
+            p.hdr.fa_len_off = append(p.blob, pend_dev.data(), pend_dev.size());
+            while (p.blob.size() % 16) p.blob.push_back(0);
+            p.hdr.fa_dead_hi = (uint32_t)ml->n_dead;
             p.hdr.fa_dead_lo = 1;
             p.hdr.fa_dead_n = (uint32_t)ml->n_dead;
             return p;

@@ -72,6 +72,9 @@ MatchLengths match_length_automaton(const RefTables &t);
 Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget, bool plain = true);
 
 
+// The filter program of an automaton too big for the LDS in any form (needle_lower.cpp): HBM-table layout + the n-gram filter.
+Program lower_filter_hbm(const RefTables &t, Which which, const MatchLengths *ml);
+
 // ---- find-all in LOCK-STEP (needle_find_all_ls.hip): the find-all transducer -------------------------------------------
 // The reference's repeated find() (DFAClassBuilder.java:616-659) restarts the search automaton AT the end of every match -- on chars
 // the walk has already consumed while it waited for the automaton to die.  The one-pass kernel (needle_find_all.hip) does that

@@ -28,11 +28,20 @@ struct NgramParams {
     uint32_t bm_bytes;    // bitmap size (power of two)
     uint32_t min_len;     // shortest accepted string (informational)
     uint32_t n_grams;     // distinct byte windows in the bitmap (informational)
+    // Second level (find / containedIn): a candidate whose 4-byte window passed is checked once more before the automaton runs --
+    // the 5-byte window [qn - 5, qn) that ends where its window ends, hashed u2 = u + byte(qn - 5) * m3 into a second, smaller bitmap
+    // (same two-bits-of-one-word scheme, addr_shift 24).  On random text that drops 26 of 27 chance hits of the first level; what is
+    // left is mostly real keyword tails, and only they cost a run of the automaton.
+    uint32_t on2;         // 0: no second level
+    uint32_t m3;          // 24-bit multiplier of the fifth byte
+    uint32_t addr_mask2;  // byte offset of the word inside the second bitmap = u2 & addr_mask2
+    uint32_t bm2_bytes;   // its size (power of two; it follows the first bitmap in the device buffer)
+    uint32_t n_grams2;    // distinct 5-byte windows (informational)
 };
 
 // LDS of the filter kernel (needle_ngram.hip), per wave: the candidate queue + one u64 result slot per row of the group
 constexpr uint32_t kNgQueue = 128;                      // candidates a wave can hold (at most 63 wait while 64 more arrive)
-constexpr uint32_t kNgWaveLds = kNgQueue * 4 + 64 * 8;
+constexpr uint32_t kNgWaveLds = 2 * kNgQueue * 4 + 64 * 8; // (two queues: first-level candidates, second-level survivors)
 // ... of its find-all form: the queue + per row of the group two slots for verified candidates (8 bytes each) and a counter
 constexpr uint32_t kNgRowSlots = 2;
 constexpr uint32_t kNgWaveLdsFA = kNgQueue * 4 + 64 * kNgRowSlots * 8 + 64 * 4;
@@ -42,15 +51,22 @@ constexpr uint32_t kNgLdsCap = 160u * 1024u;
 // Where the bitmap and the waves' queues sit behind a program of prog_bytes: the bitmap at the next multiple of its own size
 // (its address bits and the hash's do not overlap), the queues in the gap in front of it when they fit there, else behind it.
 struct NgramLayout {
-    uint32_t bm_base, q_base, total;
+    uint32_t bm_base, q_base, total, bm2_base;
 };
-inline bool ngram_layout(uint32_t prog_bytes, uint32_t bm_bytes, NgramLayout *out, uint32_t wave_bytes = kNgWaveLds) {
+// bm2_bytes != 0: the second-level bitmap behind everything else, at a multiple of its own size
+inline bool ngram_layout(uint32_t prog_bytes, uint32_t bm_bytes, NgramLayout *out, uint32_t wave_bytes = kNgWaveLds, uint32_t bm2_bytes = 0) {
     if (bm_bytes < 4096u || (bm_bytes & (bm_bytes - 1u))) return false;
     const uint32_t p = (prog_bytes + 15u) & ~15u, qb = kNgWaves * wave_bytes;
     NgramLayout l;
     l.bm_base = (p + bm_bytes - 1u) & ~(bm_bytes - 1u);
     if (l.bm_base - p >= qb) l.q_base = p, l.total = l.bm_base + bm_bytes;
     else l.q_base = l.bm_base + bm_bytes, l.total = l.q_base + qb;
+    l.bm2_base = 0;
+    if (bm2_bytes) {
+        if (bm2_bytes < 1024u || (bm2_bytes & (bm2_bytes - 1u))) return false;
+        l.bm2_base = (l.total + bm2_bytes - 1u) & ~(bm2_bytes - 1u);
+        l.total = l.bm2_base + bm2_bytes;
+    }
     if (l.total > kNgLdsCap) return false;
     if (out) *out = l;
     return true;
@@ -74,6 +90,17 @@ __device__ __forceinline__ uint32_t ngram_probe(uint32_t x, uint32_t m, uint32_t
     asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r1) : "v"(u), "v"(w)); // w >> (u >> 24 & 31)
     asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r2) : "v"(u), "v"(w)); // w >> (u >> 16 & 31)
     return r1 & r2;
+}
+
+// Second level: window x (4 bytes) + the byte c5 in front of it.  u2 = hash(x) + c5 * m3; same word / two-bit test in the second bitmap.
+inline uint32_t ngram_hash2_host(uint32_t x, uint32_t c5, uint32_t m1, uint32_t m2, uint32_t m3) { return ngram_hash_host(x, m1, m2) + c5 * m3; }
+__device__ __forceinline__ uint32_t ngram_probe2(uint32_t x, uint32_t c5, uint32_t m, uint32_t m3, uint32_t addr_mask2, uint32_t bm2_base) {
+    uint32_t u;
+    asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(u) : "v"(x), "v"(m));
+    u += c5 * m3;
+    const uint32_t a = (u & addr_mask2) | bm2_base;
+    const uint32_t w = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a;
+    return (w >> ((u >> 24) & 31u)) & (w >> ((u >> 16) & 31u)) & 1u;
 }
 
 // One 16-byte piece of text held by one lane (w0 .. w3; pw = the dword before it: the previous lane's w3).  Tests the windows

@@ -62,6 +62,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     const uint32_t bm_base = A.lay.bm_base;
     for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
     for (uint32_t i = tid * 16u; i < A.ng.bm_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + bm_base + i) = *(const u32x4 *)((const uint8_t *)A.ng_bitmap + i);
+    // the second-level bitmap (5-byte windows, needle_ngram.h) rides behind the first in HBM
+    const bool L2ON = OP != OP_NG_FIND_ALL && A.ng.on2 != 0u; // wave-uniform
+    if (L2ON)
+        for (uint32_t i = tid * 16u; i < A.ng.bm2_bytes; i += blockDim.x * 16u)
+            *(u32x4 *)(smem + A.lay.bm2_base + i) = *(const u32x4 *)((const uint8_t *)A.ng_bitmap + A.ng.bm_bytes + i);
     __syncthreads();
 
     Walk wk;
@@ -78,11 +83,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     wk.sp_pad_ident = a.hdr.sp_pad_ident;
     wk.table_off = a.hdr.off_table - (MODE == MODE_SPARSE ? 0u : a.hdr.win_lo_e);
     wk.lane4 = 0;
-    wk.gtable = nullptr;
+    // MODE_GLOBAL (lower_filter_hbm: an automaton that fits the LDS in no form): the candidates' walks read the plain uint16 table out
+    // of HBM / L2 -- the LDS holds the bitmap, the column map and the queues only
+    wk.gtable = MODE == MODE_GLOBAL ? (const uint16_t *)(a.prog + a.hdr.off_table) : nullptr;
     wk.hot_last = 0;
     const uint32_t accept_lo = a.hdr.accept_lo, start_state = a.hdr.start;
     const uint32_t qbase = A.lay.q_base + (uint32_t)wave * (FA ? kNgWaveLdsFA : kNgWaveLds);
-    const uint32_t sbase = qbase + kNgQueue * 4u; // find / containedIn: the rows' slots; find-all: two candidate slots per row ...
+    const uint32_t q2base = qbase + kNgQueue * 4u; // find / containedIn: the second queue (candidates that passed the second-level window)
+    const uint32_t sbase = qbase + (FA ? 1u : 2u) * kNgQueue * 4u; // find / containedIn: the rows' slots; find-all: two candidate slots per row ...
     const uint32_t cbase = sbase + 64u * kNgRowSlots * 8u; // ... and a counter per row
     const uint32_t mm = A.ng.m1 | A.ng.m2 << 16, amask = A.ng.addr_mask;
     const uint32_t K = A.ng.warm;
@@ -116,6 +124,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             const uint32_t room = (uint32_t)(a.total_bytes - 16u - base);
             off = off < room ? off : room;
         }
+        // (tried for MODE_GLOBAL, whose walks read the table out of L2: nontemporal text loads -- c3x 1.09 -> 1.19 ms: the candidates' own
+        // text then never hits the L2 either)
         return *(const u32x4 *)(a.rows + base + off);
     };
 
@@ -213,7 +223,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                     const uint32_t st_end = sparse_end<1>(wk, st, found && st > wk.dead_hi, a.hdr.sp_end_col4);
                     pidx = (st_end & 0xFFFFu) - a.hdr.sp_dead_row0;
                 }
-                h.start = (int32_t)last - (int32_t)lds_u8(a.hdr.fa_len_off + (found ? pidx : 0u));
+                if (MODE == MODE_GLOBAL) h.start = (int32_t)last - (int32_t)a.prog[a.hdr.fa_len_off + (found ? pidx : 0u)]; // (pend[] behind the table)
+                else h.start = (int32_t)last - (int32_t)lds_u8(a.hdr.fa_len_off + (found ? pidx : 0u));
             }
         }
         return h;
@@ -245,6 +256,29 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         }
     };
 
+    // window end `e` (byte offset inside the group) -> its row and the offset qn inside the row
+    auto locate = [&](uint32_t e, uint32_t &row, uint32_t &qn) __attribute__((always_inline)) {
+        const uint32_t em1 = e - 1u;
+        if (A.stride_log2 != 0xFFFFFFFFu) {
+            row = em1 >> A.stride_log2;
+        } else {
+            row = __umulhi(em1, A.stride_recip);
+            if (em1 - row * stride >= stride) ++row;
+        }
+        qn = e - row * stride; // window [qn - 4, qn) of the row
+    };
+    // the second-level window of a candidate (valid: row < rows_in, qn >= 4): text bytes [qn - 5, qn) hashed into the second bitmap
+    // (needle_ngram.h); candidates within 5 chars of the row's start pass as they are
+    const uint32_t bm2_base = A.lay.bm2_base, amask2 = A.ng.addr_mask2, m3 = A.ng.m3;
+    auto level2 = [&](uint64_t grp, uint32_t row, uint32_t qn) __attribute__((always_inline)) -> bool {
+        typedef uint32_t u32_u __attribute__((aligned(1)));
+        const uint8_t *rowp = a.rows + ((grp << 6) + row) * a.stride_bytes;
+        const bool deep = qn >= 5u;
+        const uint32_t w = *(const u32_u *)(rowp + qn - 4u);
+        const uint32_t c5 = deep ? (uint32_t)rowp[qn - 5u] : 0u;
+        return !deep || ngram_probe2(w, c5, mm, m3, amask2, bm2_base) != 0u;
+    };
+    uint32_t q2head = 0, q2tail = 0; // wave-uniform: the second queue
     uint32_t qhead = 0, qtail = 0; // wave-uniform
     uint32_t n_cand = 0, n_units = 0; // what this wave saw: candidates, KiB units of text (-> A.stats: the host's flood watch)
     for (; g < n_groups; g += wave_cnt) {
@@ -257,6 +291,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         else if (OP == OP_FIND) *(lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u) = ~0ull;
         else if (lane == 0) *(lds_u64_t *)(uintptr_t)sbase = 0ull;
         uint32_t carry = 0; // (the window reaching back from a row's first bytes is dropped below: what it holds does not matter)
+        // run the automaton on the second queue's candidates, 64 at a time, while at least `at_least` wait
+        auto drain2 = [&](uint32_t at_least) __attribute__((always_inline)) {
+            while (q2tail - q2head >= at_least && q2tail != q2head) {
+                const uint32_t n_take = q2tail - q2head < 64u ? q2tail - q2head : 64u;
+                const bool act = (uint32_t)lane < n_take;
+                uint32_t e = *(const lds_u32_t *)(uintptr_t)(q2base + (((q2head + (uint32_t)lane) & (kNgQueue - 1u)) << 2));
+                q2head += n_take;
+                e = act ? e : 4u;
+                uint32_t row, qn;
+                locate(e, row, qn);
+                run_rows(g, row, act && row < rows_in && qn >= 4u, qn, qn > K ? qn - K : 0u, qn + (uint32_t)S - 1u);
+            }
+        };
         for (uint32_t u0 = 0; u0 < units; u0 += kNgPF) {
             // ---- filter: four units, each slot re-loaded for the batch after next as soon as it is read
             uint32_t log = 0;
@@ -296,23 +343,30 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 const uint32_t thr = (more || !last_batch) ? full_set : 1u;
                 if (dbg == 1u) qhead = qtail;
                 while (qtail - qhead >= thr) {
-                    // ---- run the automaton on up to 64 candidates, one per lane
+                    // ---- up to 64 candidates, one per lane
                     const uint32_t n_take = qtail - qhead < 64u ? qtail - qhead : 64u;
                     const bool act = (uint32_t)lane < n_take;
                     uint32_t e = *(const lds_u32_t *)(uintptr_t)(qbase + (((qhead + (uint32_t)lane) & (kNgQueue - 1u)) << 2));
                     qhead += n_take;
                     e = act ? e : 4u;
-                    const uint32_t em1 = e - 1u;
-                    uint32_t row;
-                    if (A.stride_log2 != 0xFFFFFFFFu) {
-                        row = em1 >> A.stride_log2;
-                    } else {
-                        row = __umulhi(em1, A.stride_recip);
-                        if (em1 - row * stride >= stride) ++row;
+                    uint32_t row, qn;
+                    locate(e, row, qn);
+                    const bool valid = act && row < rows_in && qn >= 4u;
+                    if (!L2ON) { // ---- run the automaton on them
+                        run_rows(g, row, valid, qn, qn > K ? qn - K : 0u, qn + (uint32_t)S - 1u);
+                        continue;
                     }
-                    const uint32_t qn = e - row * stride; // window [qn - 4, qn) of the row
-                    run_rows(g, row, act && row < rows_in && qn >= 4u, qn, qn > K ? qn - K : 0u, qn + (uint32_t)S - 1u);
+                    // ---- second level: the 5-byte window [qn - 5, qn) -- 8 bytes of the candidate's text from memory, one more probe;
+                    // what passes (on random text 1 in 27 of the first level's chance hits, and every real keyword tail) waits in the
+                    // second queue until 64 of them make a run worth its ~10 dependent lookups
+                    const bool pass = valid && level2(g, row, qn);
+                    const uint64_t pm = __ballot(pass);
+                    const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    if (pass) *(lds_u32_t *)(uintptr_t)(q2base + (((q2tail + prank) & (kNgQueue - 1u)) << 2)) = e;
+                    q2tail += (uint32_t)__builtin_popcountll(pm);
+                    drain2((thr == 1u && qtail == qhead) ? 1u : 64u);
                 }
+                if (L2ON && thr == 1u) drain2(1u); // the group's end: whatever still waits
                 if (!more) break;
             }
         }
@@ -432,6 +486,7 @@ static hipError_t launch_ng_m(const NgramArgs &A, int n_cus, size_t lds, hipStre
     case MODE_TABLE8: return launch_ng_s<OP, MODE_TABLE8>(A, n_cus, lds, stream);
     case MODE_TABLE16: return launch_ng_s<OP, MODE_TABLE16>(A, n_cus, lds, stream);
     case MODE_SPARSE: return launch_ng_s<OP, MODE_SPARSE>(A, n_cus, lds, stream);
+    case MODE_GLOBAL: return launch_ng_s<OP, MODE_GLOBAL>(A, n_cus, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -439,6 +494,7 @@ static hipError_t launch_ng_m(const NgramArgs &A, int n_cus, size_t lds, hipStre
 // LDS a launch takes; 0 = does not fit (the caller keeps the ordinary kernel)
 size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
     NgramLayout l;
+    if (ng.on2 && ngram_layout(h.lds_bytes, ng.bm_bytes, &l, kNgWaveLds, ng.bm2_bytes)) return l.total;
     return ngram_layout(h.lds_bytes, ng.bm_bytes, &l) ? l.total : 0;
 }
 
@@ -488,7 +544,12 @@ static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams 
     A.stride_log2 = 0xFFFFFFFFu;
     if ((stride & (stride - 1u)) == 0u) A.stride_log2 = (uint32_t)__builtin_ctz(stride);
     A.stride_recip = (uint32_t)((1ull << 32) / stride);
-    if (!ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay, op == OP_NG_FIND_ALL ? kNgWaveLdsFA : kNgWaveLds) || ng.addr_shift != 24u) return hipErrorInvalidValue;
+    if (op != OP_NG_FIND_ALL && ng.on2 && !ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay, kNgWaveLds, ng.bm2_bytes)) A.ng.on2 = 0; // (cannot be: the host sized it)
+    if (op == OP_NG_FIND_ALL || !A.ng.on2) {
+        A.ng.on2 = 0;
+        if (!ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay, op == OP_NG_FIND_ALL ? kNgWaveLdsFA : kNgWaveLds)) return hipErrorInvalidValue;
+    }
+    if (ng.addr_shift != 24u) return hipErrorInvalidValue;
     A.dbg = 0;
 #ifdef NEEDLE_TUNING
     static const uint32_t dbg_env = getenv("NEEDLE_NG_DBG") ? (uint32_t)atoi(getenv("NEEDLE_NG_DBG")) : 0u;

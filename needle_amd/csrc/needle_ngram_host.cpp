@@ -8,6 +8,7 @@
 // so whatever DFACompiler produced (leftmost-first pruning, case folding, classes) is covered without a second semantics.
 #include "needle_ngram_host.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 #include <unordered_set>
 
@@ -124,7 +125,7 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
 
     // ---- T[j]: states from which a FIRST accepting transition is exactly j chars away (j = 0: the accepting states entered
     // from a pre-accept state); T[j >= 1] within the pre-accept states
-    const int depth = kN + S - 1;
+    const int depth = kN + 1 + S - 1; // (one deeper: the second level's 5-column windows)
     std::vector<std::vector<uint8_t>> T(depth + 1, std::vector<uint8_t>(n_dev, 0));
     for (int s : order)
         for (int k : cols)
@@ -134,40 +135,44 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
             for (int k : cols)
                 if (T[j - 1][nx(s, k)]) { T[j][s] = 1; break; }
 
-    // ---- windows: label sequences x1..x4 of paths p0 -> .. -> p4 with p_m in T[o + 4 - m]; frontier = (state, labels so far)
-    std::unordered_set<uint32_t> labels; // 4 columns, 8 bits each
-    for (int o = 0; o < S; ++o) {
-        std::vector<uint64_t> fr; // state << 32 | labels
-        for (int s : order)
-            if (T[o + kN][s]) fr.push_back((uint64_t)s << 32);
-        for (int m = 1; m <= kN; ++m) {
-            std::vector<uint64_t> nf;
-            for (uint64_t e : fr) {
-                const int s = (int)(e >> 32);
-                const uint32_t lab = (uint32_t)e;
-                for (int k : cols) {
-                    const int t = nx(s, k);
-                    if (!T[o + kN - m][t]) continue;
-                    if (m < kN && accepting(t)) continue; // (only the last step of a path may enter an accepting state, and only for o = 0)
-                    nf.push_back((uint64_t)t << 32 | (lab | (uint32_t)k << (8 * (m - 1))));
+    // ---- windows: label sequences x1..xN of paths p0 -> .. -> pN with p_m in T[o + N - m]; frontier = (state, labels so far).
+    // N = 4: the filter's windows; N = 5: the second level's.  false: too many paths.
+    auto enum_labels = [&](int N, std::unordered_set<uint64_t> &labels) -> bool {
+        for (int o = 0; o < S; ++o) {
+            std::vector<std::pair<uint32_t, uint64_t>> fr; // (state, labels: 8 bits per column)
+            for (int s : order)
+                if (T[o + N][s]) fr.emplace_back((uint32_t)s, 0ull);
+            for (int m = 1; m <= N; ++m) {
+                std::vector<std::pair<uint32_t, uint64_t>> nf;
+                for (const auto &e : fr) {
+                    const int s = (int)e.first;
+                    for (int k : cols) {
+                        const int t = nx(s, k);
+                        if (!T[o + N - m][t]) continue;
+                        if (m < N && accepting(t)) continue; // (only the last step of a path may enter an accepting state, and only for o = 0)
+                        nf.emplace_back((uint32_t)t, e.second | (uint64_t)k << (8 * (m - 1)));
+                    }
+                    if (nf.size() > kMaxFrontier) {
+                        std::sort(nf.begin(), nf.end());
+                        nf.erase(std::unique(nf.begin(), nf.end()), nf.end());
+                        if (nf.size() > kMaxFrontier / 2) return false;
+                    }
                 }
-                if (nf.size() > kMaxFrontier) {
-                    std::sort(nf.begin(), nf.end());
-                    nf.erase(std::unique(nf.begin(), nf.end()), nf.end());
-                    if (nf.size() > kMaxFrontier / 2) return no("too many window paths");
-                }
+                std::sort(nf.begin(), nf.end());
+                nf.erase(std::unique(nf.begin(), nf.end()), nf.end());
+                fr.swap(nf);
             }
-            std::sort(nf.begin(), nf.end());
-            nf.erase(std::unique(nf.begin(), nf.end()), nf.end());
-            fr.swap(nf);
+            for (const auto &e : fr) labels.insert(e.second);
         }
-        for (uint64_t e : fr) labels.insert((uint32_t)e);
-    }
+        return true;
+    };
+    std::unordered_set<uint64_t> labels;
+    if (!enum_labels(kN, labels)) return no("too many window paths");
     if (labels.empty()) return no("no windows");
 
     // ---- expand columns to bytes
     std::vector<uint32_t> grams;
-    for (uint32_t lab : labels) {
+    for (uint64_t lab : labels) {
         const std::vector<uint8_t> *b[kN];
         size_t n = 1;
         for (int i = 0; i < kN; ++i) {
@@ -230,6 +235,51 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
             best_fp = fp;
             f.p.m1 = mm[0], f.p.m2 = mm[1];
             f.bitmap = bm;
+        }
+    }
+    // ---- second level (needle_ngram.h): the 5-byte windows, same construction one column deeper -- when every match is long enough
+    // for them to lie inside it (else their first column is "any char" and they select nothing)
+    f.p.on2 = 0;
+    static const bool level2_on = !(getenv("NEEDLE_PREFILTER_LEVEL2") && atoi(getenv("NEEDLE_PREFILTER_LEVEL2")) == 0);
+    if (level2_on && min_len >= kN + 1 + S - 1) {
+        std::unordered_set<uint64_t> labels5;
+        std::vector<uint64_t> grams5; // bytes 0 .. 4, 8 bits each: byte 0 = the char in front of the 4-byte window
+        bool ok5 = enum_labels(kN + 1, labels5) && !labels5.empty();
+        for (uint64_t lab : labels5) {
+            if (!ok5) break;
+            const std::vector<uint8_t> *b[kN + 1];
+            size_t n = 1;
+            for (int i = 0; i <= kN; ++i) {
+                b[i] = &bytes_of[(lab >> (8 * i)) & 255u];
+                n *= b[i]->size();
+            }
+            if (grams5.size() + n > kMaxWindows) { ok5 = false; break; }
+            for (uint8_t c0 : *b[0])
+                for (uint8_t c1 : *b[1])
+                    for (uint8_t c2 : *b[2])
+                        for (uint8_t c3 : *b[3])
+                            for (uint8_t c4 : *b[4])
+                                grams5.push_back((uint64_t)c0 | (uint64_t)c1 << 8 | (uint64_t)c2 << 16 | (uint64_t)c3 << 24 | (uint64_t)c4 << 32);
+        }
+        if (ok5) {
+            std::sort(grams5.begin(), grams5.end());
+            grams5.erase(std::unique(grams5.begin(), grams5.end()), grams5.end());
+            // the largest second bitmap (<= 16 KiB) that still fits behind the queues; useless when it fills up
+            size_t bm2 = 16384;
+            while (bm2 >= 1024 && !ngram_layout((uint32_t)prog_lds_bytes, (uint32_t)bm_bytes, nullptr, kNgWaveLds, (uint32_t)bm2)) bm2 >>= 1;
+            while (bm2 > 1024 && grams5.size() * 128 < bm2 * 8) bm2 >>= 1;
+            if (bm2 >= 1024 && (double)grams5.size() / (double)(bm2 * 8) <= 0.10) {
+                f.p.on2 = 1;
+                f.p.m3 = 0x9E3779u;
+                f.p.bm2_bytes = (uint32_t)bm2;
+                f.p.addr_mask2 = (uint32_t)(bm2 - 1) & ~3u;
+                f.p.n_grams2 = (uint32_t)grams5.size();
+                f.bitmap2.assign(bm2 / 4, 0u);
+                for (uint64_t g5 : grams5) {
+                    const uint32_t u = ngram_hash2_host((uint32_t)(g5 >> 8), (uint32_t)(g5 & 255u), f.p.m1, f.p.m2, f.p.m3);
+                    f.bitmap2[ngram_word_index(u, f.p.addr_mask2)] |= ngram_word_bits(u, 24u);
+                }
+            }
         }
     }
     f.p.on = 1;

@@ -10,6 +10,7 @@ namespace needle {
 struct NgramFilter {
     NgramParams p;                // p.on == 0: no filter (why says why)
     std::vector<uint32_t> bitmap; // p.bm_bytes / 4 words; bit (i & 31) of word (i >> 5)
+    std::vector<uint32_t> bitmap2; // p.on2: the second level's, p.bm2_bytes / 4 words
     std::string why;
 };
 
@@ -26,6 +27,9 @@ struct NgramFilter {
 //  * the windows: every 4-column sequence that labels the 4 transitions ending o chars ahead of a FIRST accepting transition
 //    (o = 0 .. S - 1), expanded to bytes and hashed into the bitmap.  A first accept at char index i therefore has, for the
 //    one o with (i - o) = 0 (mod S), a window [i - o - 4, i - o) in the bitmap: no accept without a candidate.
+//  * the second level (when min_len >= 5 + S - 1): the same with 5-column sequences -- a first accept at least 5 + o chars into
+//    its row also has [i - o - 5, i - o) in the second bitmap (candidates nearer the row's start are not asked).
+//    NEEDLE_PREFILTER_LEVEL2=0: no second level (A/B, tests).
 NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, const uint8_t *cmap8, int start, int accept_lo, int dead_hi,
                                bool absorbing, size_t prog_lds_bytes);
 

@@ -193,9 +193,11 @@ class Pattern:
         out = {k: getattr(i, k) for k, _ in i._fields_}
         out["why"] = out["why"].decode()
         if with_bitmap and i.on:
-            bm = np.zeros(i.bitmap_bytes // 4, dtype=np.uint32)
+            bm = np.zeros((i.bitmap_bytes + (i.bitmap2_bytes if i.on2 else 0)) // 4, dtype=np.uint32)
             _check(L.needle_pattern_prefilter_info(self._h, list(WHICH).index(which), ctypes.byref(i), bm.ctypes.data))
-            out["bitmap"] = bm
+            out["bitmap"] = bm[:i.bitmap_bytes // 4]
+            if i.on2:
+                out["bitmap2"] = bm[i.bitmap_bytes // 4:]  # the second level's (5-byte windows)
         return out
 
     def match_length_automaton(self):

@@ -11,6 +11,26 @@ def window_passes(info, bitmap, x):
     return (w >> ((u >> info["addr_shift"]) & 31)) & (w >> ((u >> (info["addr_shift"] - 8)) & 31)) & 1
 
 
+def window2_passes(info, bitmap2, x, c5):
+    """The second level (needle_ngram.h ngram_probe2): the byte in front of the window joins the hash."""
+    u = ((x & 0xFFFF) * info["m1"] + (x >> 16) * info["m2"] + c5 * info["m3"]) & 0xFFFFFFFF
+    w = int(bitmap2[(u & info["addr_mask2"]) >> 2])
+    return (w >> ((u >> 24) & 31)) & (w >> ((u >> 16) & 31)) & 1
+
+
+def candidate(info, t, e, all_windows):
+    """Does the window ending at e make a candidate: its 4 bytes in the bitmap and -- find / containedIn, 5 chars or more into the row --
+    its 5 bytes in the second one."""
+    x = int(t[e - 4] | (t[e - 3] << 8) | (t[e - 2] << 16) | (t[e - 1] << 24))
+    if all_windows:
+        return True
+    if not window_passes(info, info["bitmap"], x):
+        return False
+    if info.get("on2") and e >= 5 and not info.get("no_level2"):
+        return bool(window2_passes(info, info["bitmap2"], x, int(t[e - 5])))
+    return True
+
+
 class Automaton:
     """step(state, char) -> state (-1 dead), in reference numbering (0 = start)."""
 
@@ -96,8 +116,7 @@ def filtered(p, op, text, all_windows=False, info=None):
     for e in range(S, len(t) + 1, S):
         if e < 4:
             continue
-        x = int(t[e - 4] | (t[e - 3] << 8) | (t[e - 2] << 16) | (t[e - 1] << 24))
-        if not all_windows and not window_passes(info, info["bitmap"], x):
+        if not candidate(info, t, e, all_windows):
             continue
         rep = run_window(au, t, e, K, S, fixed, op == "contained_in")
         if rep is not None and (best is None or rep < best):

@@ -28,6 +28,7 @@ def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
         i = p.prefilter_info(which)
         assert i["on"] == 1 and i["mode"] == 6 and i["stride"] == 2 and i["warm"] == 8 and i["min_len"] == 6, i
         assert 1500 <= i["n_windows"] <= 2000 and i["bitmap_bytes"] == 32768, i
+        assert i["on2"] == 1 and 1500 <= i["n_windows2"] <= 2100 and i["bitmap2_bytes"] == 8192, i  # the second level: 5-byte windows
     rows = W.keyword_batch(np, words, 11, 72, 256)
     rows[::7, 256 - len(words[3]):] = [ord(c) for c in words[3]]        # a keyword that ends with the row
     rows[3::7, 256 - len(words[4]) + 1:] = [ord(c) for c in words[4]][:-1]  # ... and one the row's end cuts
