@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 ENGINE_CLOCK_MHZ = 2400.0  # MI355X peak engine clock (same guide); chars/clk/CU is quoted against it
 KERNEL_SOURCES = ["needle_scan.h", "needle_kernels.hip", "needle_stripe.hip", "needle_walk.h", "needle_device.h", "needle_lower.cpp",
-                  "needle_ngram.h", "needle_ngram.hip", "needle_ngram_host.cpp"]
+                  "needle_ngram.h", "needle_ngram.hip", "needle_ngram_host.cpp", "needle_find_all.hip", "needle_find_all_ls.hip"]
 
 
 def kernel_source_sha():
@@ -590,7 +590,62 @@ def measure(workload, args, ctx, headline):
                                               "note": "needle_find_packed16_dev (the scan stores one dword per row itself) + D2H of 4 B per row; "
                                                       "scan_kernel_ms: that scan alone on the device"}
             del cw_, cr_, cc_, pk
-    if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s") and is_find:
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ... and PIPELINED ("results landed in host-visible memory" as a steady-state rate): two result sets; step k's D2H
+        # runs on a copy stream under step k + 1's scan.  find(): the one-dword form the scan stores itself (4 B per row over PCIe).
+        n_sets = 2
+        use_packed = is_find and rows.shape[1] <= 65534
+        dsets, hsets = [], []
+        for _ in range(n_sets):
+            d = {"bitmap": torch.empty(sh.per_words, dtype=torch.int64, device=dev)}
+            h = {"bitmap": torch.empty(sh.per_words, dtype=torch.int64).pin_memory()}
+            if is_find and use_packed:
+                d["packed"] = torch.empty(n_rows, dtype=torch.int32, device=dev)
+                h["packed"] = torch.empty(n_rows, dtype=torch.int32).pin_memory()
+            elif is_find:
+                d["start"], d["end"] = torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.int32, device=dev)
+                h["start"], h["end"] = torch.empty(n_rows, dtype=torch.int32).pin_memory(), torch.empty(n_rows, dtype=torch.int32).pin_memory()
+            dsets.append(d)
+            hsets.append(h)
+        s_scan, s_copy = torch.cuda.current_stream(), torch.cuda.Stream()
+        scan_done = [torch.cuda.Event() for _ in range(n_sets)]
+        copy_done = [torch.cuda.Event() for _ in range(n_sets)]
+
+        def pipelined_steps(k_steps):
+            for i in range(k_steps):
+                k = i % n_sets
+                s_scan.wait_event(copy_done[k])  # set k's previous results have left the device
+                d = dsets[k]
+                if not is_find:
+                    op(rows, out=d["bitmap"])
+                elif use_packed:
+                    pattern.find_packed16_batch(rows, out=(d["bitmap"], d["packed"]))
+                else:
+                    op(rows, out=(d["bitmap"], d["start"], d["end"]))
+                scan_done[k].record(s_scan)
+                s_copy.wait_event(scan_done[k])
+                with torch.cuda.stream(s_copy):
+                    for key, t in d.items():
+                        hsets[k][key].copy_(t, non_blocking=True)
+                    copy_done[k].record(s_copy)
+            torch.cuda.synchronize()
+        for e_ in copy_done:
+            e_.record(s_copy)
+        pipelined_steps(4)
+        kp = max(8, args.steps)
+        best = None
+        for _ in range(2):
+            tq = time.perf_counter()
+            pipelined_steps(kp)
+            dq = (time.perf_counter() - tq) / kp
+            best = dq if best is None else min(best, dq)
+        d2h = sh.per_words * 8 + ((4 if use_packed else 8) * n_rows if is_find else 0)
+        out["host_landed"]["pipelined"] = {"ms_per_step": best * 1e3, "GB/s": bytes_job / best / 1e9, "frac_of_hbm_peak": bytes_job / best / 1e9 / HBM_PEAK_GBS,
+                                           "d2h_bytes_per_step": d2h, "d2h_GB/s": d2h / best / 1e9,
+                                           "note": "steady state of scan k + 1 on the launch stream beside the D2H of step k's results on a copy stream (two result sets); "
+                                                   "find(): the one-dword form" if use_packed else "two result sets, D2H under the next scan"}
+        del dsets, hsets
+    if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s", "c3x") and is_find:
         # EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
         # the batch (needle_find_all.hip; for dictionaries behind the n-gram candidate filter -- c3s -- that kernel's find-all form,
         # needle_ngram.hip): counts + dense per-row slots.  Its own figure, never the `value`.
@@ -610,7 +665,9 @@ def measure(workload, args, ctx, headline):
         fa_bytes = n_rows * (256 * cw + 4) + 8 * n_matches
         out["find_all"] = {"ms_per_step": dt * 1e3, "matches": n_matches, "matches_per_s": n_matches / dt, "max_per_row": int(fc.max().item()),
                            "slots": slots, "more": bool(more), "GB/s": fa_bytes / dt / 1e9, "algorithmic_bytes": fa_bytes,
-                           "kernel": "needle::ngram_kernel (find-all form)" if pre["on"] else "needle::find_all_kernel",
+                           "kernel": ("needle::ngram_kernel (find-all form)" if pre["on"] else
+                                      "needle::find_all_lockstep_kernel" if pattern.find_all_transducer(cw) is not None else "needle::find_all_kernel"),
+                           "frac_of_hbm_peak": fa_bytes / dt / 1e9 / HBM_PEAK_GBS,
                            "note": "every non-overlapping match per row (repeated Matcher.find()), one pass; bytes = rows + 4 B count per row + 8 B per match"}
         # the same with each match as one dword (needle_find_all_packed16_dev: start | end << 16): one result line per row
         t = time.perf_counter()
@@ -620,13 +677,87 @@ def measure(workload, args, ctx, headline):
         dtp = (time.perf_counter() - t) / k2
         assert int(fc.sum().item()) == n_matches and ((fs >> 16) & 0xFFFF)[:, 0][fc > 0].eq(fe[:, 0][fc > 0]).all()
         out["find_all"]["packed16"] = {"ms_per_step": dtp * 1e3, "matches_per_s": n_matches / dtp,
-                                       "algorithmic_bytes": n_rows * (256 * cw + 4) + 4 * n_matches}
+                                       "algorithmic_bytes": n_rows * (256 * cw + 4) + 4 * n_matches,
+                                       "frac_of_hbm_peak": (n_rows * (256 * cw + 4) + 4 * n_matches) / dtp / 1e9 / HBM_PEAK_GBS}
+        # the counting pass alone (needle_count_matches_dev): the walk without filing
+        t = time.perf_counter()
+        for _ in range(k2):
+            pattern.count_matches_batch(rows)
+        torch.cuda.synchronize()
+        out["find_all"]["count_pass_ms"] = (time.perf_counter() - t) / k2 * 1e3
         del fc, fs, fe
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(workload, pattern, rows, op_name, 10.0 if headline else 4.0)
     del rows, sh, graphs
     torch.cuda.empty_cache()
     return out, total_rows
+
+
+def _r(x, n=4):
+    return round(x, n) if isinstance(x, float) else x
+
+
+def slim(w):
+    """One workload's digest for the stdout line: step time, roofline of its kernel, traffic / algorithmic bytes, host-landed and
+    find-all figures, the CPU baseline -- numbers only (the notes are in the full JSON on stderr / bench_full.json)."""
+    if "error" in w:
+        return w
+    r = w["roofline"]
+    o = {"workload": w["config"]["workload"].split(":")[0], "ms": _r(w["ms_per_step"]), "kernel_ms": _r(r["kernel_ms"]), "GBs": _r(r["achieved"], 1),
+         "frac": _r(r["frac"]), "kernel": r["kernel"].replace("needle::", ""), "mode": w["config"]["automaton"]["kernel_mode"][:24],
+         "states": w["config"]["automaton"]["states"],
+         "traffic_x": _r(r["traffic"] / r["algorithmic_bytes_per_launch"], 3) if r.get("traffic") else None,
+         "rows_s": _r(w["rows_per_s"], 0), "match_s": _r(w["matches_per_s"], 0), "matched": _r(w["matched_fraction"], 3)}
+    if "cold" in w:
+        o["cold_ms"], o["steady_ms"] = _r(w["cold"]["ms_per_step"]), _r(w["steady"]["ms_per_step"]) if "steady" in w else None
+    if "gather_verified" in w:
+        o["gather_verified"], o["scan_ms"], o["gather_ms"] = w["gather_verified"], _r(w.get("scan_ms")), _r(w.get("gather_ms"))
+    hl = w.get("host_landed")
+    if hl:
+        o["host_landed_ms"] = {"plain": _r(hl["ms_per_step"]), **{k: _r(hl[k]["ms_per_step"]) for k in ("packed16", "compact", "pipelined") if k in hl}}
+        if "pipelined" in hl:
+            o["host_landed_ms"]["pipelined_frac"] = _r(hl["pipelined"]["frac_of_hbm_peak"])
+    fa = w.get("find_all")
+    if fa:
+        o["find_all"] = {"ms": _r(fa["ms_per_step"]), "frac": _r(fa["frac_of_hbm_peak"]), "packed16_ms": _r(fa["packed16"]["ms_per_step"]),
+                         "packed16_frac": _r(fa["packed16"]["frac_of_hbm_peak"]), "count_ms": _r(fa.get("count_pass_ms")),
+                         "Gmatch_s": _r(fa["packed16"]["matches_per_s"] / 1e9, 2), "matches": fa["matches"], "kernel": fa["kernel"].replace("needle::", "")}
+    cb = w.get("cpu_baseline")
+    if cb:
+        o["cpu_GBs"] = {"all": _r(cb["value"], 2), "cores": cb["cores"], "one": _r(cb["single_core"]["value"], 2), "kind": cb["kind"]}
+    return o
+
+
+def slim_line(out):
+    """The stdout line: the contract's fields, `roofline` and `cpu_baseline` as the contract asks for them, then digests."""
+    keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"]
+    line = {k: out[k] for k in keep}
+    line["config"] = {k: v for k, v in out["config"].items() if k != "automaton"}
+    line["config"]["automaton"] = {k: out["config"]["automaton"][k] for k in ("states", "classes", "kernel_mode")}
+    line["roofline"] = {k: (_r(v, 6) if isinstance(v, float) else v) for k, v in out["roofline"].items() if k not in ("device", "traffic_note")}
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = {"value": _r(cb["value"], 3), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:110],
+                                "single_core_GBs": _r(cb["single_core"]["value"], 3)}
+    for k in ("rows_per_s", "matches_per_s", "gather_verified", "scan_ms", "gather_ms", "kernel_source_sha"):
+        if k in out:
+            line[k] = _r(out[k], 1) if isinstance(out[k], float) else out[k]
+    if "cold" in out:
+        line["cold_ms"], line["steady_ms"] = _r(out["cold"]["ms_per_step"]), _r(out["steady"]["ms_per_step"]) if "steady" in out else None
+    if "must_read" in out:
+        line["must_read_GBs"] = _r(out["must_read"]["GB/s"], 1)
+    hl = out.get("host_landed")
+    if hl:
+        line["host_landed_ms"] = {"plain": _r(hl["ms_per_step"]), **{k: _r(hl[k]["ms_per_step"]) for k in ("packed16", "compact", "pipelined") if k in hl}}
+        if "pipelined" in hl:
+            line["host_landed_ms"]["pipelined_frac"] = _r(hl["pipelined"]["frac_of_hbm_peak"])
+    if "c4_shard_step" in out:
+        line["c4_shard_step"] = {w: ({"ms": _r(v["ms_per_step"]), "kernel_ms": _r(v["kernel_ms"]), "overhead": _r(v["overhead_frac"], 3)} if "error" not in v else v)
+                                 for w, v in out["c4_shard_step"].items()}
+    if "workloads" in out:
+        line["workloads"] = {w: slim(v) for w, v in out["workloads"].items()}
+    line["full"] = "stderr, bench_full.json"
+    return line
 
 
 def main():
@@ -636,7 +767,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w"], help="the headline workload")
     ap.add_argument("--also", default=None, help="comma list of further workloads measured into \"workloads\" "
-                    "(default: c3,c3s,c5,c5w at 1 GPU, c3 at N > 1; 'none' for profiling runs)")
+                    "(default: c3,c3s,c3x,c5,c5w at 1 GPU, c3 at N > 1; 'none' for profiling runs)")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--graph", default="off", choices=["off", "scan"], help="launch the scan as a HIP graph (experiment; plain launches are faster)")
@@ -649,6 +780,8 @@ def main():
     ap.add_argument("--op", default=None, choices=["matches", "contained_in", "find"], help="tuning runs: another op")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed device pre-warm (plain copies of the batch) before the W warm-up steps: "
                     "an idle GPU runs its first ~40 ms of load below its steady clocks; 0 = off")
+    ap.add_argument("--full-line", action="store_true", help="print everything measured on stdout (one long JSON line) instead of the digest; "
+                    "the default keeps the line under the 8 KB the driver's log tail holds and sends the full JSON to stderr / bench_full.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the read-ceiling probe, the must-read byte count and the host-landed figure")
     args = ap.parse_args()
@@ -694,7 +827,7 @@ def main():
         if int(ok.item()) == 0:
             ctx.comm = None
     if args.also is None:
-        also = ["c3", "c3s", "c5", "c5w"] if world == 1 else ["c3"]
+        also = ["c3", "c3s", "c3x", "c5", "c5w"] if world == 1 else ["c3"]
         if args.regex or args.op or args.rows != 10_000_000:
             also = []
     else:
@@ -745,7 +878,16 @@ def main():
                 r = {"error": "%s: %s" % (type(e).__name__, e)}
             out["workloads"][w] = r
     if rank == 0:
-        print(json.dumps(out))
+        # The driver keeps the last 8 KB of stdout: the ONE line printed there is the contract's fields + roofline + cpu_baseline +
+        # a compact digest of every workload (slim()); everything measured, with its notes, goes to stderr and bench_full.json.
+        full = json.dumps(out)
+        sys.stderr.write(full + "\n")
+        try:
+            with open(os.path.join("gpurun_out" if os.path.isdir("gpurun_out") else ".", "bench_full.json"), "w") as fh:
+                fh.write(full + "\n")
+        except OSError:
+            pass
+        print(full if args.full_line else json.dumps(slim_line(out)))
     if use_dist:
         dist.destroy_process_group()
 

@@ -7,7 +7,7 @@ OUT=gpurun_out/pmc_${W}_${TAG}
 mkdir -p $OUT
 i=0
 for grp in "$@"; do
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p -- python bench.py --workload $W $NEEDLE_BENCH_EXTRA --steps 3 --warmup 1 --also none --no-cpu-baseline --no-extras > $OUT/p$i.json 2> $OUT/p$i.log
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p -- python bench.py --workload $W $NEEDLE_BENCH_EXTRA --steps 3 --warmup 1 --also none --no-cpu-baseline --no-extras --full-line > $OUT/p$i.json 2> $OUT/p$i.log
   # only the scan kernel's counter rows are kept: gpurun copies back at most 64 MiB
   python - "$OUT/p$i/p_counter_collection.csv" <<'PY'
 import csv, sys

@@ -158,7 +158,7 @@ def test_bench_two_ranks_on_one_gpu(workload):
     import sys
     from conftest import ROOT
     base = [sys.executable, "bench.py", "--workload", workload, "--rows", "200000", "--steps", "3", "--warmup", "1", "--also", "none",
-            "--no-cpu-baseline", "--no-extras"]
+            "--no-cpu-baseline", "--no-extras", "--full-line"]
     one = subprocess.run(base, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
@@ -191,7 +191,7 @@ def test_c4_rehearsal_eight_ranks_full_batch_on_one_gpu():
     import sys
     from conftest import ROOT
     for workload in ("c2", "c3"):
-        base = [sys.executable, "bench.py", "--workload", workload, "--steps", "10", "--warmup", "2", "--also", "none", "--no-cpu-baseline", "--no-extras"]
+        base = [sys.executable, "bench.py", "--workload", workload, "--steps", "10", "--warmup", "2", "--also", "none", "--no-cpu-baseline", "--no-extras", "--full-line"]
         one = subprocess.run(base, capture_output=True, text=True, cwd=ROOT, timeout=900)
         assert one.returncode == 0, one.stderr[-2000:]
         d1 = json.loads(one.stdout.strip().splitlines()[-1])
