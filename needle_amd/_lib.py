@@ -10,7 +10,7 @@ NEEDLE_OK, ERR_INVALID, ERR_SYNTAX, ERR_COMPILE, ERR_UNSUPPORTED, ERR_DEVICE = 0
 
 EXPORTS = [
     "needle_version", "needle_last_error", "needle_device_count", "needle_trim_scratch", "needle_tuning_info", "needle_compile", "needle_pattern_from_tables",
-    "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_program_info", "needle_pattern_prefilter_info", "needle_pattern_match_lengths", "needle_pattern_find_all_transducer", "needle_pattern_get_class_map", "needle_pattern_get_table",
+    "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_program_info", "needle_pattern_prefilter_info", "needle_pattern_set_prefilter", "needle_pattern_prefilter_state", "needle_pattern_match_lengths", "needle_pattern_find_all_transducer", "needle_pattern_get_class_map", "needle_pattern_get_table",
     "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_find_packed16_dev", "needle_find_next_dev", "needle_find_all_dev", "needle_find_all_packed16_dev", "needle_count_matches_dev", "needle_find_all_csr_dev", "needle_find_all_host", "needle_find_all_packed16_host", "needle_find_all_csr_host",
     "needle_pack_start_end16_dev", "needle_unpack_start_end16_dev", "needle_matches_host",
     "needle_contained_in_host", "needle_find_host", "needle_find_compact_dev", "needle_find_compact_host", "needle_find_packed16_host", "needle_matcher_create", "needle_matcher_destroy",
@@ -54,6 +54,11 @@ class ProgramInfo(ctypes.Structure):
                                               "dense_rows", "records", "chains", "hot_rows", "window", "window_lo", "window_hi", "lengths_form")]
 
 
+class PrefilterState(ctypes.Structure):
+    _fields_ = ([(k, ctypes.c_int32) for k in ("mode", "has_filter", "suspended_calls_left", "backoff")] + [("last_candidates_per_kib", ctypes.c_float)] +
+                [(k, ctypes.c_uint64) for k in ("filter_launches", "suspended_calls")])
+
+
 class PrefilterInfo(ctypes.Structure):
     _fields_ = ([(k, ctypes.c_int32) for k in ("on", "mode", "stride", "warm", "min_len", "n_windows", "bitmap_bytes")] +
                 [(k, ctypes.c_uint32) for k in ("m1", "m2", "addr_shift", "addr_mask")] + [("why", ctypes.c_char * 96)] +
@@ -94,6 +99,8 @@ def lib():
     L.needle_pattern_find_all_transducer.argtypes = [VP, ctypes.c_int, P(ctypes.c_int32), P(ctypes.c_int32), VP, ctypes.c_size_t, P(ctypes.c_size_t)]
     L.needle_pattern_program_info.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, P(ProgramInfo)]
     L.needle_pattern_prefilter_info.argtypes = [VP, ctypes.c_int, P(PrefilterInfo), VP]
+    L.needle_pattern_set_prefilter.argtypes = [VP, ctypes.c_int]
+    L.needle_pattern_prefilter_state.argtypes = [VP, ctypes.c_int, P(PrefilterState)]
     L.needle_pattern_get_class_map.argtypes = [VP, VP]
     L.needle_pattern_get_table.argtypes = [VP, I, VP, VP]
     for n in ("needle_matches_dev", "needle_contained_in_dev"):

@@ -135,11 +135,16 @@ struct DevProgram {
     // and KiB of text to d_ng_stats; the pair is copied to the pinned h_ng_stats behind the kernel, on its stream.  The NEXT call
     // reads it without waiting: above 16 candidates per KiB (the break-even; the bench text has 3.3) the filter is suspended for
     // the program's next 32 calls, doubling up to 1024 while the text stays like that.  Answers are the same either way.
-    uint32_t *d_ng_stats = nullptr;
-    volatile uint32_t *h_ng_stats = nullptr;
-    mutable std::atomic<int> ng_suspend{0}, ng_backoff{32};
+    uint32_t *d_ng_stats = nullptr;            // {candidates, KiB of text}: MONOTONIC device counters (never reset by the host)
+    volatile uint64_t *h_ng_stats = nullptr;    // pinned: the pair as it stood behind the last completed filter launch (one 8-byte copy)
+    // the watch's own state, per program (= per pattern x device x op), shared by every stream and thread that uses it
+    mutable std::mutex ng_mu;
+    mutable uint32_t ng_seen_cand = 0, ng_seen_kib = 0; // what the last evaluation had seen: the watch works on deltas
+    mutable int ng_suspend = 0, ng_backoff = 32;
+    mutable float ng_last_rate = 0.0f;
+    mutable uint64_t ng_launches = 0, ng_suspended_calls = 0;
     DevProgram() = default;
-    DevProgram(DevProgram &&o) noexcept : prog(std::move(o.prog)), d_blob(o.d_blob), d_ng(o.d_ng), d_ng_stats(o.d_ng_stats), h_ng_stats(o.h_ng_stats) {
+    DevProgram(DevProgram &&o) noexcept : prog(std::move(o.prog)), d_blob(o.d_blob), d_ng(o.d_ng), d_ng_stats(o.d_ng_stats), h_ng_stats(o.h_ng_stats) { // (moved before first use: the watch's state starts fresh)
         o.d_blob = nullptr, o.d_ng = nullptr, o.d_ng_stats = nullptr, o.h_ng_stats = nullptr;
     }
 };
@@ -165,6 +170,7 @@ struct needle_pattern {
         std::vector<uint32_t> bitmap;
     } pf_cache[4];
     std::mutex pf_mu;
+    std::atomic<int> pf_mode{0}; // needle_pattern_set_prefilter: 0 auto (the flood watch decides), 1 on (never suspended), 2 off (never used)
     std::mutex ml_mu;       // guards the one-time match-length analysis only: scans of programs that exist already do not wait for it
     int ml_state = 0;       // 0: not analysed yet, 1: find-all can report starts as end - length (ml), -1: it cannot
     MatchLengths ml;
@@ -259,7 +265,7 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
                 if (dp.d_ng_stats) (void)hipFree(dp.d_ng_stats);
                 return hip_fail(ce, "hipMalloc/hipMemcpy(n-gram bitmap)");
             }
-            dp.h_ng_stats[0] = dp.h_ng_stats[1] = 0;
+            dp.h_ng_stats[0] = 0;
         }
         it = p->cache.emplace(key, std::move(dp)).first;
     }
@@ -352,31 +358,49 @@ static int run_stripe_path(needle_pattern *p, int op, const needle_batch_view *v
     return NEEDLE_OK;
 }
 
-// Flood watch of the filter kernel (DevProgram): reads what the last completed filter launch of this program saw; false = this call
-// takes the ordinary kernel (the program is suspended, one call fewer from now).  NEEDLE_PREFILTER_WATCH=0: always true.
-static bool ngram_watch_allows(const DevProgram *fp) {
-    const uint32_t seen_cand = fp->h_ng_stats[0], seen_kib = fp->h_ng_stats[1];
-    if (seen_kib >= 1024u) {
-        fp->h_ng_stats[1] = 0;
-        if (seen_cand > 16u * (uint64_t)seen_kib) {
-            const int b = fp->ng_backoff.load();
-            fp->ng_suspend.store(b);
-            fp->ng_backoff.store(b < 1024 ? 2 * b : 1024);
+// Flood watch of the filter kernel (DevProgram).  Text that passes the filter almost everywhere makes that kernel several times
+// slower than the ordinary scan; every filter launch ADDS its candidates and KiB of text to two monotonic device counters, copied
+// (one 8-byte copy) to pinned memory behind the kernel.  The next call of that program looks at what has arrived -- without waiting --
+// and works on the DELTA against what the last evaluation saw: above 16 candidates per KiB the filter is suspended for the program's
+// next 32 calls, doubling to 1024 while the text stays like that.  One mutex per program: the state is per pattern x device x op, NOT per
+// stream -- concurrent streams share one verdict (and one backoff).  Answers are the same either way.
+//   needle_pattern_set_prefilter(p, NEEDLE_PREFILTER_AUTO | _ON | _OFF) pins the decision (ON: never suspended; OFF: the ordinary kernels);
+//   needle_pattern_prefilter_state() reports it.  Under HIP-graph capture the decision is the one taken at CAPTURE time and is replayed
+//   as captured -- the stats copy is not captured (a captured graph neither feeds nor obeys the watch): pin the mode for captured work.
+// false = this call takes the ordinary kernel.  NEEDLE_PREFILTER_WATCH=0: the watch never suspends.
+static bool ngram_watch_allows(const needle_pattern *p, const DevProgram *fp) {
+    const int mode = p->pf_mode.load();
+    if (mode == 2) return false;
+    static const bool watch_on = !(getenv("NEEDLE_PREFILTER_WATCH") && atoi(getenv("NEEDLE_PREFILTER_WATCH")) == 0);
+    std::lock_guard<std::mutex> lk(fp->ng_mu);
+    const uint64_t both = fp->h_ng_stats[0]; // (one aligned 8-byte read of what one 8-byte copy wrote)
+    const uint32_t cand = (uint32_t)both, kib = (uint32_t)(both >> 32);
+    const uint32_t d_cand = cand - fp->ng_seen_cand, d_kib = kib - fp->ng_seen_kib; // (unsigned: the counters may wrap)
+    if (d_kib >= 1024u) {
+        fp->ng_seen_cand = cand, fp->ng_seen_kib = kib;
+        fp->ng_last_rate = (float)d_cand / (float)d_kib;
+        if (mode == 1) {
+            // (pinned ON: the rate is still reported; no suspension is scheduled for a later return to AUTO)
+        } else if ((uint64_t)d_cand > 16ull * d_kib) {
+            fp->ng_suspend = fp->ng_backoff;
+            fp->ng_backoff = fp->ng_backoff < 1024 ? 2 * fp->ng_backoff : 1024;
         } else {
-            fp->ng_backoff.store(32);
+            fp->ng_backoff = 32;
         }
     }
-    static const bool watch_on = !(getenv("NEEDLE_PREFILTER_WATCH") && atoi(getenv("NEEDLE_PREFILTER_WATCH")) == 0);
-    if (!watch_on || fp->ng_suspend.load() <= 0) return true;
-    fp->ng_suspend.fetch_sub(1);
+    if (mode == 1 || !watch_on || fp->ng_suspend <= 0) {
+        ++fp->ng_launches;
+        return true;
+    }
+    --fp->ng_suspend;
+    ++fp->ng_suspended_calls;
     return false;
 }
-// (behind the kernel on its stream; the host never waits for it.  Concurrent launches on other streams may mix their counts: the watch
-// is a heuristic, the answers do not depend on it)
+// (behind the kernel on its stream; the host never waits for it)
 static hipError_t ngram_watch_after_launch(const DevProgram *fp, hipStream_t stream) {
-    hipError_t e = hipMemcpyAsync((void *)fp->h_ng_stats, fp->d_ng_stats, 8, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(fp->d_ng_stats, 0, 8, stream);
-    return e;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipSuccess; // (not captured: see above)
+    return hipMemcpyAsync((void *)fp->h_ng_stats, fp->d_ng_stats, 8, hipMemcpyDeviceToHost, stream);
 }
 
 // NEEDLE_FIND_LENGTHS: 0 = find() always by forward + backward walks, 1 (default) = the "lengths" automaton where the ordinary
@@ -582,7 +606,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
             a.start = d_start;
             a.end = d_end;
             a.packed = d_packed;
-            if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(tp)) {
+            if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
                 HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream));
                 HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
                 return NEEDLE_OK;
@@ -673,7 +697,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // (needle_ngram_host.cpp), on containedIn() and on find() whose start is end - length (lengths programs, one-length patterns).
     if (fp->d_ng && fp->prog.ng.p.on && ngram_level() > 0 && v->char_width == 1 && op != OP_MATCHES && !skip_backward &&
         (op == OP_CONTAINED_IN || lengths_form || a.fixed_len >= 0) && ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, fp->prog.ng.p)) {
-        if (ngram_watch_allows(fp)) {
+        if (ngram_watch_allows(p, fp)) {
             HIP_TRY(launch_ngram(op, a, fp->prog.ng.p, fp->d_ng, fp->d_ng_stats, n_cus, (hipStream_t)stream));
             HIP_TRY(ngram_watch_after_launch(fp, (hipStream_t)stream));
             return NEEDLE_OK;
@@ -1203,6 +1227,42 @@ int needle_pattern_prefilter_info(const needle_pattern *cp, int which, needle_pr
     return NEEDLE_OK;
 }
 
+int needle_pattern_set_prefilter(needle_pattern *p, int mode) {
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    if (mode < 0 || mode > 2) return fail(NEEDLE_ERR_INVALID, "mode must be NEEDLE_PREFILTER_AUTO (0), _ON (1) or _OFF (2)");
+    p->pf_mode.store(mode);
+    return NEEDLE_OK;
+}
+
+// What the flood watch of this pattern's filter program(s) for `which` on the CURRENT device knows (no device needed to ask; all zero
+// before the first scan).  Several programs may carry a filter (plain / lengths / HBM-table forms): the one that ran last is reported.
+int needle_pattern_prefilter_state(const needle_pattern *cp, int which, needle_prefilter_state *o) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    if (which != W_CONTAINED_IN && which != W_FORWARDS) return fail(NEEDLE_ERR_INVALID, "which must be 1 (contained_in) or 2 (forwards)");
+    memset(o, 0, sizeof(*o));
+    o->mode = p->pf_mode.load();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NEEDLE_OK; // (no device: nothing has run)
+    std::lock_guard<std::mutex> lk(p->mu);
+    uint64_t best = 0;
+    for (auto &kv : p->cache) {
+        if (std::get<0>(kv.first) != dev || std::get<1>(kv.first) != which || !kv.second.d_ng) continue;
+        const DevProgram &dp = kv.second;
+        std::lock_guard<std::mutex> lk2(dp.ng_mu);
+        o->has_filter = 1;
+        const uint64_t used = dp.ng_launches + dp.ng_suspended_calls;
+        if (used < best) continue;
+        best = used;
+        o->suspended_calls_left = dp.ng_suspend;
+        o->backoff = dp.ng_backoff;
+        o->last_candidates_per_kib = dp.ng_last_rate;
+        o->filter_launches = dp.ng_launches;
+        o->suspended_calls = dp.ng_suspended_calls;
+    }
+    return NEEDLE_OK;
+}
+
 static int prefilter_info_uncached(const needle_pattern *p, int which, needle_prefilter_info *o, std::vector<uint32_t> *bitmap_out) {
     memset(o, 0, sizeof(*o));
     const bool backward = which == W_FORWARDS && p->t.fixed_len < 0;
@@ -1499,7 +1559,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
             a.prog = sp->d_blob;
             a.hdr = sp->prog.hdr;
             a.fixed_len = p->t.fixed_len;
-            if (ngram_shape_ok(a) && ngram_watch_allows(sp)) {
+            if (ngram_shape_ok(a) && ngram_watch_allows(p, sp)) {
                 int32_t *d_more = nullptr;
                 HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
                 hipError_t e = hipMemsetAsync(d_more, 0, 4, stream);

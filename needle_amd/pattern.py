@@ -200,6 +200,19 @@ class Pattern:
                 out["bitmap2"] = bm[i.bitmap_bytes // 4:]  # the second level's (5-byte windows)
         return out
 
+    PREFILTER_AUTO, PREFILTER_ON, PREFILTER_OFF = 0, 1, 2
+
+    def set_prefilter(self, mode):
+        """needle_pattern_set_prefilter: AUTO (the flood watch decides), ON (the filter kernel whenever the shape allows, never suspended),
+        OFF (the ordinary scan kernels).  Answers are the same in all three."""
+        _check(_lib.lib().needle_pattern_set_prefilter(self._h, int(mode)))
+
+    def prefilter_state(self, which="forwards"):
+        """needle_pattern_prefilter_state: what the flood watch of this pattern's filter program knows on the current device."""
+        st = _lib.PrefilterState()
+        _check(_lib.lib().needle_pattern_prefilter_state(self._h, list(WHICH).index(which), ctypes.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
     def match_length_automaton(self):
         """The refined forward automaton behind find-all's "lengths" form (needle_pattern_match_lengths), or None when the
         pattern does not allow it -> {"n_states", "n_dead", "max_char", "table" int16[n, stride + 1] (last column: chars beyond max_char), "accepting"

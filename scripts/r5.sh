@@ -46,7 +46,15 @@ PY
     head -5 $P/$w/t_kernel_stats.csv | cut -c1-160; head -5 $P/${w}_packed/t_kernel_stats.csv | cut -c1-160; cat $P/${w}_pmc.txt
   done ;;
 bench)
-  timeout 1700 python bench.py "$@" > $O/bench_$TAG.json 2> $O/bench_$TAG.err; tail -2 $O/bench_$TAG.err; tail -c 1500 $O/bench_$TAG.json ;;
+  timeout 1700 python bench.py "$@" > $O/bench_$TAG.json 2> $O/bench_$TAG.err; grep -v "^{" $O/bench_$TAG.err | tail -3; wc -c $O/bench_$TAG.json; tail -c 1200 $O/bench_$TAG.json ;;
+repeat)
+  # repeat <workload> <n> [bench args]: the same bench line n times in one lease (timed / cold / steady ms, kernel ms), clocks before and after
+  w=$1; n=$2; shift 2
+  rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk|fclk" | head -6
+  for i in $(seq $n); do
+    python bench.py --workload $w --also none --no-cpu-baseline --no-extras --full-line "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$w', 'timed', round(d['ms_per_step'],4), 'kernel', round(d['roofline']['kernel_ms'],4), 'cold', round(d['cold']['ms_per_step'],4), 'steady', round(d['steady']['ms_per_step'],4), 'frac', round(d['roofline']['frac'],4))"
+  done
+  rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk|fclk" | head -6 ;;
 py)
   s=$1; shift
   python $s "$@" > $O/$(basename $s .py)_$TAG.log 2>&1; tail -40 $O/$(basename $s .py)_$TAG.log ;;
