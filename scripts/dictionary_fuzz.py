@@ -79,16 +79,18 @@ for l, dl in ((None, None), (lens, tl)):
     for i, w in want.items():
         assert cc[i] == len(w), ("count pass", seed, i)
 pf = p.prefilter_info("forwards")
-print("DICT-OK seed %d: %d keywords over %d letters, %d states, mode %d, lengths form %d, n-gram filter %s, %d of %d rows match" % (
+ft = p.find_all_transducer(1)  # (the budget is the process's: a transducer reported here is the one find-all walked in lock-step)
+print("DICT-OK seed %d: %d keywords over %d letters, %d states, mode %d, lengths form %d, n-gram filter %s, find-all %s, %d of %d rows match" % (
     seed, len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"],
-    ("stride %d run-up %d" % (pf["stride"], pf["warm"])) if pf["on"] else "off", int(of.sum()), n))
+    ("stride %d run-up %d%s" % (pf["stride"], pf["warm"], " +level 2" if pf["on2"] else "")) if pf["on"] else "off",
+    ("lock-step (%d states)" % ft["n_states"]) if ft is not None and not pf["on"] else "filter form" if pf["on"] else "one-pass kernel", int(of.sum()), n))
 '''
 if __name__ == "__main__":
     seed0, cnt = int(sys.argv[1]), int(sys.argv[2])
     bad = 0
     for seed in range(seed0, seed0 + cnt):
         env = dict(os.environ)
-        if seed % 4: env["NEEDLE_MAX_PROG_LDS"] = str([12000, 20000, 40000][seed % 3])  # smaller dictionaries into the compressed form too
+        if seed % 4 and not os.environ.get("FUZZ_DEFAULT_BUDGET"): env["NEEDLE_MAX_PROG_LDS"] = str([12000, 20000, 40000][seed % 3])  # smaller dictionaries into the compressed form too
         r = subprocess.run([sys.executable, "-c", CODE, str(seed)], env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
         line = [x for x in r.stdout.splitlines() if x.startswith("DICT-OK")]
         if line: print(line[0], "(LDS budget %s)" % env.get("NEEDLE_MAX_PROG_LDS", "default"))

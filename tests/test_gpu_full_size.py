@@ -279,14 +279,37 @@ def test_c5w_full_size_properties():
 
 
 @pytest.mark.gpu
-def test_c3s_find_all_behind_the_filter_full_size():
-    """C3-sparse at 10^7 rows: every match of every row through the n-gram filter kernel's find-all form: slot 0 == find() on every
-    row (another kernel path), counts == the counting pass, matches ordered and disjoint, every match spells a keyword (torch gather on
-    a slab), the oracle's repeated find() on rows sampled over the whole batch."""
+def test_c3_full_size_find_all_with_the_lock_step_kernel_off():
+    """The same find-all properties with NEEDLE_FIND_ALL_LOCKSTEP=0 (read once per process: a child): the per-lane one-pass kernel
+    (needle_find_all.hip) stays correct at the full size beside the lock-step one that is the default for this dictionary."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_full_size.py", "-x", "-q", "-m", "gpu", "-k", "test_c3_full_size_find_all_properties"],
+                       env=dict(os.environ, NEEDLE_FIND_ALL_LOCKSTEP="0"), capture_output=True, text=True, timeout=1800, cwd=root)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c3s", "c3x"])
+def test_c3s_find_all_behind_the_filter_full_size(workload):
+    """C3-sparse (and c3x: 3000 keywords at the reference's state limit, the filter's walks out of HBM / L2) at 10^7 rows: find() and
+    containedIn() against the oracle on rows sampled over the whole batch; every match of every row through the n-gram filter kernel's
+    find-all form: slot 0 == find() on every row (another kernel path), counts == the counting pass, matches ordered and disjoint, every
+    match spells a keyword, the oracle's repeated find() on sampled rows."""
     import torch
     from needle_amd.pattern import unpack_bitmap
-    p, rows, words = make("c3s")
-    assert p.prefilter_info("forwards")["on"] == 1
+    p, rows, words = make(workload)
+    assert p.prefilter_info("forwards")["on"] == 1 and p.prefilter_info("forwards")["mode"] == (6 if workload == "c3s" else 3)
+    if workload == "c3x":
+        fw0, fs0, fe0 = p.find_batch(rows)
+        cw0 = p.contained_in_batch(rows)
+        assert torch.equal(fw0, cw0)
+        f_bits = unpack_bitmap(fw0, rows.shape[0])
+        assert 0.24 < f_bits.mean() < 0.26
+        check_sample_against_oracle(p, rows, f_bits, fs0.cpu().numpy(), fe0.cpu().numpy(), unpack_bitmap(cw0, rows.shape[0]))
+        partition_invariant(p.find_batch, rows, fw0)
     n, slots = rows.shape[0], 4
     counts, st, en, more = p.find_all_dense(rows, slots)
     assert not more
