@@ -131,7 +131,7 @@ struct DevProgram {
     uint32_t *d_ng = nullptr; // the n-gram filter's bitmap (prog.ng.p.on)
     // Flood watch of the n-gram filter kernel.  Text that passes the filter almost everywhere (built from the dictionary's own
     // keyword tails: one automaton run per window) makes that kernel several times SLOWER than the ordinary scan (measured:
-    // 5.3 against 1.13 ms on the C3-sparse dictionary, scripts/r4_ngram_worstcase.py).  Every filter launch adds its candidates
+    // 5.3 against 1.13 ms on the C3-sparse dictionary, scripts/ngram_worstcase.py).  Every filter launch adds its candidates
     // and KiB of text to d_ng_stats; the pair is copied to the pinned h_ng_stats behind the kernel, on its stream.  The NEXT call
     // reads it without waiting: above 16 candidates per KiB (the break-even; the bench text has 3.3) the filter is suspended for
     // the program's next 32 calls, doubling up to 1024 while the text stays like that.  Answers are the same either way.

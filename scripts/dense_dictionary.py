@@ -4,7 +4,7 @@ back to back (separated by one space), 10M x 256 -- the opposite extreme of benc
 of the steps are in states of depth <= 2).  find() then matches in the first chars of every row, so the figure that says what
 the table walk costs is containedIn/matches-free: `matches()` never matches here and `find` on a dictionary of words that do
 NOT occur walks whole rows: the haystack is built from a SECOND dictionary sharing 4-char prefixes with the first.
-Usage: python scripts/r3_dense_dictionary.py [rows]"""
+Usage: python scripts/dense_dictionary.py [rows] [keywords]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +14,8 @@ from needle_amd import workload as W
 from needle_amd.pattern import DFACompiler, unpack_bitmap
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-words = W.keywords(1000, min_len=6, max_len=8)
+n_kw = int(sys.argv[2]) if len(sys.argv) > 2 else 1000  # 3000: the dictionary at the reference's state limit (bench.py c3x)
+words = W.keywords(n_kw, min_len=6, max_len=8)
 # decoys: the first 5 chars of a keyword + 2 other chars -- never a keyword, but they drag the automaton to depth 5
 rng = np.random.default_rng(11)
 kw = set(words)

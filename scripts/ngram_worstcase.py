@@ -2,7 +2,7 @@
 """Round 4, f-4: the n-gram filter kernel on text built to defeat it -- rows made of the dictionary's own keywords with the FIRST
 char replaced (the windows the filter keys on are the LAST chars of a keyword: every slot is a candidate, almost none is a match) --
 against the ordinary scan kernel on the same rows (NEEDLE_PREFILTER=0), and on the bench's own text for reference.
-Usage: NEEDLE_PREFILTER=0|1 python scripts/r4_ngram_worstcase.py [rows]"""
+Usage: NEEDLE_PREFILTER=0|1 python scripts/ngram_worstcase.py [rows] [keywords]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +12,8 @@ from needle_amd import workload as W
 from needle_amd.pattern import DFACompiler, unpack_bitmap
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-words = W.keywords(1000, min_len=6, max_len=8)
+n_kw = int(sys.argv[2]) if len(sys.argv) > 2 else 1000  # 3000: the dictionary at the reference's state limit (bench.py c3x)
+words = W.keywords(n_kw, min_len=6, max_len=8)
 p = DFACompiler.compile("|".join(words), "t", 0)
 slot = np.zeros((len(words), 8), dtype=np.uint8) + 32
 for i, w in enumerate(words):
