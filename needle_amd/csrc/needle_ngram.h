@@ -85,7 +85,10 @@ inline uint32_t ngram_word_bits(uint32_t u, uint32_t addr_shift) { return 1u << 
 __device__ __forceinline__ uint32_t ngram_probe(uint32_t x, uint32_t m, uint32_t addr_mask, uint32_t bm_base) {
     uint32_t u, r1, r2;
     asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(u) : "v"(x), "v"(m));
-    const uint32_t a = (u & addr_mask) | bm_base; // v_and_or_b32
+    // (u & addr_mask) | bm_base as ONE instruction: left to the compiler the two wave-uniform operands sit in SGPRs, of which a VOP3 on
+    // gfx9 may read one -- it emits v_and + v_or; the base in a VGPR (loop-invariant: one v_mov per kernel) makes v_and_or_b32 legal
+    uint32_t a;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(u), "s"(addr_mask), "v"(bm_base));
     const uint32_t w = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a;
     asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r1) : "v"(u), "v"(w)); // w >> (u >> 24 & 31)
     asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r2) : "v"(u), "v"(w)); // w >> (u >> 16 & 31)
@@ -107,24 +110,45 @@ __device__ __forceinline__ uint32_t ngram_probe2(uint32_t x, uint32_t c5, uint32
 // that END in this piece at the sampled positions -- S = 2: the windows starting at byte -2, 0, 2, .. 12 of the piece -- and
 // shifts their verdicts into `log` from the top (v_alignbit): afterwards bit 31 = the last window of this piece, bit 32 - n = its
 // first one (n = 16 / S windows), and whatever the log held before sits n bits further down.
+// Three phases, so that ONE LDS round trip is exposed per piece instead of one per window or two: all hashes and addresses, all
+// bitmap reads back to back, one wait, then the shifts (left to the scheduler the first reads of a piece are each waited for at once).
 template <int S>
 __device__ __forceinline__ uint32_t ngram_piece(uint32_t log, uint32_t pw, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t m,
                                                 uint32_t addr_mask, uint32_t bm_base) {
-#define NEEDLE_NG(X) log = __builtin_amdgcn_alignbit(ngram_probe((X), m, addr_mask, bm_base), log, 1);
+    constexpr int NWIN = 16 / S;
+    uint32_t x[NWIN];
     if (S == 4) { // windows ending at byte 4, 8, 12, 16: the piece's own dwords
-        NEEDLE_NG(w0) NEEDLE_NG(w1) NEEDLE_NG(w2) NEEDLE_NG(w3)
+        x[0] = w0, x[1] = w1, x[2] = w2, x[3] = w3;
     } else if (S == 2) { // ending at byte 2, 4, .. 16
-        NEEDLE_NG(__builtin_amdgcn_alignbit(w0, pw, 16)) NEEDLE_NG(w0)
-        NEEDLE_NG(__builtin_amdgcn_alignbit(w1, w0, 16)) NEEDLE_NG(w1)
-        NEEDLE_NG(__builtin_amdgcn_alignbit(w2, w1, 16)) NEEDLE_NG(w2)
-        NEEDLE_NG(__builtin_amdgcn_alignbit(w3, w2, 16)) NEEDLE_NG(w3)
+        const uint32_t q[5] = {pw, w0, w1, w2, w3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[2 * i] = __builtin_amdgcn_alignbit(q[i + 1], q[i], 16), x[2 * i + 1] = q[i + 1];
     } else { // S == 1: ending at byte 1 .. 16
-        NEEDLE_NG(__builtin_amdgcn_alignbit(w0, pw, 8)) NEEDLE_NG(__builtin_amdgcn_alignbit(w0, pw, 16)) NEEDLE_NG(__builtin_amdgcn_alignbit(w0, pw, 24)) NEEDLE_NG(w0)
-        NEEDLE_NG(__builtin_amdgcn_alignbit(w1, w0, 8)) NEEDLE_NG(__builtin_amdgcn_alignbit(w1, w0, 16)) NEEDLE_NG(__builtin_amdgcn_alignbit(w1, w0, 24)) NEEDLE_NG(w1)
-        NEEDLE_NG(__builtin_amdgcn_alignbit(w2, w1, 8)) NEEDLE_NG(__builtin_amdgcn_alignbit(w2, w1, 16)) NEEDLE_NG(__builtin_amdgcn_alignbit(w2, w1, 24)) NEEDLE_NG(w2)
-        NEEDLE_NG(__builtin_amdgcn_alignbit(w3, w2, 8)) NEEDLE_NG(__builtin_amdgcn_alignbit(w3, w2, 16)) NEEDLE_NG(__builtin_amdgcn_alignbit(w3, w2, 24)) NEEDLE_NG(w3)
+        const uint32_t q[5] = {pw, w0, w1, w2, w3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[4 * i] = __builtin_amdgcn_alignbit(q[i + 1], q[i], 8), x[4 * i + 1] = __builtin_amdgcn_alignbit(q[i + 1], q[i], 16);
+            x[4 * i + 2] = __builtin_amdgcn_alignbit(q[i + 1], q[i], 24), x[4 * i + 3] = q[i + 1];
+        }
     }
-#undef NEEDLE_NG
+    uint32_t u[NWIN], wv[NWIN];
+#pragma unroll
+    for (int i = 0; i < NWIN; ++i) {
+        asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(u[i]) : "v"(x[i]), "v"(m));
+        uint32_t a;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(u[i]), "s"(addr_mask), "v"(bm_base)); // (one SGPR per VOP3: the base rides in a VGPR)
+        wv[i] = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): all of the piece's bitmap words
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NWIN; ++i) {
+        uint32_t r1, r2;
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r1) : "v"(u[i]), "v"(wv[i])); // w >> (u >> 24 & 31)
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r2) : "v"(u[i]), "v"(wv[i])); // w >> (u >> 16 & 31)
+        log = __builtin_amdgcn_alignbit(r1 & r2, log, 1);
+    }
     return log;
 }
 

@@ -47,6 +47,23 @@ PY
   done ;;
 bench)
   timeout 1700 python bench.py "$@" > $O/bench_$TAG.json 2> $O/bench_$TAG.err; grep -v "^{" $O/bench_$TAG.err | tail -3; wc -c $O/bench_$TAG.json; tail -c 1200 $O/bench_$TAG.json ;;
+profiles)
+  # everything profiles/r05_* is made from (then: summarize_profile.py gpurun_out/prof_<w> 05 <w>, summarize_pmc.py 05)
+  for w in c2 c3 c3s c3x c5 c5w; do scripts/profile.sh $w > gpurun_out/profile_$w.log 2>&1; done
+  G1="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SMEM"
+  G2="SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY"
+  G3="SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+  scripts/pmc.sh c3s r5final "$G1" "$G2" "$G3" > gpurun_out/pmc_c3s_r5final.log 2>&1
+  NEEDLE_PREFILTER_LEVEL2=0 scripts/pmc.sh c3s r5nolevel2 "$G1" "$G2" "$G3" > gpurun_out/pmc_c3s_r5nolevel2.log 2>&1
+  scripts/pmc.sh c3x r5 "$G1" "$G2" "$G3" > gpurun_out/pmc_c3x_r5.log 2>&1
+  NEEDLE_PREFILTER=0 scripts/pmc.sh c3x r5scan "$G1" "$G2" "$G3" > gpurun_out/pmc_c3x_r5scan.log 2>&1
+  scripts/pmc.sh c3 r5 "$G1" "$G2" "$G3" > gpurun_out/pmc_c3_r5.log 2>&1
+  scripts/pmc.sh c5 r5 "$G1" "$G2" "$G3" > gpurun_out/pmc_c5_r5.log 2>&1
+  scripts/pmc.sh c5w r5 "$G1" "$G2" "$G3" > gpurun_out/pmc_c5w_r5.log 2>&1
+  rm -rf $O/fa_prof; $0 fa_prof c3 > $O/fa_prof.log 2>&1
+  NEEDLE_FIND_ALL_LOCKSTEP=0 R5_SUB=ls0 bash -c 'P=gpurun_out/r5/fa_prof_ls0; mkdir -p $P; FIND_ALL_PROBE_PACKED=1 FIND_ALL_PROBE_DENSE_ONLY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $P/c3_packed -o t -- python scripts/find_all_probe.py c3 10000000 32 > $P/c3_packed.json 2> $P/err.log; find $P -name "*_kernel_trace.csv" -delete; find $P -name "*_agent_info.csv" -delete'
+  for w in c3 c3s c3x c2 c5; do python scripts/find_all_probe.py $w 10000000 32 check 2>/dev/null | tail -1 > $O/fa_$w.json; FIND_ALL_PROBE_PACKED=1 python scripts/find_all_probe.py $w 10000000 32 2>/dev/null | tail -1 > $O/fa_${w}_packed.json; done
+  timeout 1700 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python scripts/bench_digest.py $O/bench_default.json ;;
 repeat)
   # repeat <workload> <n> [bench args]: the same bench line n times in one lease (timed / cold / steady ms, kernel ms), clocks before and after
   w=$1; n=$2; shift 2

@@ -43,6 +43,13 @@ SETS = {
            ("c5w find: flat 64 KB page map (shipped)", "pmc_c5w_r4flat"),
            ("c5w containedIn: two-level page map (NEEDLE_FLAT_MAP=0)", "pmc_c5w_r4contained"),
            ("c5w containedIn: flat page map (shipped)", "pmc_c5w_r4flatc")],
+    "05": [("c3s find: n-gram filter kernel + second-level 5-byte window, two queues (shipped)", "pmc_c3s_r5final"),
+           ("c3s find: the same without the second level (NEEDLE_PREFILTER_LEVEL2=0: round 4's kernel)", "pmc_c3s_r5nolevel2"),
+           ("c3x find (3000 keywords, 12 270 states): filter kernel, candidates' walks out of HBM / L2 (shipped)", "pmc_c3x_r5"),
+           ("c3x find: hot rows in LDS + HBM table in the scan kernel (NEEDLE_PREFILTER=0: what round 4 would have run)", "pmc_c3x_r5scan"),
+           ("c3 find (lengths automaton, LDS table u16; unchanged kernel)", "pmc_c3_r5"),
+           ("c5 find (packed functions; unchanged kernel)", "pmc_c5_r5"),
+           ("c5w find: LDS table u8 behind the flat page map (unchanged kernel)", "pmc_c5w_r5")],
 }
 sets = SETS[RND]
 keys = ["kernel_us", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
