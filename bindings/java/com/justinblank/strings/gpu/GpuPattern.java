@@ -206,6 +206,24 @@ public final class GpuPattern implements Pattern, AutoCloseable {
         return info[0] != 0 ? "" : why;
     }
 
+    public static final int PREFILTER_AUTO = 0, PREFILTER_ON = 1, PREFILTER_OFF = 2;
+
+    /**
+     * Pins the n-gram filter's flood watch (needle_pattern_set_prefilter): ON = the filter kernel whenever the batch shape allows it,
+     * never suspended; OFF = the ordinary scan kernels; AUTO = the watch decides (default).  Answers are the same in all three; pin
+     * the mode for work captured into a HIP graph.
+     */
+    public void setPrefilter(int mode) {
+        check(Native.setPrefilter(handle, mode), null);
+    }
+
+    /** Calls of find() batches that will still take the ordinary kernel because the last evaluated text flooded the filter (0: none). */
+    public int prefilterSuspendedCallsLeft() {
+        int[] st = new int[4];
+        check(Native.prefilterState(handle, 2, st, new float[1], new long[2]), null);
+        return st[2];
+    }
+
     /** The library's NEEDLE_* environment switches (needle_tuning_info). */
     public static String tuningInfo() {
         return Native.tuningInfo();

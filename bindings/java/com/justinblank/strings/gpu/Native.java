@@ -90,6 +90,15 @@ final class Native {
      */
     static native String prefilterInfo(long handle, int which, int[] info);
 
+    /** needle_pattern_set_prefilter: 0 auto (the flood watch decides), 1 on (never suspended), 2 off (the ordinary kernels). */
+    static native int setPrefilter(long handle, int mode);
+
+    /**
+     * needle_pattern_prefilter_state (which: 1 containedIn, 2 find): state[0..3] = mode, has_filter, suspended calls left, backoff;
+     * rate[0] = candidates per KiB of the last evaluation; counts[0..1] = filter launches, suspended calls.
+     */
+    static native int prefilterState(long handle, int which, int[] state, float[] rate, long[] counts);
+
     /** needle_pattern_serialize / needle_pattern_deserialize: the precompiled-pattern blob (Precompile's analogue). */
     static native byte[] serialize(long handle);
 

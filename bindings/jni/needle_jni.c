@@ -240,6 +240,29 @@ NATIVE(jstring, prefilterInfo)(JNIEnv *env, jclass c, jlong h, jint which, jintA
     return (*env)->NewStringUTF(env, pi.why);
 }
 
+/* needle_pattern_set_prefilter / needle_pattern_prefilter_state: the filter's flood watch pinned and reported (include/needle_hip.h).
+ * state[0..3] = mode, has_filter, suspended_calls_left, backoff; rate[0] = last candidates per KiB; counts[0..1] = launches, suspended calls. */
+NATIVE(jint, setPrefilter)(JNIEnv *env, jclass c, jlong h, jint mode) { return needle_pattern_set_prefilter((needle_pattern *)(intptr_t)h, mode); }
+
+NATIVE(jint, prefilterState)(JNIEnv *env, jclass c, jlong h, jint which, jintArray state, jfloatArray rate, jlongArray counts) {
+    needle_prefilter_state st;
+    const int rc = needle_pattern_prefilter_state((const needle_pattern *)(intptr_t)h, which, &st);
+    if (rc != NEEDLE_OK) return rc;
+    if (int_room(env, state, 4)) {
+        const jint v[4] = {st.mode, st.has_filter, st.suspended_calls_left, st.backoff};
+        (*env)->SetIntArrayRegion(env, state, 0, 4, v);
+    }
+    if (rate && (*env)->GetArrayLength(env, rate) >= 1) {
+        const jfloat r = st.last_candidates_per_kib;
+        (*env)->SetFloatArrayRegion(env, rate, 0, 1, &r);
+    }
+    if (counts && (*env)->GetArrayLength(env, counts) >= 2) {
+        const jlong v[2] = {(jlong)st.filter_launches, (jlong)st.suspended_calls};
+        (*env)->SetLongArrayRegion(env, counts, 0, 2, v);
+    }
+    return NEEDLE_OK;
+}
+
 NATIVE(jint, packedHost)(JNIEnv *env, jclass c, jlong h, jint op, jcharArray data, jlongArray offsets, jlongArray bitmap, jintArray start, jintArray end) {
     needle_packed_view v;
     memset(&v, 0, sizeof(v));
