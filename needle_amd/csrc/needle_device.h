@@ -109,7 +109,8 @@ struct ProgHeader {
     // state << 4 | code, code != 0 = "this transition ends a match"; codes[code] = (k + length) | k << 16 (uint32, LDS at ft_codes_off):
     // end = index of the char that took the transition - k, start = end - length.  State 0 = dead (row finished).  ft_odd: at most 8
     // codes, numbered 1, 3, .. 15 (bit 0 of an entry = "a match ends here").
-    // ft_direct: every code has k = 0 and is its own length (1 .. 15): no table lookup when a match is filed.
+    // ft_direct: every code has k = 0 and names its own length -- no table lookup when a match is filed: 1 = the code is the length (1 .. 15),
+    // 2 = the code is length << 1 | 1 (lengths 1 .. 7; ft_odd holds too).
     uint32_t ft_on, ft_codes_off, ft_odd, ft_direct;
     uint32_t off_bpack;  // != 0: the backward automaton has <= 5 states and rides along as packed functions: 8-bit rows
                          // u32 F[256] there; UTF-16 rows ptab64[256] there ({absolute F address, mask} per high byte)

@@ -165,13 +165,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
             count += (uint32_t)__builtin_popcount(t);
             return;
         }
-        if (direct_codes) { // wave-uniform: the code is the match's length, k = 0 -- no lookup on the filing chain
+        if (direct_codes) { // wave-uniform: the code names the match's length, k = 0 -- no lookup on the filing chain
+            const uint32_t hl = a.hdr.ft_direct == 2u ? h >> 1 : h; // (2: length << 1 | 1)
             do {
                 const bool has = t != 0u;
                 uint32_t b; // bit index of the next match's nibble (lanes that have none: 0xFFFFFFFF -- nothing filed)
                 asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"(t));
                 t &= t - 1u;
-                file(has, pos0 + (b >> 2), __builtin_amdgcn_ubfe(h, b, 4));
+                file(has, pos0 + (b >> 2), __builtin_amdgcn_ubfe(hl, b, a.hdr.ft_direct == 2u ? 3u : 4u));
             } while (__ballot(t != 0u) != 0ull);
             return;
         }

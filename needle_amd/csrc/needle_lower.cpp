@@ -1415,11 +1415,16 @@ Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, in
     // ends here" and the kernel finds its next one with one and + one find-first-bit (ft_odd).
     // ft_direct: every code has k = 0 and a length below 16 (keyword unions whose accepting states die on every char): the code IS
     // the length -- the kernel files a match without a table lookup.
-    bool direct = true;
-    for (const auto &kv : codes) direct = direct && kv.first.second == 0 && kv.first.first >= 1 && kv.first.first <= 15;
+    bool direct = true, direct_odd = true;
+    for (const auto &kv : codes) {
+        direct = direct && kv.first.second == 0 && kv.first.first >= 1 && kv.first.first <= 15;
+        direct_odd = direct_odd && kv.first.second == 0 && kv.first.first >= 1 && kv.first.first <= 7;
+    }
+    // (lengths up to 7: the code is length << 1 | 1 -- bit 0 of a log nibble says "a match ends here", as for ft_odd, AND the length needs
+    // no lookup: ft_direct = 2)
     const bool odd = !direct && codes.size() <= 8;
     uint32_t ct[16] = {0};
-    auto renum = [&](int c, int L) { return direct ? L : odd ? 2 * c - 1 : c; };
+    auto renum = [&](int c, int L) { return direct_odd ? 2 * L + 1 : direct ? L : odd ? 2 * c - 1 : c; };
     std::vector<int> code_to(16, 0);
     for (const auto &kv : codes) {
         code_to[kv.second] = renum(kv.second, kv.first.first);
@@ -1430,8 +1435,8 @@ Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, in
         for (size_t i = 0; i < out.size(); ++i)
             if (cells[i] & 15u) cells[i] = (uint16_t)((cells[i] & ~15u) | (uint32_t)code_to[cells[i] & 15u]);
     }
-    p.hdr.ft_odd = odd ? 1u : 0u;
-    p.hdr.ft_direct = direct ? 1u : 0u;
+    p.hdr.ft_odd = (odd || direct_odd) ? 1u : 0u;
+    p.hdr.ft_direct = direct_odd ? 2u : direct ? 1u : 0u;
     p.hdr.ft_codes_off = append(p.blob, ct, sizeof(ct));
     while (p.blob.size() % 16) p.blob.push_back(0);
     if (p.blob.size() > lds_table_budget || p.blob.size() + 4u * 64u * 64u > 160u * 1024u) { // (no room beside even 4 waves of tiles)

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     for (uint32_t i = tid * 16u; i < a.hdr.lds_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + i) = *(const u32x4 *)(a.prog + i);
     for (uint32_t i = tid * 16u; i < A.ng.bm_bytes; i += blockDim.x * 16u) *(u32x4 *)(smem + bm_base + i) = *(const u32x4 *)((const uint8_t *)A.ng_bitmap + i);
     // the second-level bitmap (5-byte windows, needle_ngram.h) rides behind the first in HBM
-    const bool L2ON = OP != OP_NG_FIND_ALL && A.ng.on2 != 0u; // wave-uniform
+    const bool L2ON = A.ng.on2 != 0u; // wave-uniform (the launcher clears it where the LDS has no room for the second queue and bitmap)
     if (L2ON)
         for (uint32_t i = tid * 16u; i < A.ng.bm2_bytes; i += blockDim.x * 16u)
             *(u32x4 *)(smem + A.lay.bm2_base + i) = *(const u32x4 *)((const uint8_t *)A.ng_bitmap + A.ng.bm_bytes + i);
@@ -88,9 +88,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     wk.gtable = MODE == MODE_GLOBAL ? (const uint16_t *)(a.prog + a.hdr.off_table) : nullptr;
     wk.hot_last = 0;
     const uint32_t accept_lo = a.hdr.accept_lo, start_state = a.hdr.start;
-    const uint32_t qbase = A.lay.q_base + (uint32_t)wave * (FA ? kNgWaveLdsFA : kNgWaveLds);
+    const uint32_t qbase = A.lay.q_base + (uint32_t)wave * (FA ? kNgWaveLdsFA + (A.ng.on2 ? kNgQueue * 4u : 0u) : kNgWaveLds);
     const uint32_t q2base = qbase + kNgQueue * 4u; // find / containedIn: the second queue (candidates that passed the second-level window)
-    const uint32_t sbase = qbase + (FA ? 1u : 2u) * kNgQueue * 4u; // find / containedIn: the rows' slots; find-all: two candidate slots per row ...
+    const uint32_t sbase = qbase + ((FA && !A.ng.on2) ? 1u : 2u) * kNgQueue * 4u; // find / containedIn: the rows' slots; find-all: two candidate slots per row ...
     const uint32_t cbase = sbase + 64u * kNgRowSlots * 8u; // ... and a counter per row
     const uint32_t mm = A.ng.m1 | A.ng.m2 << 16, amask = A.ng.addr_mask;
     const uint32_t K = A.ng.warm;
@@ -516,6 +516,7 @@ hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const 
 // LDS of the find-all form; 0 = does not fit
 size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
     NgramLayout l;
+    if (ng.on2 && ngram_layout(h.lds_bytes, ng.bm_bytes, &l, kNgWaveLdsFA + kNgQueue * 4u, ng.bm2_bytes)) return l.total;
     return ngram_layout(h.lds_bytes, ng.bm_bytes, &l, kNgWaveLdsFA) ? l.total : 0;
 }
 
@@ -544,11 +545,12 @@ static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams 
     A.stride_log2 = 0xFFFFFFFFu;
     if ((stride & (stride - 1u)) == 0u) A.stride_log2 = (uint32_t)__builtin_ctz(stride);
     A.stride_recip = (uint32_t)((1ull << 32) / stride);
-    if (op != OP_NG_FIND_ALL && ng.on2 && !ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay, kNgWaveLds, ng.bm2_bytes)) A.ng.on2 = 0; // (cannot be: the host sized it)
-    if (op == OP_NG_FIND_ALL || !A.ng.on2) {
-        A.ng.on2 = 0;
-        if (!ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay, op == OP_NG_FIND_ALL ? kNgWaveLdsFA : kNgWaveLds)) return hipErrorInvalidValue;
-    }
+    // the second level needs its bitmap and a second queue per wave in LDS: find / containedIn were sized for it by the host; the find-all
+    // form (two slots + a counter per row beside the queues) takes it where it still fits (walks out of HBM: yes; a 96 KB automaton: no)
+    const uint32_t wb1 = op == OP_NG_FIND_ALL ? kNgWaveLdsFA : kNgWaveLds;
+    const uint32_t wb2 = op == OP_NG_FIND_ALL ? kNgWaveLdsFA + kNgQueue * 4u : kNgWaveLds;
+    if (ng.on2 && !ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay, wb2, ng.bm2_bytes)) A.ng.on2 = 0;
+    if (!A.ng.on2 && !ngram_layout(a.hdr.lds_bytes, ng.bm_bytes, &A.lay, wb1)) return hipErrorInvalidValue;
     if (ng.addr_shift != 24u) return hipErrorInvalidValue;
     A.dbg = 0;
 #ifdef NEEDLE_TUNING

@@ -171,8 +171,7 @@ def filtered_find_all(p, text, info=None, all_windows=False, row_slots=2, with_c
     for e in range(S, len(t) + 1, S):
         if e < 4:
             continue
-        x = int(t[e - 4] | (t[e - 3] << 8) | (t[e - 2] << 16) | (t[e - 1] << 24))
-        if not all_windows and not window_passes(info, info["bitmap"], x):
+        if not candidate(info, t, e, all_windows):  # (the find-all form asks the second level too where its LDS has room: exact either way)
             continue
         h = walk_row_sim(au, t, e, max(e - K, 0), e + S - 1, fixed)
         crossed = h["crossed"] and with_crossed

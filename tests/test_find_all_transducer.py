@@ -74,7 +74,7 @@ def test_transducer_of_the_bench_dictionary(oracle_lib):
     ml = p.match_length_automaton()
     assert ft is not None and ft["window"] == 1 and ft["n_states"] <= ml["n_states"] and ft["lds_bytes"] + 16 * 64 * 64 <= 160 * 1024
     codes = [int(ft["blob"][ft["codes_off"] + 4 * c]) | int(ft["blob"][ft["codes_off"] + 4 * c + 1]) << 8 for c in range(16)]
-    assert sorted(c for c in codes if c) == [3, 4, 5] and all(codes[c] in (0, c) for c in range(16))  # (k = 0 throughout: a code IS its length)
+    assert sorted(c for c in codes if c) == [3, 4, 5] and all(codes[c] in (0, c >> 1) for c in range(16))  # (k = 0 throughout: code = length << 1 | 1)
     o, _ = oracle_for("|".join(words), 0)
     rows = W.keyword_batch(np, words, 5, 200, 256)
     lens = (np.arange(len(rows)) * 37 % 257)
