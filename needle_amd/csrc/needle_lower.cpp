@@ -644,7 +644,13 @@ static Program lower_core(const RefTables &t, Which which, int char_width, size_
         // a small backward table rides along in LDS (same layout as the global-walk program: uint16 [n_dev][n_cols])
         const Program bp = lower(t, W_BACKWARDS, char_width, lds_table_budget, true, false, false);
         const size_t tbytes = bp.blob.size() - bp.hdr.off_table;
-        if (tbytes <= 2048) p.hdr.off_btable = append(p.blob, bp.blob.data() + bp.hdr.off_table, tbytes);
+        // (up to 2 KB always; up to 8 KB when the program then still leaves room for 16 waves x 64-byte tiles -- C5w's reversed automaton is
+        // 34 states x 33 columns = 2244 bytes, its 33 columns rule out the popcount form below, and out of HBM / L2 every step of every
+        // matched row's backward walk waited for a load: NEEDLE_BTABLE_LDS_MAX=2048 brings that back, A/B)
+        static const size_t btable_max = getenv("NEEDLE_BTABLE_LDS_MAX") ? (size_t)atol(getenv("NEEDLE_BTABLE_LDS_MAX")) : (size_t)8192;
+        const bool roomy = tbytes <= btable_max && mode != MODE_GLOBAL && mode != MODE_HYBRID && mode != MODE_PACK &&
+                           p.blob.size() + tbytes + 64 + 16u * 64u * 64u <= 160u * 1024u && p.blob.size() + tbytes + 64 <= lds_table_budget;
+        if (tbytes <= 2048 || roomy) p.hdr.off_btable = append(p.blob, bp.blob.data() + bp.hdr.off_table, tbytes);
         else if (bp.hdr.n_cols <= 32 && mode != MODE_GLOBAL && mode != MODE_HYBRID) {
             // (when the FORWARD table itself overflows the LDS, every byte goes to its hot rows instead)
             // a big but sparse backward table (most cells lead to the sink): popcount-compressed rows, if they still fit

@@ -113,38 +113,47 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         const uint32_t rows_in = (uint32_t)(a.n_rows - (grp << 6));
         return (((rows_in * stride + 1023u) >> 10) + (kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
     };
-    // 16 bytes of unit `unit` of group `grp`.  Always issued (a load under a branch makes the compiler drain vmcnt at the join);
-    // units past the batch are read from its last KiB, lanes past it from its last 16 bytes -- never used.
+    // The prefetch cursor, kNgPF units ahead of the batch being filtered: the byte offset of the next unit to load is carried along
+    // (+ 1 KiB per unit) and only recomputed when the cursor moves to another group, together with a flag that says whether the whole
+    // group lies inside the batch -- a unit of such a group needs no clamping.  (Recomputing (group * 64) * stride + unit * 1024 and
+    // comparing it with the batch's size for EVERY unit cost ~30 scalar and half a dozen vector instructions per KiB: the kernel issued
+    // 61 SALU per unit beside its 98 VALU, through the CU's one scalar unit.)
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    auto load_unit = [&](uint64_t grp, uint32_t unit) __attribute__((always_inline)) -> u32x4 {
-        uint64_t base = (grp << 6) * a.stride_bytes + ((uint64_t)unit << 10);
+    uint64_t pf_g = g, pf_base = 0;
+    uint32_t pf_u = 0, pf_units = 0;
+    bool pf_interior = false;
+    auto pf_enter_group = [&]() __attribute__((always_inline)) {
+        pf_u = 0;
+        pf_base = (pf_g << 6) * a.stride_bytes;
+        pf_units = pf_g < n_groups ? units_of(pf_g) : (uint32_t)kNgPF;
+        pf_interior = pf_g < n_groups && pf_base + ((uint64_t)pf_units << 10) <= a.total_bytes;
+    };
+    // 16 bytes of the cursor's unit.  Always issued (a load under a branch makes the compiler drain vmcnt at the join); units past the
+    // batch are read from its last KiB, lanes past it from its last 16 bytes -- never used.
+    auto load_next = [&]() __attribute__((always_inline)) -> u32x4 {
+        uint64_t base = pf_base;
         uint32_t off = lane16;
-        if (base + 1024u > a.total_bytes) { // wave-uniform: the batch's last, partial unit, or a prefetch past the end
-            if (base + 16u > a.total_bytes) base = a.total_bytes - 16u;
-            const uint32_t room = (uint32_t)(a.total_bytes - 16u - base);
-            off = off < room ? off : room;
+        if (!pf_interior) { // wave-uniform: the batch's last group(s), or a prefetch past the end
+            if (base + 1024u > a.total_bytes) {
+                if (base + 16u > a.total_bytes) base = a.total_bytes - 16u;
+                const uint32_t room = (uint32_t)(a.total_bytes - 16u - base);
+                off = off < room ? off : room;
+            }
         }
         // (tried for MODE_GLOBAL, whose walks read the table out of L2: nontemporal text loads -- c3x 1.09 -> 1.19 ms: the candidates' own
         // text then never hits the L2 either)
-        return *(const u32x4 *)(a.rows + base + off);
-    };
-
-    // prefetch cursor: kNgPF units ahead of the batch being filtered
-    uint64_t pf_g = g;
-    uint32_t pf_u = 0, pf_units = units_of(g);
-    auto pf_advance = [&]() __attribute__((always_inline)) {
+        const u32x4 v = *(const u32x4 *)(a.rows + base + off);
+        pf_base += 1024u;
         if (++pf_u == pf_units) {
-            pf_u = 0;
             pf_g += wave_cnt;
-            pf_units = pf_g < n_groups ? units_of(pf_g) : (uint32_t)kNgPF;
+            pf_enter_group();
         }
+        return v;
     };
+    pf_enter_group();
     u32x4 R[kNgPF];
 #pragma unroll
-    for (int k = 0; k < kNgPF; ++k) {
-        R[k] = load_unit(pf_g, pf_u);
-        pf_advance();
-    }
+    for (int k = 0; k < kNgPF; ++k) R[k] = load_next();
 
     // Run the automaton for one row per lane from the start state: chars [r, ..) of row `row` of group grp, looking for a FIRST accept
     // at indexes qn .. lim0 - 1 (after it the walk runs on until the automaton dies: the reference's lastMatch), and report to the
@@ -311,8 +320,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             for (int k = 0; k < kNgPF; ++k) {
                 const u32x4 v = R[k];
                 asm volatile("" ::: "memory");
-                R[k] = load_unit(pf_g, pf_u);
-                pf_advance();
+                R[k] = load_next();
                 asm volatile("" ::: "memory");
                 const uint32_t pw = ngram_prev_dword(v[3], carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);

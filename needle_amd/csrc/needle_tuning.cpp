@@ -32,6 +32,7 @@ const Switch kSwitches[] = {
     {"NEEDLE_HYBRID", "1", "layout", "0: no hot-rows form either: plain HBM table"},
     {"NEEDLE_WINDOW", "1", "layout", "0: column-map lookups instead of window addressing (clamped char = column offset)"},
     {"NEEDLE_FLAT_MAP", "1", "layout", "0: UTF-16 rows of LDS-table automata always use the compact two-level page map instead of the flat 64 KB one (one column lookup per char)"},
+    {"NEEDLE_BTABLE_LDS_MAX", "8192", "size", "largest dense backward table of find() that rides in the forward program's LDS image when 16 waves of tiles still fit beside it (2048: round 4's rule)"},
     {"NEEDLE_PAIR_MAX_BYTES", "98304", "size", "largest pair table ([state][col][col] uint16, two chars per lookup); 0: never"},
     {"NEEDLE_MAX_PROG_LDS", "(device limit)", "size", "LDS bytes an automaton may take (tests lower it to force the HBM-table mode)"},
     {"NEEDLE_SHAPE", "(by LDS footprint)", "layout", "\"<waves>x<tile bytes>\" workgroup shape of the tiled scan kernel"},
