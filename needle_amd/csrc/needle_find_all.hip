@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
     uint32_t cap = 0;       // matches this row may file
 
     auto backward = [&](bool act, int32_t en, int32_t bound, uint32_t tile_b0) __attribute__((always_inline)) -> int32_t {
-        return backward_walk<CW>(a, act, en, bound, tile.row_addr, tile_b0, (uint32_t)CHB, swz16, rowp);
+        return backward_walk<CW, true>(a, act, en, bound, tile.row_addr, tile_b0, (uint32_t)CHB, swz16, rowp);
     };
 
     auto begin_group = [&](uint64_t grp) __attribute__((always_inline)) {

@@ -338,89 +338,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             }
             s = res ? last - (int32_t)lds_u8(a.hdr.fa_len_off + pidx) : -1;
         } else {
-            // indexBackwards(end - 1, 0), :536-583.  Column map in LDS, row bytes (L2-hot) fetched 8 at a time,
-            // backward table walked out of HBM/L2.
-            const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
-            const uint16_t *bt = a.hdr.off_btable ? (const uint16_t *)(smem + a.hdr.off_btable)
-                                                   : (const uint16_t *)(a.bprog + a.bhdr.off_table);
-            // (packed backward automaton: states are field offsets)
-            const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
+            // indexBackwards(end - 1, FROM), :536-583: backward_walk (needle_walk.h).  The text it reads: the 32-byte window
+            // [snapB | snapA] goes to the lane's own row of the LDS tile (walked and free by now), so that char p is ONE ds_read
+            // at a per-lane address instead of a select chain over eight registers per char; text before the window comes from
+            // memory (the row's line was fetched a moment ago: L2).
             const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
-            int32_t idx_b = last - 1;
-            uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
-            int32_t lastb = a.bhdr.root_accepting ? cursor : INT_MAX; // :543-547 (LENGTH var = FROM)
-            bool active = res;
-            // The text the walk reads: the 32-byte window [snapB | snapA] goes to the lane's own row of the LDS tile
-            // (walked and free by now), so that char p is ONE ds_read at a per-lane address instead of a select chain
-            // over eight registers per char.
             if (res) {
                 *(lds_u32x4 *)(uintptr_t)(tile.row_addr) = snapB;
                 *(lds_u32x4 *)(uintptr_t)(tile.row_addr + 16u) = snapA;
             }
-            const int32_t win0 = (snap_pi - 1) * 16;                 // byte offset (in the row) of the window's start
-            const int32_t win_lo = snapB_ok ? 0 : 16;                // first valid byte of the window
-            while (__ballot(active) != 0ull) {
-                uint32_t cs[8];
-                const int32_t wb0 = idx_b * CW - win0;               // window offset of char idx_b (< 32)
-                const uint32_t rd = tile.row_addr + (uint32_t)(wb0 - 7 * CW); // chars idx_b - 7 .. idx_b at rd + 0 .. 7 * CW
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int32_t p = idx_b - k;
-                    const uint32_t held = (CW == 1) ? lds_u8(rd + (uint32_t)(7 - k)) : lds_u16(rd + (uint32_t)(7 - k) * 2u);
-                    cs[k] = 0;
-                    if (active && p >= cursor) {
-                        if ((uint32_t)(wb0 - k * CW - win_lo) < (uint32_t)(32 - win_lo)) cs[k] = held; // inside the held window
-                        else cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p]; // beyond the snapshot: from memory
-                    }
-                }
-                if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton -- 8 independent char -> F lookups, then bfe
-                    uint32_t fb[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (CW == 1) {
-                            fb[k] = lds_u32(a.hdr.off_bpack + (cs[k] << 2));
-                        } else {
-                            const u32x2 pg = lds_u32x2(a.hdr.off_bpack + ((cs[k] >> 8) << 3));
-                            fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]); // absolute address (needle_lower.cpp)
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const bool in_range = active && idx_b >= cursor; // loop bound `index >= FROM`, :549
-                        const uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
-                        const bool alive = in_range && nb != 0u;
-                        lastb = (alive && nb >= bacc) ? idx_b : lastb;
-                        bs = alive ? nb : bs;
-                        idx_b = alive ? idx_b - 1 : idx_b;
-                        active = alive;
-                    }
-                } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (active) {
-                        if (idx_b < cursor) { // loop bound `index >= FROM`, :549
-                            active = false;
-                        } else {
-                            const uint32_t col = column_of<CW>(bcmap, bptab, bpages, cs[k]);
-                            if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
-                                const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
-                                const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col) - 1u));
-                                const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
-                                bs = ((bm >> col) & 1u) ? tgt : 0u;
-                            } else {
-                                bs = bt[bs * bcols + col];
-                            }
-                            if (bs == 0) {
-                                active = false;
-                            } else {
-                                if (bs >= bacc) lastb = idx_b;
-                                --idx_b;
-                            }
-                        }
-                    }
-                }
-                }
-            }
+            const uint32_t win_lo = snapB_ok ? 0u : 16u;                        // first valid byte of the window
+            const uint32_t win0 = (uint32_t)(snap_pi - 1) * 16u + win_lo;       // byte offset (in the row) of its start
+            const int32_t lastb = backward_walk<CW>(a, res, last, cursor, tile.row_addr + win_lo, win0, 32u - win_lo, 0u, rowp);
             s = res ? lastb : -1;
         }
         if (row_ok) {

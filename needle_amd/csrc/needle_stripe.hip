@@ -660,7 +660,9 @@ hipError_t launch_find_all_collect(uint64_t n_rows, uint32_t slots, uint32_t k, 
 // ------------------------------------------------------------------------------------------------
 // GUARD = false: every row fills its stride and there are no cursors -- the per-char length / cursor selects go, and packed
 // automata log find()'s accept flags (one v_alignbit per char) instead of selecting a position per char (needle_walk.h).
-constexpr uint32_t kShortSlotBytes = 80; // LDS slot per lane for the backward walk's text (20 dwords apart: 4-way bank conflicts at worst)
+// LDS slot per lane for the backward walk's text: the row's stride + one dword, so that the lanes' slots are an ODD number of dwords
+// apart (5 / 9 / 13 / 17): the dword writes and the walk's byte reads at equal offsets are conflict-free (round 4: 80 bytes, 4-way)
+__host__ __device__ constexpr uint32_t short_slot_bytes(uint32_t stride_bytes) { return stride_bytes + 4u; }
 template <int OP, int CW, int MODE, bool GUARD>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanArgs a) {
     const int tid = threadIdx.x;
@@ -696,27 +698,40 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
     const uint64_t wave_cnt = (uint64_t)gridDim.x * kWavesPerBlock;
     uint64_t g = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
     if (g >= n_groups) return;
-    auto fetch = [&](uint64_t grp, u32x4 (&d)[4]) __attribute__((always_inline)) {
+    // (GUARD: the rows' lengths and find() cursors travel with the text, one group ahead; the unguarded kernel has neither)
+    const bool has_len = GUARD && a.lengths != nullptr, has_from = GUARD && OP == OP_FIND && a.from != nullptr;
+    auto fetch = [&](uint64_t grp, u32x4 (&d)[4], uint32_t &d_len, int32_t &d_from) __attribute__((always_inline)) {
         uint64_t row = (grp << 6) + lane;
         if (row >= a.n_rows) row = a.n_rows - 1; // lanes past the batch re-read its last row (verdict masked below)
         const uint8_t *p = a.rows + row * a.stride_bytes;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if ((uint32_t)j < n_pieces) d[j] = *(const u32x4 *)(p + 16 * j);
+        if (has_len) d_len = a.lengths[row];
+        if (has_from) d_from = a.from[row];
     };
     u32x4 cur[4] = {}, nxt[4] = {};
-    fetch(g, cur);
+    uint32_t cur_len = a.row_len, nxt_len = a.row_len;
+    int32_t cur_from = 0, nxt_from = 0;
+    // The compiler counts vmcnt conservatively wherever paths with different numbers of loads / stores meet: with the first group's
+    // loads still pending at the loop head, or this group's result stores issued ahead of the copy nxt -> cur, every wait became a
+    // vmcnt(0) RIGHT BEHIND the prefetch it had just issued (each iteration a full memory latency, hidden only by the other waves).
+    // So: nothing is pending at the loop head, and the prefetch is collected before the result stores are issued.
+    auto landed = [&](u32x4 (&d)[4], uint32_t &d_len, int32_t &d_from) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d_len), "+v"(d_from));
+    };
+    fetch(g, cur, cur_len, cur_from);
+    landed(cur, cur_len, cur_from);
     for (;;) {
         const uint64_t ng = g + wave_cnt;
-        if (ng < n_groups) fetch(ng, nxt);
+        if (ng < n_groups) fetch(ng, nxt, nxt_len, nxt_from);
         const uint64_t my_row = (g << 6) + lane;
         const bool row_ok = my_row < a.n_rows;
-        uint32_t len = 0;
-        if (row_ok) len = a.lengths ? a.lengths[my_row] : a.row_len;
+        const uint32_t len = row_ok ? cur_len : 0u;
         int32_t cursor = 0;
         bool dead = false;
-        if (OP == OP_FIND && a.from) {
-            cursor = row_ok ? a.from[my_row] : -1;
+        if (has_from) {
+            cursor = row_ok ? cur_from : -1;
             dead = cursor < 0; // find(): `if nextStart == -1 return false`, DFAClassBuilder.java:629-630
             if (dead) cursor = 0;
         }
@@ -740,10 +755,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
         if (OP == OP_FIND) res = row_ok && !dead && (last >= 0);
         else res = row_ok && (st >= accept_lo);
         const uint64_t word = __ballot(res);
-        if (lane == 0) a.bitmap[g] = word;
+        int32_t s = -1, e = -1;
         if (OP == OP_FIND) {
-            int32_t s = -1;
-            const int32_t e = res ? last : -1;
+            e = res ? last : -1;
             if (a.fixed_len >= 0) {
                 s = res ? last - a.fixed_len : -1; // :640-646
             } else if (a.hdr.fa_len_off) { // the "lengths" automaton: the end state remembers the match length (needle_scan.h)
@@ -752,67 +766,44 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
                 // indexBackwards(end - 1, FROM), :536-583, on the row's text parked in this lane's LDS slot (it is in
                 // registers, which cannot be indexed per lane): one ds_read per char instead of a load from L2, and the packed /
                 // popcount-compressed / small dense forms of the backward automaton that ride in the program (needle_walk.h)
-                const uint32_t slot = ((a.hdr.lds_bytes + 15u) & ~15u) + ((uint32_t)wave * 64u + (uint32_t)lane) * kShortSlotBytes;
+                const uint32_t slot = ((a.hdr.lds_bytes + 15u) & ~15u) + ((uint32_t)wave * 64u + (uint32_t)lane) * short_slot_bytes((uint32_t)a.stride_bytes);
                 if (res) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if ((uint32_t)j < n_pieces) *(lds_u32x4 *)(uintptr_t)(slot + 16u * j) = cur[j];
+                        if ((uint32_t)j < n_pieces) {
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(slot + 16u * j + 4u * d) = cur[j][d];
+                        }
                 }
                 const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
                 const int32_t sb = backward_walk<CW>(a, res, last, cursor, slot, 0u, (uint32_t)a.stride_bytes, 0u, rowp);
                 s = res ? sb : -1;
             } else {
-                // indexBackwards(end - 1, FROM), :536-583.  Column map (and a small backward table) in LDS, the row's
-                // chars re-read 8 at a time from its line (fetched a moment ago: L2).
-                const uint8_t *bcmap = smem + a.hdr.off_bcmap, *bptab = smem + a.hdr.off_bptab, *bpages = smem + a.hdr.off_bpages;
-                const uint16_t *bt = a.hdr.off_btable ? (const uint16_t *)(smem + a.hdr.off_btable)
-                                                       : (const uint16_t *)(a.bprog + a.bhdr.off_table);
-                const uint32_t bcols = a.bhdr.n_cols, bacc = a.bhdr.accept_lo;
+                // no room for the text slots behind the program: the same walk with an empty window, the text out of L2
                 const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
-                int32_t idx_b = last - 1;
-                uint32_t bs = a.bhdr.start;
-                int32_t lastb = a.bhdr.root_accepting ? cursor : INT_MAX; // :543-547 (LENGTH var = FROM)
-                bool active = res;
-                while (__ballot(active) != 0ull) {
-                    uint32_t cs[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int32_t p = idx_b - k;
-                        cs[k] = 0;
-                        if (active && p >= cursor) cs[k] = (CW == 1) ? rowp[p] : ((const uint16_t *)rowp)[p];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (active) {
-                            if (idx_b < cursor) { // loop bound `index >= FROM`, :549
-                                active = false;
-                            } else {
-                                bs = bt[bs * bcols + column_of<CW>(bcmap, bptab, bpages, cs[k])];
-                                if (bs == 0) {
-                                    active = false;
-                                } else {
-                                    if (bs >= bacc) lastb = idx_b;
-                                    --idx_b;
-                                }
-                            }
-                        }
-                    }
-                }
-                s = res ? lastb : -1;
+                const int32_t sb = backward_walk<CW>(a, res, last, cursor, 16u, 0u, 0u, 0u, rowp);
+                s = res ? sb : -1;
             }
-            if (row_ok) {
-                if (a.packed) { // wave-uniform: one dword per row (ScanArgs::packed)
-                    a.packed[my_row] = ((uint32_t)s & 0xFFFFu) | ((uint32_t)e << 16);
-                } else {
-                    a.start[my_row] = s;
-                    a.end[my_row] = e;
-                }
+        }
+        // The next group's text is collected BEFORE this group's stores enter the queue (see `landed`), and on EVERY path to the loop
+        // head, the last iteration's included (nothing is pending there): a path around the wait, even one no wave ever takes, makes
+        // the compiler wait at the loop head again.
+        landed(nxt, nxt_len, nxt_from);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((uint32_t)j < n_pieces) cur[j] = nxt[j];
+        cur_len = nxt_len, cur_from = nxt_from;
+        if (lane == 0) a.bitmap[g] = word;
+        if (OP == OP_FIND && row_ok) {
+            if (a.packed) { // wave-uniform: one dword per row (ScanArgs::packed)
+                a.packed[my_row] = ((uint32_t)s & 0xFFFFu) | ((uint32_t)e << 16);
+            } else {
+                a.start[my_row] = s;
+                a.end[my_row] = e;
             }
         }
         if (ng >= n_groups) break;
         g = ng;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
     }
 }
 
@@ -831,9 +822,10 @@ static hipError_t launch_short_one(const ScanArgs &a_in, int grid, size_t lds, h
     const bool full = !a.lengths && !a.from && a.row_len != 0 && (uint64_t)a.row_len * CW == a.stride_bytes;
     // find() by indexBackwards: room for the lanes' text slots behind the program?
     a.short_window = 0;
-    if (OP == OP_FIND && a.fixed_len < 0 && lds + (size_t)kWavesPerBlock * 64 * kShortSlotBytes <= 160u * 1024u) {
+    const size_t slots = (size_t)kWavesPerBlock * 64 * short_slot_bytes((uint32_t)a.stride_bytes);
+    if (OP == OP_FIND && a.fixed_len < 0 && !a.hdr.fa_len_off && lds + slots <= 160u * 1024u) {
         a.short_window = 1;
-        lds += (size_t)kWavesPerBlock * 64 * kShortSlotBytes;
+        lds += slots;
     }
     return full ? launch_short_g<OP, CW, MODE, false>(a, grid, lds, stream) : launch_short_g<OP, CW, MODE, true>(a, grid, lds, stream);
 }
@@ -863,7 +855,12 @@ hipError_t launch_short_rows(int op, int char_width, const ScanArgs &a, int n_cu
     // of 48 and 64 bytes lose 5 % that way and keep one.  find() has no room for a second copy beside its text slots.
     // NEEDLE_SHORT_WGS=1: one workgroup per CU everywhere (A/B).
     static const int wgs_env = getenv("NEEDLE_SHORT_WGS") ? atoi(getenv("NEEDLE_SHORT_WGS")) : 2;
-    const uint64_t per_cu = (op != OP_FIND && wgs_env >= 2 && a.stride_bytes <= 32 && 2 * lds <= 160u * 1024u) ? 2 : 1;
+    // find() on full rows (the unguarded kernels: at most 64 VGPRs) shares a CU the same way when two programs AND two sets of text slots
+    // fit (table-mode programs; the packed program of 8-bit rows is 64 KB by itself)
+    const bool full = !a.lengths && !a.from && a.row_len != 0 && (uint64_t)a.row_len * char_width == a.stride_bytes;
+    const size_t find_lds = lds + ((a.fixed_len < 0 && !a.hdr.fa_len_off) ? (size_t)kWavesPerBlock * 64 * short_slot_bytes((uint32_t)a.stride_bytes) : 0);
+    const bool two = wgs_env >= 2 && a.stride_bytes <= 32 && (op != OP_FIND ? 2 * lds <= 160u * 1024u : (full && 2 * find_lds <= 160u * 1024u));
+    const uint64_t per_cu = two ? 2 : 1;
     if (blocks > (uint64_t)n_cus * per_cu) blocks = (uint64_t)n_cus * per_cu;
     switch (op) {
     case OP_MATCHES: return launch_short_c<OP_MATCHES>(a, char_width, (int)blocks, lds, stream);

@@ -463,38 +463,63 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
 }
 
 // indexBackwards(en - 1, bound), DFAClassBuilder.java:536-583, for the lanes of `act`.  The row bytes [win_b0, win_b0 +
-// win_bytes) are in LDS at win_addr (byte b at win_addr + ((b - win_b0) ^ swz16): the find-all tile is bank-swizzled, a
-// plain window is not); anything else is read from memory.  The backward automaton rides in the forward program's LDS part
-// (packed functions, popcount-compressed rows, a small dense table) or is walked out of HBM / L2.
-template <int CW>
+// win_bytes) are in LDS at win_addr (byte b at win_addr + ((b - win_b0) ^ swz16): the find-all tile is bank-swizzled -- SWZ --
+// a plain window is not); anything else is read from memory.  At least 8 chars' worth of LDS precede win_addr (it lies behind
+// the program image).  The backward automaton rides in the forward program's LDS part (packed functions, popcount-compressed
+// rows, a small dense table) or is walked out of HBM / L2.
+//
+// The walk is LOCK-STEP: every lane still walking has taken the same number of steps, so step k of a round reads char
+// idx0 - k for all of them and positions need no per-lane bookkeeping; a lane that is done carries state 0 (the sink: row 0 of
+// every table, field 0 of every packed function, leads to 0), chars below `bound` (the loop bound `index >= FROM`, :549) lead
+// there by a select on the lane's room.  Per step of the packed form: v_bfe, a compare + select for the bound, a compare +
+// select for "accepting" -- 5 VALU ops where the per-lane (active, index, state, last) bookkeeping of rounds 1-4 took 12 and a
+// branch around a memory fallback per char.
+template <int CW, bool SWZ = false>
 __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, int32_t en, int32_t bound, uint32_t win_addr, uint32_t win_b0,
                                                  uint32_t win_bytes, uint32_t swz16, const uint8_t *rowp) {
     const uint16_t *gbt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
     const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
-    int32_t idx_b = en - 1;
+    int32_t idx0 = en - 1;                                     // the char step 0 of the round reads
     uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
-    int32_t lastb = a.bhdr.root_accepting ? bound : INT_MAX; // :543-547
-    bool active = act;
-    while (__ballot(active) != 0ull) {
+    bs = act ? bs : 0u;
+    int32_t lastb = a.bhdr.root_accepting ? bound : INT_MAX;   // :543-547
+    for (;;) {
+        const int32_t room = idx0 - bound;                     // chars idx0 .. idx0 - room may be read
+        const bool live = bs != 0u && room >= 0;
+        if (__ballot(live) == 0ull) break;
+        // ---- the round's text: chars idx0 - 7 .. idx0
+        const int32_t rel0 = idx0 * CW - (int32_t)win_b0;      // window offset of char idx0
+        const int32_t lo = idx0 - 7 > bound ? idx0 - 7 : bound; // the lowest char this lane can need
+        const bool from_mem = live && ((uint32_t)rel0 >= win_bytes || lo * CW < (int32_t)win_b0);
         uint32_t cs[8];
+        if (!SWZ) {
+            // one address per lane, the chars at immediate offsets (a lane outside its window reads the window's start: unused)
+            const uint32_t rd = win_addr + ((uint32_t)rel0 < win_bytes ? (uint32_t)rel0 : 7u * CW) - 7u * CW;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int32_t p = idx_b - k;
-            const uint32_t rel = (uint32_t)(p * CW) - win_b0;      // byte offset inside the window, if it is there
-            const bool in_tile = rel < win_bytes;
-            const uint32_t ad = win_addr + ((in_tile ? rel : 0u) ^ swz16);
-            const uint32_t held = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
-            uint32_t c = 0;
-            if (active && p >= bound) {
-                c = held;
-                if (!in_tile) { // text outside the window (rare): waited for inside the branch, as in walk_tile
-                    c = (CW == 1) ? (uint32_t)rowp[p] : (uint32_t)((const uint16_t *)rowp)[p];
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(c));
-                }
+            for (int k = 0; k < 8; ++k) cs[k] = (CW == 1) ? lds_u8(rd + (uint32_t)(7 - k)) : lds_u16(rd + (uint32_t)(7 - k) * 2u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t rel = (uint32_t)(rel0 - k * CW);
+                const uint32_t ad = win_addr + ((rel < win_bytes ? rel : 0u) ^ swz16);
+                cs[k] = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
             }
-            cs[k] = c;
         }
-        if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton
+        if (__ballot(from_mem) != 0ull) { // text outside the window (rare): waited for inside the branch, as in walk_tile
+            uint32_t m[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int32_t p = idx0 - k;
+                m[k] = cs[k];
+                if (live && k <= room && (uint32_t)(p * CW - (int32_t)win_b0) >= win_bytes)
+                    m[k] = (CW == 1) ? (uint32_t)rowp[p] : (uint32_t)((const uint16_t *)rowp)[p];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cs[k] = m[k];
+        }
+        uint32_t last_k = 8u; // the round's last accepting step (8: none)
+        if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton -- 8 independent char -> F lookups, then the chain
             uint32_t fb[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -502,50 +527,47 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
                     fb[k] = lds_u32(a.hdr.off_bpack + (cs[k] << 2));
                 } else {
                     const u32x2 pg = lds_u32x2(a.hdr.off_bpack + ((cs[k] >> 8) << 3));
-                    fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]);
+                    fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]); // absolute address (needle_lower.cpp)
                 }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const bool in_range = active && idx_b >= bound; // loop bound `index >= FROM`, :549
-                const uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
-                const bool alive = in_range && nb != 0u;
-                lastb = (alive && nb >= bacc) ? idx_b : lastb;
-                bs = alive ? nb : bs;
-                idx_b = alive ? idx_b - 1 : idx_b;
-                active = alive;
+                uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
+                nb = room >= k ? nb : 0u;
+                last_k = nb >= bacc ? (uint32_t)k : last_k;
+                bs = nb;
             }
         } else {
+            // the backward automaton's char -> column maps, at absolute LDS addresses: all eight ahead of the dependent chain
+            uint32_t col[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (active) {
-                    if (idx_b < bound) {
-                        active = false;
-                    } else {
-                        uint32_t col; // the backward automaton's char -> column maps, at absolute LDS addresses
-                        if (CW == 1) col = lds_u8(a.hdr.off_bcmap + cs[k]);
-                        else col = lds_u8(a.hdr.off_bpages + ((lds_u8(a.hdr.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
-                        if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
-                            const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
-                            const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col) - 1u));
-                            const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
-                            bs = ((bm >> col) & 1u) ? tgt : 0u;
-                        } else if (a.hdr.off_btable) { // wave-uniform: small dense table in LDS
-                            bs = lds_u16(a.hdr.off_btable + (bs * bcols + col) * 2u);
-                        } else { // dense table in HBM / L2 (waited for here: no vmcnt wait on the other paths)
-                            bs = gbt[bs * bcols + col];
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bs));
-                        }
-                        if (bs == 0) {
-                            active = false;
-                        } else {
-                            if (bs >= bacc) lastb = idx_b;
-                            --idx_b;
-                        }
+                if (CW == 1) col[k] = lds_u8(a.hdr.off_bcmap + cs[k]);
+                else col[k] = lds_u8(a.hdr.off_bpages + ((lds_u8(a.hdr.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (bs != 0u) { // (the lanes that are done stay out of the LDS)
+                    uint32_t nb;
+                    if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
+                        const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
+                        const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col[k]) - 1u));
+                        const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
+                        nb = ((bm >> col[k]) & 1u) ? tgt : 0u;
+                    } else if (a.hdr.off_btable) { // wave-uniform: small dense table in LDS
+                        nb = lds_u16(a.hdr.off_btable + (bs * bcols + col[k]) * 2u);
+                    } else { // dense table in HBM / L2 (waited for here: no vmcnt wait on the other paths)
+                        nb = gbt[bs * bcols + col[k]];
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nb));
                     }
+                    nb = room >= k ? nb : 0u;
+                    last_k = nb >= bacc ? (uint32_t)k : last_k;
+                    bs = nb;
                 }
             }
         }
+        lastb = last_k < 8u ? idx0 - (int32_t)last_k : lastb;
+        idx0 = idx0 - 8 > -1 ? idx0 - 8 : -1; // (lanes that are done do not run away below their rows)
     }
     return lastb;
 }

@@ -5,6 +5,7 @@
 #   fa_prof                 rocprofv3 --kernel-trace --stats + PMC passes of the find-all kernels on C3 -> gpurun_out/r5/fa_prof/
 #   bench [args]            python bench.py [args] -> gpurun_out/r5/bench_<tag>.json
 #   py <script> [args]      python <script> [args] > gpurun_out/r5/<basename>.log
+#   pmc_py <tag> <script> [args]   PMC passes (VALU / SALU / LDS instructions, LDS conflicts, waits) of any script: per kernel, per launch
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r5; mkdir -p $O
@@ -72,6 +73,25 @@ repeat)
     python bench.py --workload $w --also none --no-cpu-baseline --no-extras --full-line "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$w', 'timed', round(d['ms_per_step'],4), 'kernel', round(d['roofline']['kernel_ms'],4), 'cold', round(d['cold']['ms_per_step'],4), 'steady', round(d['steady']['ms_per_step'],4), 'frac', round(d['roofline']['frac'],4))"
   done
   rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk|fclk" | head -6 ;;
+pmc_py)
+  tag=$1; shift
+  P=$O/pmc_$tag; mkdir -p $P; : > $P.txt
+  for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
+    t=$(echo $c | tr ' ' '_')
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P/$t -o p -- python "$@" > /dev/null 2>> $P/err.log
+    python - "$P/$t/p_counter_collection.csv" <<'PY' >> $P.txt
+import csv, sys, collections
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "needle::" in r["Kernel_Name"]]
+agg = collections.defaultdict(float); disp = collections.defaultdict(set)
+for r in rows:
+    k = r["Kernel_Name"][:70]
+    agg[(k, r["Counter_Name"])] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+for (k, c), v in sorted(agg.items()):
+    print("%-72s %-24s %.5g per launch (%d launches)" % (k, c, v / len(disp[k]), len(disp[k])))
+PY
+    rm -rf $P/$t
+  done
+  cat $P.txt ;;
 py)
   s=$1; shift
   python $s "$@" > $O/$(basename $s .py)_$TAG.log 2>&1; tail -40 $O/$(basename $s .py)_$TAG.log ;;
