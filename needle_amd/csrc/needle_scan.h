@@ -304,6 +304,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
     // their bit in later.
     auto finish_rows = [&](uint64_t grp, auto pooled_c) __attribute__((always_inline)) {
         constexpr bool POOLED = decltype(pooled_c)::value;
+        // (the result pointers: read from the kernel arguments here, once per group, instead of living in SGPRs through the walk -- see
+        // kernarg_here, needle_walk.h)
+        const KernargPtr ka = kernarg_here();
+        uint64_t *const o_bitmap = kernarg_ptr<uint64_t>(ka, (uint32_t)offsetof(ScanArgs, bitmap));
+        uint32_t *const o_end_state = kernarg_ptr<uint32_t>(ka, (uint32_t)offsetof(ScanArgs, end_state));
         bool res;
         if (OP == OP_FIND) res = row_ok && !dead && (last >= 0);
         else res = row_ok && (st >= accept_lo);
@@ -315,13 +320,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             // address up to the L2 (the point of coherence); a plain store would leave that to how the vector L1 happens to
             // drain.  (Relaxed: no fence, no vmcnt wait -- the tile prefetch in flight is not drained.)
             if (lane == 0) {
-                if (POOL) __hip_atomic_store(&a.bitmap[grp], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else a.bitmap[grp] = word;
+                if (POOL) __hip_atomic_store(&o_bitmap[grp], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else o_bitmap[grp] = word;
             }
         } else if (res) {
-            __hip_atomic_fetch_or(&a.bitmap[my_row >> 6], 1ull << (my_row & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_or(&o_bitmap[my_row >> 6], 1ull << (my_row & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (a.end_state && row_ok) a.end_state[my_row] = st; // (speculative stripes, table modes only: the state at the stripe's end)
+        if (o_end_state && row_ok) o_end_state[my_row] = st; // (speculative stripes, table modes only: the state at the stripe's end)
         if (OP != OP_FIND) return;
         int32_t s = -1;
         const int32_t e = res ? last : -1;
@@ -353,11 +358,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
             s = res ? lastb : -1;
         }
         if (row_ok) {
-            if (a.packed) { // wave-uniform: one dword per row (no match: s = e = -1 -> 0xFFFFFFFF)
-                a.packed[my_row] = ((uint32_t)s & 0xFFFFu) | ((uint32_t)e << 16);
+            uint32_t *const o_packed = kernarg_ptr<uint32_t>(ka, (uint32_t)offsetof(ScanArgs, packed));
+            if (o_packed) { // wave-uniform: one dword per row (no match: s = e = -1 -> 0xFFFFFFFF)
+                o_packed[my_row] = ((uint32_t)s & 0xFFFFu) | ((uint32_t)e << 16);
             } else {
-                a.start[my_row] = s;
-                a.end[my_row] = e;
+                kernarg_ptr<int32_t>(ka, (uint32_t)offsetof(ScanArgs, start))[my_row] = s;
+                kernarg_ptr<int32_t>(ka, (uint32_t)offsetof(ScanArgs, end))[my_row] = e;
             }
         }
     };

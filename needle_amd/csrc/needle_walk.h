@@ -474,15 +474,55 @@ __device__ __forceinline__ void walk_piece(const Walk &wk, const uint32_t (&w)[4
 // there by a select on the lane's room.  Per step of the packed form: v_bfe, a compare + select for the bound, a compare +
 // select for "accepting" -- 5 VALU ops where the per-lane (active, index, state, last) bookkeeping of rounds 1-4 took 12 and a
 // branch around a memory fallback per char.
+// A kernel-argument word read where it is used.  The compiler hoists plain `a.hdr.x` reads out of every loop and keeps them in SGPRs for the
+// whole kernel; the backward walk's header words, needed once per group of rows, pushed the find() kernels past their 102 SGPRs (up to 52
+// spilled into VGPR lanes, reloaded by v_readlane_b32 inside the forward walk's loop).  Read through the kernarg segment pointer and an
+// address the optimiser cannot see through, the scalar loads stay where the walk is.  (Not through &a: an escaping address of the by-value
+// argument makes the compiler keep a private copy of all 832 bytes in scratch.)  ScanArgs is the FIRST member of every kernel argument whose
+// kernel walks backwards (scan_kernel, short_kernel: ScanArgs itself; find_all_kernel: FindAllArgs::s).
+typedef __attribute__((address_space(4))) const char *KernargPtr;
+__device__ __forceinline__ KernargPtr kernarg_here() {
+    KernargPtr p = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ uint32_t kernarg_u32(KernargPtr base, uint32_t byte_offset) {
+    return *(__attribute__((address_space(4))) const uint32_t *)(base + byte_offset);
+}
+template <typename T>
+__device__ __forceinline__ T *kernarg_ptr(KernargPtr base, uint32_t byte_offset) {
+    typedef T *Ptr; // (a generic pointer stored in the kernarg segment)
+    return *(__attribute__((address_space(4))) const Ptr *)(base + byte_offset);
+}
+#define NEEDLE_KA_HDR(f) kernarg_u32(ka, (uint32_t)(offsetof(ScanArgs, hdr) + offsetof(ProgHeader, f)))
+#define NEEDLE_KA_BHDR(f) kernarg_u32(ka, (uint32_t)(offsetof(ScanArgs, bhdr) + offsetof(ProgHeader, f)))
+struct BackwardHdr { // the backward automaton as the walk sees it
+    uint32_t off_bpack, bacc, start, root_accepting, bcols, off_bcmap, off_bptab, off_bpages, off_bsp_bm, off_bsp_base, off_bsp_edges, off_btable, b_off_table;
+};
+__device__ __forceinline__ BackwardHdr backward_hdr() {
+    const KernargPtr ka = kernarg_here();
+    BackwardHdr h;
+    h.off_bpack = NEEDLE_KA_HDR(off_bpack);
+    h.bacc = h.off_bpack ? NEEDLE_KA_HDR(bpack_accept_off) : NEEDLE_KA_BHDR(accept_lo);
+    h.start = h.off_bpack ? NEEDLE_KA_HDR(bpack_start_off) : NEEDLE_KA_BHDR(start);
+    h.root_accepting = NEEDLE_KA_BHDR(root_accepting);
+    h.bcols = NEEDLE_KA_BHDR(n_cols);
+    h.off_bcmap = NEEDLE_KA_HDR(off_bcmap), h.off_bptab = NEEDLE_KA_HDR(off_bptab), h.off_bpages = NEEDLE_KA_HDR(off_bpages);
+    h.off_bsp_bm = NEEDLE_KA_HDR(off_bsp_bm), h.off_bsp_base = NEEDLE_KA_HDR(off_bsp_base), h.off_bsp_edges = NEEDLE_KA_HDR(off_bsp_edges);
+    h.off_btable = NEEDLE_KA_HDR(off_btable);
+    h.b_off_table = NEEDLE_KA_BHDR(off_table);
+    return h;
+}
+
 template <int CW, bool SWZ = false>
 __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, int32_t en, int32_t bound, uint32_t win_addr, uint32_t win_b0,
                                                  uint32_t win_bytes, uint32_t swz16, const uint8_t *rowp) {
-    const uint16_t *gbt = (const uint16_t *)(a.bprog + a.bhdr.off_table);
-    const uint32_t bcols = a.bhdr.n_cols, bacc = a.hdr.off_bpack ? a.hdr.bpack_accept_off : a.bhdr.accept_lo;
+    const BackwardHdr h = backward_hdr();
+    const uint16_t *gbt = (const uint16_t *)(a.bprog + h.b_off_table);
+    const uint32_t bcols = h.bcols, bacc = h.bacc;
     int32_t idx0 = en - 1;                                     // the char step 0 of the round reads
-    uint32_t bs = a.hdr.off_bpack ? a.hdr.bpack_start_off : a.bhdr.start;
-    bs = act ? bs : 0u;
-    int32_t lastb = a.bhdr.root_accepting ? bound : INT_MAX;   // :543-547
+    uint32_t bs = act ? h.start : 0u;
+    int32_t lastb = h.root_accepting ? bound : INT_MAX;        // :543-547
     for (;;) {
         const int32_t room = idx0 - bound;                     // chars idx0 .. idx0 - room may be read
         const bool live = bs != 0u && room >= 0;
@@ -519,14 +559,14 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
             for (int k = 0; k < 8; ++k) cs[k] = m[k];
         }
         uint32_t last_k = 8u; // the round's last accepting step (8: none)
-        if (a.hdr.off_bpack) { // wave-uniform: packed backward automaton -- 8 independent char -> F lookups, then the chain
+        if (h.off_bpack) { // wave-uniform: packed backward automaton -- 8 independent char -> F lookups, then the chain
             uint32_t fb[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (CW == 1) {
-                    fb[k] = lds_u32(a.hdr.off_bpack + (cs[k] << 2));
+                    fb[k] = lds_u32(h.off_bpack + (cs[k] << 2));
                 } else {
-                    const u32x2 pg = lds_u32x2(a.hdr.off_bpack + ((cs[k] >> 8) << 3));
+                    const u32x2 pg = lds_u32x2(h.off_bpack + ((cs[k] >> 8) << 3));
                     fb[k] = lds_u32((((cs[k] & 255u) << 2) & pg[1]) | pg[0]); // absolute address (needle_lower.cpp)
                 }
             }
@@ -542,20 +582,20 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
             uint32_t col[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (CW == 1) col[k] = lds_u8(a.hdr.off_bcmap + cs[k]);
-                else col[k] = lds_u8(a.hdr.off_bpages + ((lds_u8(a.hdr.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
+                if (CW == 1) col[k] = lds_u8(h.off_bcmap + cs[k]);
+                else col[k] = lds_u8(h.off_bpages + ((lds_u8(h.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (bs != 0u) { // (the lanes that are done stay out of the LDS)
                     uint32_t nb;
-                    if (a.hdr.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
-                        const uint32_t bm = lds_u32(a.hdr.off_bsp_bm + bs * 4u);
-                        const uint32_t at = lds_u16(a.hdr.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col[k]) - 1u));
-                        const uint32_t tgt = lds_u16(a.hdr.off_bsp_edges + at * 2u);
+                    if (h.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
+                        const uint32_t bm = lds_u32(h.off_bsp_bm + bs * 4u);
+                        const uint32_t at = lds_u16(h.off_bsp_base + bs * 2u) + (uint32_t)__builtin_popcount(bm & ((1u << col[k]) - 1u));
+                        const uint32_t tgt = lds_u16(h.off_bsp_edges + at * 2u);
                         nb = ((bm >> col[k]) & 1u) ? tgt : 0u;
-                    } else if (a.hdr.off_btable) { // wave-uniform: small dense table in LDS
-                        nb = lds_u16(a.hdr.off_btable + (bs * bcols + col[k]) * 2u);
+                    } else if (h.off_btable) { // wave-uniform: small dense table in LDS
+                        nb = lds_u16(h.off_btable + (bs * bcols + col[k]) * 2u);
                     } else { // dense table in HBM / L2 (waited for here: no vmcnt wait on the other paths)
                         nb = gbt[bs * bcols + col[k]];
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(nb));
