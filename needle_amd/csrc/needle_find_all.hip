@@ -50,6 +50,7 @@ __device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t
     constexpr int CPP = 16 / CW;
     uint32_t col[CPP];
     piece_lookups<MODE, CW, false>(wk, w, 0, 0, 0, col);
+    const uint32_t tb_in_col = col_has_table_off<MODE, CW>() ? wk.table_off : 0u; // (UTF-16 table programs: needle_walk.h)
     if (MODE == MODE_PACK) lds_fence();
     if (MODE == MODE_SPARSE) {
         // The compressed automaton (needle_device.h) has no PRE / PAD columns: chars before the lane's cursor and chars past the
@@ -66,11 +67,11 @@ __device__ __forceinline__ uint32_t walk_piece_fa(const Walk &wk, const uint32_t
     }
     if (CUT) {
 #pragma unroll
-        for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < in_row) ? col[i] : wk.pad_e;
+        for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < in_row) ? col[i] : wk.pad_e + tb_in_col;
     }
     if (!SKIPST) {
 #pragma unroll
-        for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < skip_rel) ? wk.pre_e : col[i];
+        for (int i = 0; i < CPP; ++i) col[i] = ((uint32_t)i < skip_rel) ? wk.pre_e + tb_in_col : col[i];
     }
     uint32_t h = 0;
     const uint32_t acc_m1 = accept_lo - 1u;

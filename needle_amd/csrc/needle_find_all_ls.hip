@@ -45,7 +45,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
     wk.table_off = a.hdr.off_table - a.hdr.win_lo_e; // (window addressing: column offsets are not rebased, needle_device.h)
     wk.sp_chains = 0, wk.sp_pad_ident = 0, wk.dead_hi = 0, wk.lane4 = 0, wk.gtable = nullptr, wk.hot_last = 0;
     wk.flat = 0;
-    const uint32_t tbase = CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off;
+    const uint32_t tbase = CW == 1 ? (uint32_t)kLdsTable1 : 0u;           // (UTF-16: piece_lookups has added the table's offset to the columns)
+    const uint32_t pad_addr = wk.pad_e + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off);
     const uint32_t codes_off = a.hdr.ft_codes_off;
     const uint32_t e_start = a.hdr.start << 4;
 
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
     auto end_group = [&](uint64_t grp) __attribute__((always_inline)) {
         // the row's end: one more transition, on the PAD column -- a pending match is emitted (rows that ended inside a tile took it
         // there and sit in the dead state, whose PAD entry is 0)
-        const uint32_t ee = lds_u16(__umul24(e >> 4, wk.ncols_e) + wk.pad_e + tbase);
+        const uint32_t ee = lds_u16(__umul24(e >> 4, wk.ncols_e) + pad_addr);
         const uint32_t code = ee & 15u;
         if (__ballot(code != 0u) != 0ull) file(code != 0u, len, lds_u32(codes_off + (code << 2)));
         if (row_ok && fa.counts) fa.counts[my_row] = count < cap ? count : cap;

@@ -159,6 +159,11 @@ __device__ __forceinline__ uint32_t column_of(const uint8_t *cmap, const uint8_t
     return pages[((uint32_t)ptab[c >> 8] << 8) | (c & 255u)];
 }
 
+// UTF-16 table programs: the table's LDS offset (a kernel argument, not a compile-time constant as for 8-bit rows) is added to the COLUMN
+// offset ahead of the state chain, so that a transition is one v_mad_u32_u24 + the LDS read instead of v_mul_u32_u24 + v_add3_u32 + the read.
+template <int MODE, int CW>
+__device__ __forceinline__ constexpr bool col_has_table_off() { return CW == 2 && (MODE == MODE_TABLE8 || MODE == MODE_TABLE16); }
+
 // A transition in two halves so that a whole 16-byte piece can be batched: `lookup` is everything that does not
 // depend on the automaton state (char -> F, or char -> column * element size); `apply` is the dependent part.
 // K: char number inside dword w (0..3 for bytes, 0..1 for UTF-16 units).
@@ -244,7 +249,7 @@ __device__ __forceinline__ uint32_t apply(const Walk &wk, uint32_t st, uint32_t 
     }
     const uint32_t i = __umul24(st, wk.ncols_e) + col;
     if (MODE == MODE_GLOBAL) return wk.gtable[i];
-    const uint32_t addr = i + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off);
+    const uint32_t addr = i + (CW == 1 ? (uint32_t)kLdsTable1 : (col_has_table_off<MODE, CW>() ? 0u : wk.table_off));
     return MODE == MODE_TABLE8 ? lds_u8(addr) : lds_u16(addr);
 }
 
@@ -299,6 +304,13 @@ __device__ __forceinline__ void piece_lookups(const Walk &wk, const uint32_t (&w
             }
         }
 #undef NEEDLE_WIN
+        if (col_has_table_off<MODE, CW>()) {
+#pragma unroll
+            for (int i = 0; i < CPP; ++i) {
+                col[i] += wk.table_off;
+                asm("" : "+v"(col[i])); // (kept off the state chain: the compiler would fold it back into the transition's add)
+            }
+        }
         return;
     }
     // all state-independent lookups of the piece first (they pipeline in the LDS) ...
@@ -365,6 +377,13 @@ __device__ __forceinline__ void piece_lookups(const Walk &wk, const uint32_t (&w
                     c = (p0 + i < rem) ? c : wk.pad_e;
                     c = (p0 + i < skip) ? wk.pre_e : c;
                     col[i] = c;
+                }
+            }
+            if (col_has_table_off<MODE, CW>()) {
+#pragma unroll
+                for (int i = 0; i < CPP; ++i) {
+                    col[i] += wk.table_off;
+                    asm("" : "+v"(col[i]));
                 }
             }
         }
