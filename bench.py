@@ -65,6 +65,15 @@ def make_pattern(workload):
         words = W.keywords(1000, min_len=6, max_len=8)
         return (DFACompiler.compile("|".join(words), "Keywords1kSparse"),
                 "union-of-1k-keywords, sparse-match variant (6..8 chars: only the planted 25 % of the rows match) find()", words)
+    if workload == "c3s16":
+        words = W.keywords(1000, min_len=6, max_len=8)
+        return (DFACompiler.compile("|".join(words), "Keywords1kSparse"),
+                "union-of-1k-keywords (6..8 chars) find() over UTF-16 rows (Java's strings): the byte program's n-gram filter, text narrowed as it is loaded", words)
+    if workload == "c3x16":
+        words = W.keywords(3000, min_len=6, max_len=8)
+        return (DFACompiler.compile("|".join(words), "Keywords3k"),
+                "union-of-3k-keywords (12 270 states) find() over UTF-16 rows (Java's strings): the byte program's n-gram filter, text narrowed as it is "
+                "loaded, candidates' walks out of L2", words)
     if workload == "c3x":
         words = W.keywords(3000, min_len=6, max_len=8)
         return (DFACompiler.compile("|".join(words), "Keywords3k"),
@@ -100,14 +109,14 @@ def make_rows(workload, words, row0, n_rows, device):
     """Shard [row0, row0 + n_rows) of the synthetic batch, generated on the GPU in slabs (into the process's one batch buffer)."""
     import torch
     from needle_amd import workload as W
-    dtype = torch.int16 if workload in ("c5", "c5w") else torch.uint8
+    dtype = torch.int16 if workload in ("c5", "c5w", "c3s16", "c3x16") else torch.uint8
     out = batch_buffer(n_rows, dtype, device)
     slab = 1 << 19
     for s in range(0, n_rows, slab):
         n = min(slab, n_rows - s)
         if workload == "c2":
             out[s:s + n] = W.digits_batch(torch, row0 + s, n, 256, device=device)
-        elif workload in ("c3", "c3s", "c3x"):
+        elif workload in ("c3", "c3s", "c3x", "c3s16", "c3x16"):
             out[s:s + n] = W.keyword_batch(torch, words, row0 + s, n, 256, device=device)
         elif workload == "c5w":
             out[s:s + n] = W.scriptseq_batch(torch, row0 + s, n, 256, device=device)
@@ -422,7 +431,10 @@ def measure(workload, args, ctx, headline):
     inf = pattern.info()
     which = {"contained_in": "contained_in", "find": "forwards", "matches": "matches"}[op_name]
     # the kernel behind the op: the n-gram candidate filter kernel where the program carries a filter (8-bit rows, containedIn / find)
-    pre = pattern.prefilter_info(which) if cw == 1 and which != "matches" else {"on": 0}
+    # (UTF-16 rows of a pattern below 0xFF take the BYTE program's filter kernel, the text narrowed as it is loaded: the launches counted by
+    # needle_pattern_prefilter_state say whether they did)
+    utf16_route = cw == 2 and which != "matches" and inf["max_char"]["matches"] < 0xFF and pattern.prefilter_state(which)["filter_launches"] > 0
+    pre = pattern.prefilter_info(which) if (cw == 1 or utf16_route) and which != "matches" else {"on": 0}
     kernel_name = "needle::ngram_kernel" if pre["on"] else "needle::scan_kernel"
     mode_names = {0: "packed functions", 1: "LDS table u8", 2: "LDS table u16", 3: "HBM table", 4: "LDS pair table", 5: "LDS hot rows + HBM table",
                   6: "compressed automaton in LDS (dense rows + exception records)"}
@@ -784,9 +796,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w"], help="the headline workload")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16"], help="the headline workload")
     ap.add_argument("--also", default=None, help="comma list of further workloads measured into \"workloads\" "
-                    "(default: c3,c3s,c3x,c5,c5w at 1 GPU, c3 at N > 1; 'none' for profiling runs)")
+                    "(default: c3,c3s,c3x,c5,c5w,c3x16 at 1 GPU, c3 at N > 1; 'none' for profiling runs; c3s16 / c3x16: the c3s / c3x dictionaries over UTF-16 rows)")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--graph", default="off", choices=["off", "scan"], help="launch the scan as a HIP graph (experiment; plain launches are faster)")
@@ -846,7 +858,7 @@ def main():
         if int(ok.item()) == 0:
             ctx.comm = None
     if args.also is None:
-        also = ["c3", "c3s", "c3x", "c5", "c5w"] if world == 1 else ["c3"]
+        also = ["c3", "c3s", "c3x", "c5", "c5w", "c3x16"] if world == 1 else ["c3"]
         if args.regex or args.op or args.rows != 10_000_000:
             also = []
     else:

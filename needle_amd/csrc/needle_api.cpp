@@ -38,7 +38,8 @@ hipError_t launch_dict(int op, const ScanArgs &a, int n_cus, hipStream_t stream)
 // needle_ngram.hip: containedIn / find behind the n-gram candidate filter
 bool ngram_shape_ok(const ScanArgs &a);
 size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng);
-hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream);
+hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
+                        int char_width = 1);
 size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng);
 hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
                                  int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
@@ -564,6 +565,55 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     const DevProgram *fp = nullptr, *bp = nullptr;
     int n_cus = 0;
     const bool need_backward = op == OP_FIND && p->t.fixed_len < 0;
+    // UTF-16 rows (Java's strings) of a pattern whose chars all lie below 0xFF -- ASCII / Latin-1 dictionaries: behind the BYTE program's
+    // n-gram filter, the text narrowed as it is loaded (needle_ngram.h narrow16; a char above 0xFE is "beyond maxChar", the reference's
+    // `c > maxChar` exit, exactly as byte 0xFF is for the byte program).  The program is chosen as for 8-bit rows below; whatever rules the
+    // filter out there (no filter for this automaton, the shape, the flood watch) leaves these rows to the UTF-16 kernels.
+    static const bool utf16_filter_off = getenv("NEEDLE_PREFILTER_UTF16") && atoi(getenv("NEEDLE_PREFILTER_UTF16")) == 0;
+    if (v->char_width == 2 && op != OP_MATCHES && !d_from && !d_end_state && !no_backward && ngram_level() > 0 && dict_env == 0 && !utf16_filter_off &&
+        p->t.dfa[W_MATCHES].max_char < 0xFF && v->row_stride * 2 < 8 * (uint64_t)kStripeBytes) { // (the anchored automaton's maxChar is the pattern's own largest char:
+                                                                                                  // the searching ones loop on every char)
+        const DevProgram *tp = nullptr;
+        rc = get_program(p, which, 1, need_backward ? 2 : 0, &tp, &n_cus);
+        if (rc) return rc;
+        bool ok = false;
+        if (tp->prog.hdr.mode == MODE_HYBRID || tp->prog.hdr.mode == MODE_GLOBAL) {
+            rc = get_program(p, which, 1, 9, &tp, nullptr);
+            if (rc) return rc;
+            ok = tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0);
+        } else {
+            bool lengths8 = false;
+            if (need_backward && find_lengths_for(tp->prog.hdr.mode)) {
+                const DevProgram *lp = nullptr;
+                rc = get_program(p, W_FORWARDS, 1, 7, &lp, nullptr);
+                if (rc) return rc;
+                if (lp && !(tp->prog.hdr.mode == MODE_PAIR && lp->prog.hdr.mode != MODE_PAIR)) tp = lp, lengths8 = true;
+            }
+            ok = tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || lengths8 || p->t.fixed_len >= 0);
+        }
+        if (ok) {
+            ScanArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rows = (const uint8_t *)v->rows;
+            a.n_rows = v->n_rows;
+            a.stride_bytes = v->row_stride;             // (in CHARS: launch_ngram with char_width 2)
+            a.total_bytes = a.n_rows * a.stride_bytes;
+            a.row_len = v->row_len;
+            a.lengths = v->lengths;
+            a.prog = tp->d_blob;
+            a.hdr = tp->prog.hdr;
+            a.fixed_len = op == OP_FIND ? p->t.fixed_len : -1;
+            a.bitmap = d_bitmap;
+            a.start = d_start;
+            a.end = d_end;
+            a.packed = d_packed;
+            if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
+                HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream, 2));
+                HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
+                return NEEDLE_OK;
+            }
+        }
+    }
     rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
     if (d_end_state && (fp->prog.hdr.mode == MODE_HYBRID || fp->prog.hdr.mode == MODE_SPARSE)) {

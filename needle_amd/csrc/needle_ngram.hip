@@ -40,6 +40,7 @@ struct NgramArgs {
                             // no walk, 3: walk on zeros (no gather), +16: runs start as soon as 32 candidates wait; 0 in the product
     uint32_t stride_log2;   // stride_bytes is a power of two (else 0xFFFFFFFF)
     uint32_t stride_recip;  // floor(2^32 / stride_bytes)
+    uint32_t char_width;    // 2: UTF-16 rows narrowed on the fly (needle_ngram.h narrow16); a.stride_bytes / a.total_bytes then count CHARS
 };
 
 static_assert(kNgWaves == (uint32_t)kWavesPerBlock, "ngram_layout assumes the scan kernels' workgroup");
@@ -50,7 +51,9 @@ typedef u32x4 u32x4_u __attribute__((aligned(1)));
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 
-template <int OP, int MODE, int S>
+// CW = 2: UTF-16 rows of a pattern whose chars all lie below 0xFF -- every offset, stride and length below is in CHARS, the text is
+// narrowed to bytes where it is loaded (the probe stream, the candidates' pieces, the second-level windows), nothing else differs.
+template <int OP, int MODE, int S, int CW = 1>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramArgs A) {
     const ScanArgs &a = A.a;
     constexpr int NW = 16 / S; // windows per 16-byte piece
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     };
     // 16 bytes of the cursor's unit.  Always issued (a load under a branch makes the compiler drain vmcnt at the join); units past the
     // batch are read from its last KiB, lanes past it from its last 16 bytes -- never used.
-    auto load_next = [&]() __attribute__((always_inline)) -> u32x4 {
+    struct Raw { u32x4 lo, hi; }; // 16 chars as loaded (CW = 1: lo only)
+    auto load_next = [&]() __attribute__((always_inline)) -> Raw {
         uint64_t base = pf_base;
         uint32_t off = lane16;
         if (!pf_interior) { // wave-uniform: the batch's last group(s), or a prefetch past the end
@@ -142,7 +146,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         }
         // (tried for MODE_GLOBAL, whose walks read the table out of L2: nontemporal text loads -- c3x 1.09 -> 1.19 ms: the candidates' own
         // text then never hits the L2 either)
-        const u32x4 v = *(const u32x4 *)(a.rows + base + off);
+        Raw v;
+        const uint8_t *src = a.rows + (base + off) * CW;
+        v.lo = *(const u32x4 *)src;
+        if (CW == 2) v.hi = *(const u32x4 *)(src + 16);
         pf_base += 1024u;
         if (++pf_u == pf_units) {
             pf_g += wave_cnt;
@@ -151,9 +158,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         return v;
     };
     pf_enter_group();
-    u32x4 R[kNgPF];
+    Raw R[kNgPF];
 #pragma unroll
     for (int k = 0; k < kNgPF; ++k) R[k] = load_next();
+    // 16 chars of text at p (unaligned) as 16 bytes
+    auto text16 = [&](const uint8_t *p) __attribute__((always_inline)) -> u32x4 {
+        if (CW == 1) return *(const u32x4_u *)p;
+        return narrow16(*(const u32x4_u *)p, *(const u32x4_u *)(p + 16));
+    };
 
     // Run the automaton for one row per lane from the start state: chars [r, ..) of row `row` of group grp, looking for a FIRST accept
     // at indexes qn .. lim0 - 1 (after it the walk runs on until the automaton dies: the reference's lastMatch), and report to the
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         if (a.lengths) len = valid ? a.lengths[grow] : 0u;
         valid = valid && qn <= len;
         const uint64_t rowabs = grow * a.stride_bytes;
-        const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull);
+        const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull) * CW;
         uint32_t lim = lim0 < len ? lim0 : len;
         uint32_t st = start_state, last = 0, first = 0;
         bool found = false, over = !valid, died = false, crossed = false;
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         };
         for (;;) {
             u32x4 tx = {0, 0, 0, 0};
-            if (dbg != 3u) tx = *(const u32x4_u *)(rowp + base);
+            if (dbg != 3u) tx = text16(rowp + base * CW);
             if (dbg == 2u) over = over || tx[0] != 0x12345678u; // (the text is waited for, the walk is not taken)
             const uint32_t w[4] = {tx[0], tx[1], tx[2], tx[3]};
             uint32_t col[16];
@@ -281,10 +293,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     const uint32_t bm2_base = A.lay.bm2_base, amask2 = A.ng.addr_mask2, m3 = A.ng.m3;
     auto level2 = [&](uint64_t grp, uint32_t row, uint32_t qn) __attribute__((always_inline)) -> bool {
         typedef uint32_t u32_u __attribute__((aligned(1)));
-        const uint8_t *rowp = a.rows + ((grp << 6) + row) * a.stride_bytes;
+        const uint8_t *rowp = a.rows + ((grp << 6) + row) * a.stride_bytes * CW;
         const bool deep = qn >= 5u;
-        const uint32_t w = *(const u32_u *)(rowp + qn - 4u);
-        const uint32_t c5 = deep ? (uint32_t)rowp[qn - 5u] : 0u;
+        uint32_t w, c5;
+        if (CW == 1) {
+            w = *(const u32_u *)(rowp + qn - 4u);
+            c5 = deep ? (uint32_t)rowp[qn - 5u] : 0u;
+        } else {
+            typedef uint16_t u16_u __attribute__((aligned(1)));
+            w = narrow_pair_patched(*(const u32_u *)(rowp + (qn - 4u) * 2u), *(const u32_u *)(rowp + (qn - 2u) * 2u));
+            c5 = deep ? (uint32_t)*(const u16_u *)(rowp + (qn - 5u) * 2u) : 0u;
+            c5 = c5 > 0xFFu ? 0xFFu : c5;
+        }
         return !deep || ngram_probe2(w, c5, mm, m3, amask2, bm2_base) != 0u;
     };
     uint32_t q2head = 0, q2tail = 0; // wave-uniform: the second queue
@@ -318,10 +338,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             uint32_t log = 0;
 #pragma unroll
             for (int k = 0; k < kNgPF; ++k) {
-                const u32x4 v = R[k];
+                const Raw raw = R[k];
                 asm volatile("" ::: "memory");
                 R[k] = load_next();
                 asm volatile("" ::: "memory");
+                const u32x4 v = CW == 1 ? raw.lo : narrow16(raw.lo, raw.hi);
                 const uint32_t pw = ngram_prev_dword(v[3], carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);
                 log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], mm, amask, bm_base);
@@ -474,9 +495,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     }
 }
 
-template <int OP, int MODE, int S>
+template <int OP, int MODE, int S, int CW>
 static hipError_t launch_ng(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
-    auto k = ngram_kernel<OP, MODE, S>;
+    auto k = ngram_kernel<OP, MODE, S, CW>;
     static thread_local uint64_t configured = 0;
     if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(n_cus), dim3(kWavesPerBlock * 64), lds, stream, A);
@@ -485,7 +506,11 @@ static hipError_t launch_ng(const NgramArgs &A, int n_cus, size_t lds, hipStream
 
 template <int OP, int MODE>
 static hipError_t launch_ng_s(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
-    return A.ng.stride == 4 ? launch_ng<OP, MODE, 4>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2>(A, n_cus, lds, stream);
+    if (A.char_width == 2) {
+        if constexpr (OP == OP_NG_FIND_ALL) return hipErrorInvalidValue; // (find-all on UTF-16 rows keeps its own kernels)
+        else return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 2>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 2>(A, n_cus, lds, stream);
+    }
+    return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 1>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 1>(A, n_cus, lds, stream);
 }
 
 template <int OP>
@@ -515,10 +540,13 @@ bool ngram_shape_ok(const ScanArgs &a) {
 }
 
 static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
-                                   const NgramArgs *fa);
+                                   const NgramArgs *fa, int char_width = 1);
 
-hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream) {
-    return launch_ngram_any(op, a, ng, d_bitmap, d_stats, n_cus, stream, nullptr);
+// char_width 2: UTF-16 rows behind the BYTE program's filter (patterns below 0xFF only: the caller checks) -- a.stride_bytes and
+// a.total_bytes count chars then
+hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
+                        int char_width) {
+    return launch_ngram_any(op, a, ng, d_bitmap, d_stats, n_cus, stream, nullptr, char_width);
 }
 
 // LDS of the find-all form; 0 = does not fit
@@ -541,10 +569,11 @@ hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const
 }
 
 static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
-                                   const NgramArgs *fa) {
+                                   const NgramArgs *fa, int char_width) {
     NgramArgs A;
     memset(&A, 0, sizeof(A));
     if (fa) A = *fa;
+    A.char_width = (uint32_t)char_width;
     A.a = a;
     A.ng = ng;
     A.ng_bitmap = d_bitmap;

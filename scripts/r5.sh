@@ -50,7 +50,7 @@ bench)
   timeout 1700 python bench.py "$@" > $O/bench_$TAG.json 2> $O/bench_$TAG.err; grep -v "^{" $O/bench_$TAG.err | tail -3; wc -c $O/bench_$TAG.json; tail -c 1200 $O/bench_$TAG.json ;;
 profiles)
   # everything profiles/r05_* is made from (then: summarize_profile.py gpurun_out/prof_<w> 05 <w>, summarize_pmc.py 05)
-  for w in c2 c3 c3s c3x c5 c5w; do scripts/profile.sh $w > gpurun_out/profile_$w.log 2>&1; done
+  for w in c2 c3 c3s c3x c5 c5w c3x16; do scripts/profile.sh $w > gpurun_out/profile_$w.log 2>&1; done
   G1="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SMEM"
   G2="SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY"
   G3="SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"

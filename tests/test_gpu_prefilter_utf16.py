@@ -1,0 +1,120 @@
+"""UTF-16 rows behind the byte program's n-gram filter (needle_amd/csrc/needle_ngram.hip, CW = 2; needle_ngram.h narrow16): for patterns
+whose chars all lie below 0xFF the filter kernel narrows the text as it loads it and runs the 8-bit program -- a char above 0xFE is "beyond
+maxChar" (DFAClassBuilder.java:440, :565: `c > maxChar`), exactly what byte 0xFF is to the byte program.  The answers must be the CPU
+oracle's on the UTF-16 rows, bit for bit, and those of the UTF-16 scan kernels with the route switched off (NEEDLE_PREFILTER_UTF16=0);
+`filter_launches` of needle_pattern_prefilter_state proves which kernel ran.  Shapes: full rows, ragged rows, strides of 64 / 192 / 256 /
+1024 chars, batches ending inside a group and inside a unit, keywords at both ends of a row, chars above 0xFF around and inside keywords'
+places (CJK, 0x0100 + a keyword char: same low byte, another char), one-dword results, the big dictionary whose walks leave the LDS."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from needle_amd import workload as W
+from needle_amd.pattern import DFACompiler, unpack_bitmap
+from test_compile_matches_txt import oracle_for
+route_on = int(sys.argv[1])
+dev = "cuda"
+rng = np.random.default_rng(7)
+
+def utf16_rows(words, n, stride, seed):
+    """keyword text as UTF-16, with chars above 0xFF sprinkled in: plain CJK, and `0x0100 | c` for chars c of the text itself
+    (the low byte of a keyword char under a non-zero high byte must NOT read as that char)"""
+    rows8 = W.keyword_batch(np, words, seed, n, stride)
+    r = rows8.astype(np.uint16)
+    g = np.random.default_rng(seed)
+    m = g.random(r.shape) < 0.02
+    r[m] = g.integers(0x4E00, 0x9FFF, size=int(m.sum()), dtype=np.uint16)
+    m2 = g.random(r.shape) < 0.02
+    r[m2] |= 0x0100
+    m3 = g.random(r.shape) < 0.005
+    r[m3] = 0x00FF   # the substitute itself, and 0xFF00-ish values
+    m4 = g.random(r.shape) < 0.005
+    r[m4] = 0xFF00 | (r[m4] & 0xFF)
+    # keywords at both ends of some rows (row start: no window reaches back; row end: cut by the row)
+    for i in range(0, n, 7):
+        w = words[i % len(words)]
+        r[i, :len(w)] = np.frombuffer(w.encode(), dtype=np.uint8)
+        w2 = words[(i * 3 + 1) % len(words)]
+        r[i, stride - len(w2):] = np.frombuffer(w2.encode(), dtype=np.uint8)
+        if i % 14 == 0: r[i, stride - len(w2) + 1] |= 0x0100  # ... broken by a high byte
+    return r
+
+def check(p, o, host, lens, tag):
+    n = host.shape[0]
+    rows = torch.from_numpy(host.view(np.int16)).to(dev)
+    dl = None if lens is None else torch.from_numpy(lens.astype(np.int32)).to(dev)
+    before = p.prefilter_state("forwards")["filter_launches"] + p.prefilter_state("contained_in")["filter_launches"]
+    fw, fs, fe = p.find_batch(rows, dl)
+    cw = p.contained_in_batch(rows, dl)
+    pw, pk = p.find_packed16_batch(rows, dl)
+    torch.cuda.synchronize()
+    after = p.prefilter_state("forwards")["filter_launches"] + p.prefilter_state("contained_in")["filter_launches"]
+    hl = None if lens is None else lens.astype(np.uint32)
+    of, ofs, ofe = o.batch_find(host, hl, threads=8)
+    oc = o.batch_contained_in(host, hl, threads=8)
+    got = unpack_bitmap(fw, n)
+    bad = np.nonzero(got != of)[0]
+    assert bad.size == 0, (tag, "find bitmap", bad[:5], n)
+    fs, fe = fs.cpu().numpy(), fe.cpu().numpy()
+    bs = np.nonzero((fs != ofs) | (fe != ofe))[0]
+    assert bs.size == 0, (tag, "start/end", bs[:5], fs[bs[:5]], ofs[bs[:5]], fe[bs[:5]], ofe[bs[:5]])
+    assert (unpack_bitmap(cw, n) == oc).all(), (tag, "containedIn")
+    pkv = pk.cpu().numpy().view(np.uint32)
+    assert (unpack_bitmap(pw, n) == of).all() and ((pkv & 0xFFFF)[of] == ofs[of]).all() and ((pkv >> 16)[of] == ofe[of]).all() and (pkv[~of] == 0xFFFFFFFF).all(), (tag, "packed16")
+    return after - before, int(of.sum())
+
+big = W.keywords(1000, min_len=6, max_len=8)
+huge = W.keywords(3000, min_len=6, max_len=8)
+small = ["Sherlock", "Holmes", "Watson", "Moriarty", "Mycroft", "Baskerville"]
+total_launches = 0
+for name, words, shapes in (("1000 keywords", big, [(20000, 256), (4099, 192), (2500, 1024), (7001, 64)]),
+                            ("3000 keywords (walks out of L2)", huge, [(20000, 256), (3001, 192)]),
+                            ("six names", small, [(9000, 256)])):
+    rx = "|".join(words)
+    p = DFACompiler.compile(rx, "t", 0)
+    o, _ = oracle_for(rx, 0)
+    for n, stride in shapes:
+        host = utf16_rows(words, n, stride, 1000 + n)
+        launches, hits = check(p, o, host, None, (name, n, stride, "full"))
+        total_launches += launches
+        assert hits > 0
+        if name != "six names":
+            assert (launches >= 3) == bool(route_on), (name, n, stride, launches)
+        lens = rng.integers(0, stride + 1, size=n)
+        lens[::5] = stride
+        launches, _ = check(p, o, host, lens, (name, n, stride, "ragged"))
+        total_launches += launches
+# a pattern with a char at or above 0xFF never takes the route: the UTF-16 kernels' answers
+p = DFACompiler.compile("abcdefÿgh|bcdefgh", "t", 0)
+o, _ = oracle_for("abcdefÿgh|bcdefgh", 0)
+host = utf16_rows(["abcdefgh", "bcdefgh"], 5000, 256, 5)
+host[::3, 10:19] = np.array([97, 98, 99, 100, 101, 102, 0xFF, 103, 104], dtype=np.uint16)
+launches, hits = check(p, o, host, None, ("char 0xFF in the pattern",))
+assert launches == 0 and hits > 0
+print("OK", total_launches)
+'''
+
+
+def run_child(route_on):
+    env = dict(os.environ)
+    env["NEEDLE_PREFILTER_UTF16"] = "1" if route_on else "0"
+    r = subprocess.run([sys.executable, "-c", CODE, str(route_on)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    return int(r.stdout.strip().split()[-1])
+
+
+@pytest.mark.gpu
+def test_utf16_rows_behind_the_byte_filter_match_the_oracle():
+    assert run_child(1) > 0
+
+
+@pytest.mark.gpu
+def test_utf16_route_off_is_the_same_answer():
+    assert run_child(0) == 0
