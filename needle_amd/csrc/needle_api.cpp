@@ -133,11 +133,16 @@ struct DevProgram {
     // Flood watch of the n-gram filter kernel.  Text that passes the filter almost everywhere (built from the dictionary's own
     // keyword tails: one automaton run per window) makes that kernel several times SLOWER than the ordinary scan (measured:
     // 5.3 against 1.13 ms on the C3-sparse dictionary, scripts/ngram_worstcase.py).  Every filter launch adds its candidates
-    // and KiB of text to d_ng_stats; the pair is copied to the pinned h_ng_stats behind the kernel, on its stream.  The NEXT call
+    // and KiB of text to d_ng_stats; the pair is copied to the pinned h_ng_stats behind the kernel (on ng_stream, below).  The NEXT call
     // reads it without waiting: above 16 candidates per KiB (the break-even; the bench text has 3.3) the filter is suspended for
     // the program's next 32 calls, doubling up to 1024 while the text stays like that.  Answers are the same either way.
     uint32_t *d_ng_stats = nullptr;            // {candidates, KiB of text}: MONOTONIC device counters (never reset by the host)
     volatile uint64_t *h_ng_stats = nullptr;    // pinned: the pair as it stood behind the last completed filter launch (one 8-byte copy)
+    // The copy runs on a stream of its own behind an event of the launch: on the caller's stream it could queue behind another stream's
+    // bulk D2H on the copy engine and hold the NEXT scan back until that finished (measured: pipelined host landing of a 1.1 ms scan
+    // at 1.86 ms per step = scan + copy, serialised).
+    hipStream_t ng_stream = nullptr;
+    hipEvent_t ng_ev = nullptr;
     // the watch's own state, per program (= per pattern x device x op), shared by every stream and thread that uses it
     mutable std::mutex ng_mu;
     mutable uint32_t ng_seen_cand = 0, ng_seen_kib = 0; // what the last evaluation had seen: the watch works on deltas
@@ -145,8 +150,9 @@ struct DevProgram {
     mutable float ng_last_rate = 0.0f;
     mutable uint64_t ng_launches = 0, ng_suspended_calls = 0;
     DevProgram() = default;
-    DevProgram(DevProgram &&o) noexcept : prog(std::move(o.prog)), d_blob(o.d_blob), d_ng(o.d_ng), d_ng_stats(o.d_ng_stats), h_ng_stats(o.h_ng_stats) { // (moved before first use: the watch's state starts fresh)
-        o.d_blob = nullptr, o.d_ng = nullptr, o.d_ng_stats = nullptr, o.h_ng_stats = nullptr;
+    DevProgram(DevProgram &&o) noexcept
+        : prog(std::move(o.prog)), d_blob(o.d_blob), d_ng(o.d_ng), d_ng_stats(o.d_ng_stats), h_ng_stats(o.h_ng_stats), ng_stream(o.ng_stream), ng_ev(o.ng_ev) { // (moved before first use: the watch's state starts fresh)
+        o.d_blob = nullptr, o.d_ng = nullptr, o.d_ng_stats = nullptr, o.h_ng_stats = nullptr, o.ng_stream = nullptr, o.ng_ev = nullptr;
     }
 };
 
@@ -177,10 +183,13 @@ struct needle_pattern {
     MatchLengths ml;
     ~needle_pattern() {
         for (auto &kv : cache) {
+            if (kv.second.ng_stream) (void)hipStreamSynchronize(kv.second.ng_stream); // (a stats copy may still be on its way into h_ng_stats)
             if (kv.second.d_blob) (void)hipFree(kv.second.d_blob);
             if (kv.second.d_ng) (void)hipFree(kv.second.d_ng);
             if (kv.second.d_ng_stats) (void)hipFree(kv.second.d_ng_stats);
             if (kv.second.h_ng_stats) (void)hipHostFree((void *)kv.second.h_ng_stats);
+            if (kv.second.ng_stream) (void)hipStreamDestroy(kv.second.ng_stream);
+            if (kv.second.ng_ev) (void)hipEventDestroy(kv.second.ng_ev);
         }
     }
 };
@@ -260,10 +269,15 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
             if (ce == hipSuccess) ce = hipMalloc((void **)&dp.d_ng_stats, 8);
             if (ce == hipSuccess) ce = hipMemset(dp.d_ng_stats, 0, 8);
             if (ce == hipSuccess) ce = hipHostMalloc((void **)&dp.h_ng_stats, 8, hipHostMallocDefault);
+            if (ce == hipSuccess) ce = hipStreamCreateWithFlags(&dp.ng_stream, hipStreamNonBlocking);
+            if (ce == hipSuccess) ce = hipEventCreateWithFlags(&dp.ng_ev, hipEventDisableTiming);
             if (ce != hipSuccess) {
                 (void)hipFree(dp.d_blob);
                 if (dp.d_ng) (void)hipFree(dp.d_ng);
                 if (dp.d_ng_stats) (void)hipFree(dp.d_ng_stats);
+                if (dp.h_ng_stats) (void)hipHostFree((void *)dp.h_ng_stats);
+                if (dp.ng_stream) (void)hipStreamDestroy(dp.ng_stream);
+                if (dp.ng_ev) (void)hipEventDestroy(dp.ng_ev);
                 return hip_fail(ce, "hipMalloc/hipMemcpy(n-gram bitmap)");
             }
             dp.h_ng_stats[0] = 0;
@@ -397,11 +411,15 @@ static bool ngram_watch_allows(const needle_pattern *p, const DevProgram *fp) {
     ++fp->ng_suspended_calls;
     return false;
 }
-// (behind the kernel on its stream; the host never waits for it)
+// (behind the kernel, on the program's own copy stream; neither the host nor the caller's stream ever waits for it)
 static hipError_t ngram_watch_after_launch(const DevProgram *fp, hipStream_t stream) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipSuccess; // (not captured: see above)
-    return hipMemcpyAsync((void *)fp->h_ng_stats, fp->d_ng_stats, 8, hipMemcpyDeviceToHost, stream);
+    std::lock_guard<std::mutex> lk(fp->ng_mu); // (one event per program: record / wait pairs of concurrent callers must not interleave)
+    hipError_t e = hipEventRecord(fp->ng_ev, stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(fp->ng_stream, fp->ng_ev, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync((void *)fp->h_ng_stats, fp->d_ng_stats, 8, hipMemcpyDeviceToHost, fp->ng_stream);
+    return e;
 }
 
 // NEEDLE_FIND_LENGTHS: 0 = find() always by forward + backward walks, 1 (default) = the "lengths" automaton where the ordinary
