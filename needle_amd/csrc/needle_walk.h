@@ -553,14 +553,17 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
         uint32_t cs[8];
         if (!SWZ) {
             // one address per lane, the chars at immediate offsets (a lane outside its window reads the window's start: unused)
-            const uint32_t rd = win_addr + ((uint32_t)rel0 < win_bytes ? (uint32_t)rel0 : 7u * CW) - 7u * CW;
+            // (a lane that is not walking reads LDS offset 0: all of them the same chars, so that their map / table lookups below are
+            // one broadcast address instead of 64 scattered ones -- C5: 70 % of the lanes)
+            uint32_t rd = win_addr + ((uint32_t)rel0 < win_bytes ? (uint32_t)rel0 : 7u * CW) - 7u * CW;
+            rd = live ? rd : 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k) cs[k] = (CW == 1) ? lds_u8(rd + (uint32_t)(7 - k)) : lds_u16(rd + (uint32_t)(7 - k) * 2u);
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t rel = (uint32_t)(rel0 - k * CW);
-                const uint32_t ad = win_addr + ((rel < win_bytes ? rel : 0u) ^ swz16);
+                const uint32_t ad = live ? win_addr + ((rel < win_bytes ? rel : 0u) ^ swz16) : 0u;
                 cs[k] = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
             }
         }
