@@ -676,7 +676,7 @@ def measure(workload, args, ctx, headline):
                                            "note": "steady state of scan k + 1 on the launch stream beside the D2H of step k's results on a copy stream (two result sets); "
                                                    "find(): the one-dword form" if use_packed else "two result sets, D2H under the next scan"}
         del dsets, hsets
-    if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s", "c3x") and is_find:
+    if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s", "c3x", "c3s16", "c3x16") and is_find:
         # EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
         # the batch (needle_find_all.hip; for dictionaries behind the n-gram candidate filter -- c3s -- that kernel's find-all form,
         # needle_ngram.hip): counts + dense per-row slots.  Its own figure, never the `value`.

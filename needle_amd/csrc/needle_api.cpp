@@ -43,7 +43,7 @@ hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const 
 size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng);
 hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
                                  int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int char_width = 1);
 int ngram_level(); // needle_lower.cpp (NEEDLE_PREFILTER)
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
@@ -422,6 +422,14 @@ static hipError_t ngram_watch_after_launch(const DevProgram *fp, hipStream_t str
     return e;
 }
 
+// UTF-16 rows behind the BYTE program's n-gram filter (needle_ngram.h narrow16): patterns whose chars all lie below 0xFF -- the anchored
+// automaton's maxChar is the pattern's own largest char (the searching automata loop on every char) -- so that a char above 0xFE is "beyond
+// maxChar" exactly as byte 0xFF is for the program lowered for 8-bit rows.  NEEDLE_PREFILTER_UTF16=0: never.
+static bool utf16_filter_ok(const needle_pattern *p) {
+    static const bool off = getenv("NEEDLE_PREFILTER_UTF16") && atoi(getenv("NEEDLE_PREFILTER_UTF16")) == 0;
+    return !off && p->t.dfa[W_MATCHES].max_char < 0xFF;
+}
+
 // NEEDLE_FIND_LENGTHS: 0 = find() always by forward + backward walks, 1 (default) = the "lengths" automaton where the ordinary
 // program is a plain LDS table, 2 = also instead of the pair table (measured slower: DESIGN.md s4)
 static bool find_lengths_for(uint32_t mode) {
@@ -587,10 +595,8 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // n-gram filter, the text narrowed as it is loaded (needle_ngram.h narrow16; a char above 0xFE is "beyond maxChar", the reference's
     // `c > maxChar` exit, exactly as byte 0xFF is for the byte program).  The program is chosen as for 8-bit rows below; whatever rules the
     // filter out there (no filter for this automaton, the shape, the flood watch) leaves these rows to the UTF-16 kernels.
-    static const bool utf16_filter_off = getenv("NEEDLE_PREFILTER_UTF16") && atoi(getenv("NEEDLE_PREFILTER_UTF16")) == 0;
-    if (v->char_width == 2 && op != OP_MATCHES && !d_from && !d_end_state && !no_backward && ngram_level() > 0 && dict_env == 0 && !utf16_filter_off &&
-        p->t.dfa[W_MATCHES].max_char < 0xFF && v->row_stride * 2 < 8 * (uint64_t)kStripeBytes) { // (the anchored automaton's maxChar is the pattern's own largest char:
-                                                                                                  // the searching ones loop on every char)
+    if (v->char_width == 2 && op != OP_MATCHES && !d_from && !d_end_state && !no_backward && ngram_level() > 0 && dict_env == 0 && utf16_filter_ok(p) &&
+        v->row_stride * 2 < 8 * (uint64_t)kStripeBytes) {
         const DevProgram *tp = nullptr;
         rc = get_program(p, which, 1, need_backward ? 2 : 0, &tp, &n_cus);
         if (rc) return rc;
@@ -1606,7 +1612,9 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     // kernel's find-all form files every verified candidate and each row sorts its own out against its moving cursor (dense slots,
     // the counting pass and the compact filing alike).  NEEDLE_FIND_ALL_FILTER=0: off (A/B, tests).
     static const bool fa_filter = !(getenv("NEEDLE_FIND_ALL_FILTER") && atoi(getenv("NEEDLE_FIND_ALL_FILTER")) == 0);
-    if (fa_filter && (count_only || d_offsets || slots) && v->char_width == 1 && ngram_level() > 0 && (p->t.fixed_len >= 0 || find_lengths_for(MODE_SPARSE))) {
+    // (UTF-16 rows of a pattern below 0xFF: the same byte programs, the text narrowed as it is loaded -- utf16_filter_ok)
+    if (fa_filter && (count_only || d_offsets || slots) && (v->char_width == 1 || (v->char_width == 2 && utf16_filter_ok(p))) && ngram_level() > 0 &&
+        (p->t.fixed_len >= 0 || find_lengths_for(MODE_SPARSE))) {
         const DevProgram *sp = nullptr;
         int cus = 0;
         rc = get_program(p, W_FORWARDS, 1, p->t.fixed_len >= 0 ? 0 : 7, &sp, &cus);
@@ -1620,7 +1628,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
             memset(&a, 0, sizeof(a));
             a.rows = (const uint8_t *)v->rows;
             a.n_rows = v->n_rows;
-            a.stride_bytes = stride_bytes;
+            a.stride_bytes = v->row_stride; // (UTF-16 rows: in CHARS -- launch_ngram_find_all with char_width 2)
             a.total_bytes = a.n_rows * a.stride_bytes;
             a.row_len = v->row_len;
             a.lengths = v->lengths;
@@ -1631,7 +1639,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
                 int32_t *d_more = nullptr;
                 HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
                 hipError_t e = hipMemsetAsync(d_more, 0, 4, stream);
-                if (e == hipSuccess) e = launch_ngram_find_all(a, sp->prog.ng.p, sp->d_ng, sp->d_ng_stats, slots, d_counts, d_start, d_end, d_packed, d_more, d_offsets, count_only, cus, stream);
+                if (e == hipSuccess) e = launch_ngram_find_all(a, sp->prog.ng.p, sp->d_ng, sp->d_ng_stats, slots, d_counts, d_start, d_end, d_packed, d_more, d_offsets, count_only, cus, stream, (int)v->char_width);
                 if (e == hipSuccess) e = ngram_watch_after_launch(sp, stream);
                 int32_t m = 0;
                 if (e == hipSuccess && more) {

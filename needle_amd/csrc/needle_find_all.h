@@ -1,6 +1,7 @@
 // Launch arguments of the one-pass find-all kernel (needle_find_all.hip); shared with the launcher's caller in
 // needle_api.cpp.
 #pragma once
+#include <stddef.h>
 #include "needle_device.h"
 
 namespace needle {
@@ -24,5 +25,8 @@ struct FindAllArgs {
     uint32_t lmode;          // 1: the program is the "lengths" automaton (needle_lower.h): start = end - pend[end state], read
                              // from LDS at hdr.fa_len_off; the search also ends in the states fa_dead_lo .. + fa_dead_n - 1
 };
+// backward_walk (needle_walk.h) reads the ScanArgs header words from the kernarg segment at their offsets INSIDE ScanArgs: it must be the first member
+static_assert(offsetof(FindAllArgs, s) == 0, "ScanArgs must be the first member of FindAllArgs (kernarg_here, needle_walk.h)");
+
 
 } // namespace needle

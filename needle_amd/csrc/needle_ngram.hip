@@ -506,10 +506,7 @@ static hipError_t launch_ng(const NgramArgs &A, int n_cus, size_t lds, hipStream
 
 template <int OP, int MODE>
 static hipError_t launch_ng_s(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
-    if (A.char_width == 2) {
-        if constexpr (OP == OP_NG_FIND_ALL) return hipErrorInvalidValue; // (find-all on UTF-16 rows keeps its own kernels)
-        else return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 2>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 2>(A, n_cus, lds, stream);
-    }
+    if (A.char_width == 2) return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 2>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 2>(A, n_cus, lds, stream);
     return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 1>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 1>(A, n_cus, lds, stream);
 }
 
@@ -560,12 +557,12 @@ size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
 // rows and the lengths program, the outputs are the find-all ones.
 hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
                                  int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int char_width) {
     NgramArgs F;
     memset(&F, 0, sizeof(F));
     F.fa_slots = slots, F.fa_counts = counts, F.fa_starts = starts, F.fa_ends = ends, F.fa_packed = packed, F.fa_more = more;
     F.fa_offsets = offsets, F.fa_count_only = count_only ? 1u : 0u;
-    return launch_ngram_any(OP_NG_FIND_ALL, a, ng, d_bitmap, d_stats, n_cus, stream, &F);
+    return launch_ngram_any(OP_NG_FIND_ALL, a, ng, d_bitmap, d_stats, n_cus, stream, &F, char_width);
 }
 
 static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,

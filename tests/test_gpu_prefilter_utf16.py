@@ -4,7 +4,8 @@ maxChar" (DFAClassBuilder.java:440, :565: `c > maxChar`), exactly what byte 0xFF
 oracle's on the UTF-16 rows, bit for bit, and those of the UTF-16 scan kernels with the route switched off (NEEDLE_PREFILTER_UTF16=0);
 `filter_launches` of needle_pattern_prefilter_state proves which kernel ran.  Shapes: full rows, ragged rows, strides of 64 / 192 / 256 /
 1024 chars, batches ending inside a group and inside a unit, keywords at both ends of a row, chars above 0xFF around and inside keywords'
-places (CJK, 0x0100 + a keyword char: same low byte, another char), one-dword results, the big dictionary whose walks leave the LDS."""
+places (CJK, 0x0100 + a keyword char: same low byte, another char), one-dword results, every match of every row (dense, one dword per match, counting pass, compact filing), the big dictionary whose walks
+leave the LDS."""
 import os
 import subprocess
 import sys
@@ -68,7 +69,31 @@ def check(p, o, host, lens, tag):
     assert (unpack_bitmap(cw, n) == oc).all(), (tag, "containedIn")
     pkv = pk.cpu().numpy().view(np.uint32)
     assert (unpack_bitmap(pw, n) == of).all() and ((pkv & 0xFFFF)[of] == ofs[of]).all() and ((pkv >> 16)[of] == ofe[of]).all() and (pkv[~of] == 0xFFFFFFFF).all(), (tag, "packed16")
-    return after - before, int(of.sum())
+    # every match of every row through the filter kernel's find-all form (dense slots, one dword per match, the counting pass, the
+    # compact filing) against the oracle's repeated find() on every 5th row
+    want = {i: o.find_all(host[i] if hl is None else host[i, :hl[i]]) for i in range(0, n, 5)}
+    slots = max([len(w) for w in want.values()] + [1]) + 1
+    counts, st, en, more = p.find_all_dense(rows, slots, dl)
+    c2, se, more2 = p.find_all_dense_packed16(rows, slots, dl)
+    cnt = p.count_matches_batch(rows, dl).cpu().numpy()
+    offs, s1, e1 = p.find_all_csr(rows, dl)
+    torch.cuda.synchronize()
+    counts, st, en = counts.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+    for i, w in want.items():
+        k = min(len(w), slots)
+        assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == w[:k], (tag, "find-all", i, counts[i], st[i], en[i], w[:6])
+    assert (c2.cpu().numpy() == counts).all() and more2 == more, (tag, "find-all packed counts")
+    sev = se.cpu().numpy().view(np.uint32)
+    filed = np.arange(slots)[None, :] < counts[:, None]
+    assert ((sev & 0xFFFF)[filed] == st[filed]).all() and ((sev >> 16)[filed] == en[filed]).all(), (tag, "find-all packed")
+    assert (np.minimum(cnt, slots) == counts).all() and bool(more) == bool((cnt > slots).any()), (tag, "count pass")
+    offs, s1, e1 = offs.cpu().numpy(), s1.cpu().numpy(), e1.cpu().numpy()
+    assert (np.diff(offs) == cnt).all() and offs[-1] == cnt.sum() == len(s1), (tag, "csr offsets")
+    fits = cnt <= slots
+    csr_row = np.repeat(np.arange(n), cnt)
+    assert (s1[fits[csr_row]] == st[filed & fits[:, None]]).all() and (e1[fits[csr_row]] == en[filed & fits[:, None]]).all(), (tag, "csr matches")
+    final = p.prefilter_state("forwards")["filter_launches"] + p.prefilter_state("contained_in")["filter_launches"]
+    return after - before, int(of.sum()), final - after
 
 big = W.keywords(1000, min_len=6, max_len=8)
 huge = W.keywords(3000, min_len=6, max_len=8)
@@ -82,21 +107,22 @@ for name, words, shapes in (("1000 keywords", big, [(20000, 256), (4099, 192), (
     o, _ = oracle_for(rx, 0)
     for n, stride in shapes:
         host = utf16_rows(words, n, stride, 1000 + n)
-        launches, hits = check(p, o, host, None, (name, n, stride, "full"))
+        launches, hits, fa_launches = check(p, o, host, None, (name, n, stride, "full"))
         total_launches += launches
         assert hits > 0
         if name != "six names":
             assert (launches >= 3) == bool(route_on), (name, n, stride, launches)
+            assert (fa_launches >= 4) == bool(route_on), (name, n, stride, "find-all launches", fa_launches)
         lens = rng.integers(0, stride + 1, size=n)
         lens[::5] = stride
-        launches, _ = check(p, o, host, lens, (name, n, stride, "ragged"))
+        launches, _, _ = check(p, o, host, lens, (name, n, stride, "ragged"))
         total_launches += launches
 # a pattern with a char at or above 0xFF never takes the route: the UTF-16 kernels' answers
 p = DFACompiler.compile("abcdefÿgh|bcdefgh", "t", 0)
 o, _ = oracle_for("abcdefÿgh|bcdefgh", 0)
 host = utf16_rows(["abcdefgh", "bcdefgh"], 5000, 256, 5)
 host[::3, 10:19] = np.array([97, 98, 99, 100, 101, 102, 0xFF, 103, 104], dtype=np.uint16)
-launches, hits = check(p, o, host, None, ("char 0xFF in the pattern",))
+launches, hits, _ = check(p, o, host, None, ("char 0xFF in the pattern",))
 assert launches == 0 and hits > 0
 print("OK", total_launches)
 '''
