@@ -44,6 +44,11 @@ struct NgramArgs {
 };
 
 static_assert(kNgWaves == (uint32_t)kWavesPerBlock, "ngram_layout assumes the scan kernels' workgroup");
+static_assert(offsetof(NgramArgs, a) == 0, "the kernel reads ScanArgs words from the kernarg segment at their own offsets (kernarg_here, needle_walk.h)");
+// kernel-argument words that are needed once per group of rows (result pointers, the lengths table's place): read from the kernarg segment
+// where they are used instead of living in SGPRs through the filter loop (needle_walk.h kernarg_here: the kernel spilled 24 of them)
+#define NEEDLE_NG_PTR(T, member) kernarg_ptr<T>(ka, (uint32_t)offsetof(NgramArgs, member))
+#define NEEDLE_NG_U32(member) kernarg_u32(ka, (uint32_t)offsetof(NgramArgs, member))
 constexpr int OP_NG_FIND_ALL = 3; // (beside OP_CONTAINED_IN / OP_FIND of needle_device.h)
 constexpr int kNgPF = 4;                                // units in flight per wave = units per batch
 
@@ -183,7 +188,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     auto walk_row = [&](uint64_t grp, uint32_t row, bool valid, uint32_t qn, uint32_t r, uint32_t lim0) __attribute__((always_inline)) -> Hit {
         const uint64_t grow = (grp << 6) + row;
         uint32_t len = a.row_len;
-        if (a.lengths) len = valid ? a.lengths[grow] : 0u;
+        const KernargPtr ka = kernarg_here();
+        const uint32_t *const lens = NEEDLE_NG_PTR(const uint32_t, a.lengths);
+        if (lens) len = valid ? lens[grow] : 0u;
         valid = valid && qn <= len;
         const uint64_t rowabs = grow * a.stride_bytes;
         const uint8_t *rowp = a.rows + (valid ? rowabs : 0ull) * CW;
@@ -236,16 +243,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         Hit h;
         h.found = found, h.died = died && !found, h.crossed = crossed, h.first = first, h.last = last, h.start = 0;
         if (FINDLIKE) {
-            if (a.fixed_len >= 0) {
-                h.start = (int32_t)last - a.fixed_len; // :640-646
+            const int32_t fixed_len = (int32_t)NEEDLE_NG_U32(a.fixed_len);
+            if (fixed_len >= 0) {
+                h.start = (int32_t)last - fixed_len; // :640-646
             } else {
                 uint32_t pidx = st;
                 if (MODE == MODE_SPARSE) { // (needle_scan.h finish_rows: a live stop state asks its END record)
-                    const uint32_t st_end = sparse_end<1>(wk, st, found && st > wk.dead_hi, a.hdr.sp_end_col4);
-                    pidx = (st_end & 0xFFFFu) - a.hdr.sp_dead_row0;
+                    const uint32_t st_end = sparse_end<1>(wk, st, found && st > wk.dead_hi, NEEDLE_NG_U32(a.hdr.sp_end_col4));
+                    pidx = (st_end & 0xFFFFu) - NEEDLE_NG_U32(a.hdr.sp_dead_row0);
                 }
-                if (MODE == MODE_GLOBAL) h.start = (int32_t)last - (int32_t)a.prog[a.hdr.fa_len_off + (found ? pidx : 0u)]; // (pend[] behind the table)
-                else h.start = (int32_t)last - (int32_t)lds_u8(a.hdr.fa_len_off + (found ? pidx : 0u));
+                const uint32_t len_off = NEEDLE_NG_U32(a.hdr.fa_len_off);
+                if (MODE == MODE_GLOBAL) h.start = (int32_t)last - (int32_t)a.prog[len_off + (found ? pidx : 0u)]; // (pend[] behind the table)
+                else h.start = (int32_t)last - (int32_t)lds_u8(len_off + (found ? pidx : 0u));
             }
         }
         return h;
@@ -474,24 +483,31 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             const bool row_ok = (uint32_t)lane < rows_in;
             const bool res = row_ok && key != ~0ull;
             const uint64_t word = __ballot(res);
-            if (lane == 0) a.bitmap[g] = word;
+            const KernargPtr ka = kernarg_here();
+            if (lane == 0) NEEDLE_NG_PTR(uint64_t, a.bitmap)[g] = word;
             if (row_ok) {
-                if (a.packed) { // the key's low dword is end << 16 | start already; ~0 = no match
-                    a.packed[(g << 6) + lane] = (uint32_t)key;
+                uint32_t *const o_packed = NEEDLE_NG_PTR(uint32_t, a.packed);
+                if (o_packed) { // the key's low dword is end << 16 | start already; ~0 = no match
+                    o_packed[(g << 6) + lane] = (uint32_t)key;
                 } else {
-                    a.start[(g << 6) + lane] = res ? (int32_t)(key & 0xFFFFu) : -1;
-                    a.end[(g << 6) + lane] = res ? (int32_t)((key >> 16) & 0xFFFFu) : -1;
+                    NEEDLE_NG_PTR(int32_t, a.start)[(g << 6) + lane] = res ? (int32_t)(key & 0xFFFFu) : -1;
+                    NEEDLE_NG_PTR(int32_t, a.end)[(g << 6) + lane] = res ? (int32_t)((key >> 16) & 0xFFFFu) : -1;
                 }
             }
         } else if (lane == 0) {
-            a.bitmap[g] = *(const lds_u64_t *)(uintptr_t)sbase;
+            const KernargPtr ka = kernarg_here();
+            NEEDLE_NG_PTR(uint64_t, a.bitmap)[g] = *(const lds_u64_t *)(uintptr_t)sbase;
         }
         asm volatile("" ::: "memory");
     }
     // what the host's flood watch reads (needle_api.cpp): candidates and KiB of text of this launch
-    if (A.stats && lane == 0) {
-        atomicAdd(&A.stats[0], n_cand);
-        atomicAdd(&A.stats[1], n_units);
+    {
+        const KernargPtr ka = kernarg_here();
+        uint32_t *const o_stats = NEEDLE_NG_PTR(uint32_t, stats);
+        if (o_stats && lane == 0) {
+            atomicAdd(&o_stats[0], n_cand);
+            atomicAdd(&o_stats[1], n_units);
+        }
     }
 }
 
