@@ -559,6 +559,28 @@ static int run_speculative_stripes(needle_pattern *p, int op, const needle_batch
     return finish(NEEDLE_OK);
 }
 
+// Launch arguments of the filter kernel (needle_ngram.hip) for program `tp` on batch `v`.  stride: bytes between rows -- or CHARS, for UTF-16
+// rows behind the byte program (launch_ngram with char_width 2 scales the addresses).
+static ScanArgs filter_scan_args(const needle_batch_view *v, uint64_t stride, const DevProgram *tp, int32_t fixed_len, uint64_t *d_bitmap, int32_t *d_start,
+                                 int32_t *d_end, uint32_t *d_packed) {
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = (const uint8_t *)v->rows;
+    a.n_rows = v->n_rows;
+    a.stride_bytes = stride;
+    a.total_bytes = a.n_rows * a.stride_bytes;
+    a.row_len = v->row_len;
+    a.lengths = v->lengths;
+    a.prog = tp->d_blob;
+    a.hdr = tp->prog.hdr;
+    a.fixed_len = fixed_len;
+    a.bitmap = d_bitmap;
+    a.start = d_start;
+    a.end = d_end;
+    a.packed = d_packed;
+    return a;
+}
+
 // d_packed (OP_FIND, needle_find_packed16_dev): a row's start / end go there as one dword, stored by the scan kernel itself;
 // d_start / d_end are not used.  The paths for few long rows (stripes) and the opt-in two-row-set kernel keep their int32
 // arrays: they run into scratch and one pack pass follows.
@@ -616,21 +638,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
             ok = tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || lengths8 || p->t.fixed_len >= 0);
         }
         if (ok) {
-            ScanArgs a;
-            memset(&a, 0, sizeof(a));
-            a.rows = (const uint8_t *)v->rows;
-            a.n_rows = v->n_rows;
-            a.stride_bytes = v->row_stride;             // (in CHARS: launch_ngram with char_width 2)
-            a.total_bytes = a.n_rows * a.stride_bytes;
-            a.row_len = v->row_len;
-            a.lengths = v->lengths;
-            a.prog = tp->d_blob;
-            a.hdr = tp->prog.hdr;
-            a.fixed_len = op == OP_FIND ? p->t.fixed_len : -1;
-            a.bitmap = d_bitmap;
-            a.start = d_start;
-            a.end = d_end;
-            a.packed = d_packed;
+            const ScanArgs a = filter_scan_args(v, v->row_stride /* chars */, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed);
             if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
                 HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream, 2));
                 HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
@@ -665,21 +673,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
         rc = get_program(p, which, 1, 9, &tp, nullptr);
         if (rc) return rc;
         if (tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0)) {
-            ScanArgs a;
-            memset(&a, 0, sizeof(a));
-            a.rows = (const uint8_t *)v->rows;
-            a.n_rows = v->n_rows;
-            a.stride_bytes = v->row_stride * v->char_width;
-            a.total_bytes = a.n_rows * a.stride_bytes;
-            a.row_len = v->row_len;
-            a.lengths = v->lengths;
-            a.prog = tp->d_blob;
-            a.hdr = tp->prog.hdr;
-            a.fixed_len = op == OP_FIND ? p->t.fixed_len : -1;
-            a.bitmap = d_bitmap;
-            a.start = d_start;
-            a.end = d_end;
-            a.packed = d_packed;
+            const ScanArgs a = filter_scan_args(v, v->row_stride, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed);
             if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
                 HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream));
                 HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
@@ -1624,17 +1618,8 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
             if (rc) return rc;
         }
         if (sp && sp->d_ng && sp->prog.ng.p.on && ngram_find_all_lds_bytes(sp->prog.hdr, sp->prog.ng.p)) {
-            ScanArgs a;
-            memset(&a, 0, sizeof(a));
-            a.rows = (const uint8_t *)v->rows;
-            a.n_rows = v->n_rows;
-            a.stride_bytes = v->row_stride; // (UTF-16 rows: in CHARS -- launch_ngram_find_all with char_width 2)
-            a.total_bytes = a.n_rows * a.stride_bytes;
-            a.row_len = v->row_len;
-            a.lengths = v->lengths;
-            a.prog = sp->d_blob;
-            a.hdr = sp->prog.hdr;
-            a.fixed_len = p->t.fixed_len;
+            // (UTF-16 rows: the stride in CHARS -- launch_ngram_find_all with char_width 2)
+            const ScanArgs a = filter_scan_args(v, v->row_stride, sp, p->t.fixed_len, nullptr, nullptr, nullptr, nullptr);
             if (ngram_shape_ok(a) && ngram_watch_allows(p, sp)) {
                 int32_t *d_more = nullptr;
                 HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
