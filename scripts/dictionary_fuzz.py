@@ -1,6 +1,6 @@
 """Random DICTIONARIES against the oracle: keyword unions big enough for the compressed automaton (mode 6) and its lengths program, with
 keywords that are prefixes / suffixes / infixes of one another (states with a match pending that live on: END records, D_L rows as
-default rows), planted at row ends and cut by ragged lengths.  python scripts/dictionary_fuzz.py <seed0> <n>
+default rows), planted at row ends and cut by ragged lengths.  python scripts/dictionary_fuzz.py <seed0> <n>   (FUZZ_MIN_LEN=5 | 7: dictionaries the n-gram filter takes; FUZZ_UTF16=1: the rows as UTF-16)
 (child processes: NEEDLE_MAX_PROG_LDS is read once per process)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,8 +50,15 @@ if fuzz_min:  # near misses: a keyword's tail behind a wrong first char (passes 
         w = np.frombuffer(words[nr.integers(len(words))].encode(), dtype=np.uint8).copy()
         w[0] = ord(alpha[nr.integers(len(alpha))])
         at = int(nr.integers(0, width - len(w) + 1)); rows[r, at:at + len(w)] = w
+utf16 = int(os.environ.get("FUZZ_UTF16", "0"))  # the same rows as UTF-16 (Java's strings), chars above 0xFF sprinkled over text and keywords:
+if utf16:                                        # dictionaries with a filter take the byte program's filter kernel, the text narrowed on the fly
+    rows = rows.astype(np.uint16)
+    m = nr.random(rows.shape) < 0.01
+    rows[m] = nr.integers(0x0100, 0xFFFF, size=int(m.sum()), dtype=np.uint16)
+    rows[nr.random(rows.shape) < 0.01] |= 0x0100
+    rows[nr.random(rows.shape) < 0.002] = 0x00FF
 lens = nr.integers(0, width + 1, n).astype(np.uint32)
-t = torch.from_numpy(rows).cuda()
+t = torch.from_numpy(rows.view(np.int16) if utf16 else rows).cuda()
 tl = torch.from_numpy(lens.astype(np.int32)).cuda()
 for l, dl in ((None, None), (lens, tl)):
     fw, fs, fe = p.find_batch(t, dl)
@@ -80,8 +87,8 @@ for l, dl in ((None, None), (lens, tl)):
         assert cc[i] == len(w), ("count pass", seed, i)
 pf = p.prefilter_info("forwards")
 ft = p.find_all_transducer(1)  # (the budget is the process's: a transducer reported here is the one find-all walked in lock-step)
-print("DICT-OK seed %d: %d keywords over %d letters, %d states, mode %d, lengths form %d, n-gram filter %s, find-all %s, %d of %d rows match" % (
-    seed, len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"],
+print("DICT-OK seed %d%s: %d keywords over %d letters, %d states, mode %d, lengths form %d, n-gram filter %s, find-all %s, %d of %d rows match" % (
+    seed, " (UTF-16 rows, %d filter launches)" % p.prefilter_state("forwards")["filter_launches"] if utf16 else "", len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"],
     ("stride %d run-up %d%s" % (pf["stride"], pf["warm"], " +level 2" if pf["on2"] else "")) if pf["on"] else "off",
     ("lock-step (%d states)" % ft["n_states"]) if ft is not None and not pf["on"] else "filter form" if pf["on"] else "one-pass kernel", int(of.sum()), n))
 '''
