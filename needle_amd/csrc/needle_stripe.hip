@@ -131,6 +131,132 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void stripe_kernel(const Strip
     const uint32_t kIdentFn = fl.ident;
     const bool one_per_row = FIND && a.cand_stripe != nullptr; // (pass 2: the row's candidate stripe only)
     const uint64_t total = one_per_row ? a.n_rows : a.n_rows * a.spr;
+    if constexpr (!FIND) {
+        // ---- pass 1, software-pipelined (round 5).  The loop below it loads a stripe and waits for it at once: every iteration a full
+        // memory latency, hidden by the CU's other 15 waves only (1000 x 1 MiB rows: 3.8 TB/s).  Here the NEXT stripe of this wave is
+        // in flight while the current one is walked and scanned.  As in short_kernel (below): nothing is pending at the loop head, a
+        // stripe's loads are ALWAYS four (addresses clamped into the row's stride -- a conditional load makes the compiler's vmcnt
+        // conservative at the join), its row length travels with it, and it is collected before this iteration's stores enter the queue.
+        const uint64_t step = (uint64_t)gridDim.x * kWavesPerBlock;
+        uint64_t it = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+        if (it >= total) return;
+        const bool has_len = a.lengths != nullptr;
+        struct Stripe { uint64_t row; uint32_t s; };
+        auto place = [&](uint64_t v) __attribute__((always_inline)) -> Stripe {
+            Stripe st;
+            st.row = v / a.spr;
+            st.s = (uint32_t)(v - st.row * a.spr);
+            return st;
+        };
+        auto fetch = [&](const Stripe &st, u32x4 (&d)[4], uint32_t &d_len) __attribute__((always_inline)) {
+            const uint64_t off = (uint64_t)st.s * kStripeBytes + (uint64_t)lane * 64u;
+            const uint8_t *base = a.rows + st.row * a.stride_bytes;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint64_t o = off + 16u * j;
+                o = o + 16u <= a.stride_bytes ? o : a.stride_bytes - 16u; // (past the stride: the row's last 16 bytes, masked by n_valid)
+                d[j] = *(const u32x4 *)(base + o);
+            }
+            if (has_len) d_len = a.lengths[st.row];
+        };
+        auto landed = [&](u32x4 (&d)[4], uint32_t &d_len) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d_len));
+        };
+        Stripe cur_st = place(it);
+        u32x4 nxt[4];
+        uint32_t nxt_len = a.row_len;
+        fetch(cur_st, nxt, nxt_len);
+        landed(nxt, nxt_len);
+        for (;;) {
+            u32x4 d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = nxt[j];
+            const uint32_t len = nxt_len;
+            const uint64_t v = it;
+            const Stripe me = cur_st;
+            const uint64_t itn = it + step;
+            const bool more = itn < total;
+            cur_st = place(more ? itn : it);
+            fetch(cur_st, nxt, nxt_len); // (the last iteration re-reads its own stripe: unused)
+            const uint64_t first = (uint64_t)me.s * (kStripeBytes / CW) + (uint64_t)lane * CPL; // this lane's first char
+            const uint32_t n_valid = first >= len ? 0u : (uint32_t)(len - first < (uint64_t)CPL ? len - first : CPL);
+            const bool beyond = (uint64_t)me.s * (kStripeBytes / CW) >= len; // stripe past the row's end (wave-uniform)
+            uint32_t incl = kIdentFn, bits = 0;
+            if (!beyond) {
+                uint32_t g[NS], seen[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) g[i] = fl.off[i], seen[i] = 0;
+                const bool full = __ballot(n_valid != (uint32_t)CPL) == 0ull;
+                auto walk_all = [&](auto per_char) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t w[4] = {d[j][0], d[j][1], d[j][2], d[j][3]};
+                        uint32_t f[16 / CW];
+#define NEEDLE_F(D, K) f[(D) * (4 / CW) + (K)] = lookup<MODE_PACK, CW, false, K>(wk, w[D], true, false);
+#pragma unroll
+                        for (int dd = 0; dd < 4; ++dd) {
+                            NEEDLE_F(dd, 0)
+                            NEEDLE_F(dd, 1)
+                            if (CW == 1) {
+                                NEEDLE_F(dd, 2)
+                                NEEDLE_F(dd, 3)
+                            }
+                        }
+#undef NEEDLE_F
+                        lds_fence();
+#pragma unroll
+                        for (int i = 0; i < 16 / CW; ++i) per_char(j * (16 / CW) + i, f[i]);
+                    }
+                };
+                if (full) {
+                    walk_all([&](int, uint32_t f) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int i = 1; i < NS; ++i) {
+                            g[i] = __builtin_amdgcn_ubfe(f, g[i], 5);
+                            if (CAND) seen[i] |= g[i];
+                        }
+                    });
+                } else {
+                    walk_all([&](int c, uint32_t f) __attribute__((always_inline)) {
+                        const bool in_row = (uint32_t)c < n_valid;
+                        f = in_row ? f : kIdentFn;
+#pragma unroll
+                        for (int i = 1; i < NS; ++i) {
+                            g[i] = __builtin_amdgcn_ubfe(f, g[i], 5);
+                            if (CAND) seen[i] |= in_row ? g[i] : 0u;
+                        }
+                    });
+                }
+                uint32_t fn = 0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) fn |= g[i] << fl.off[i];
+                incl = fn; // ordered inclusive scan over the lanes: after step d lane l holds the function of lanes l-2d+1 .. l
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                    const uint32_t left = (uint32_t)__shfl_up((int)incl, dlt);
+                    if (lane >= dlt) incl = compose_fn(fl, left, incl);
+                }
+                if (CAND) {
+                    uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
+                    if (lane == 0) excl = kIdentFn;
+#pragma unroll
+                    for (int i = 1; i < NS; ++i) {
+                        const uint32_t e = __builtin_amdgcn_ubfe(excl, fl.off[i], 5); // this lane's entry state when the stripe is entered in state i
+                        uint32_t sv = 0;
+#pragma unroll
+                        for (int k = 1; k < NS; ++k) sv = e == fl.off[k] ? seen[k] : sv; // (the sink: nothing seen)
+                        if (__ballot((sv & 1u) != 0u) != 0ull) bits |= 1u << i;
+                    }
+                }
+            }
+            landed(nxt, nxt_len); // the next stripe, before this one's stores are queued
+            if (lane == 63) a.fn[v] = incl; // (a stripe past its row's end: the identity -- every lane holds it then)
+            if (CAND && lane == 0) a.cand[v] = bits;
+            if (!more) break;
+            it = itn;
+        }
+        return;
+    }
     for (uint64_t it = (uint64_t)blockIdx.x * kWavesPerBlock + wave; it < total; it += (uint64_t)gridDim.x * kWavesPerBlock) {
         uint64_t v = it;
         if (one_per_row) {
