@@ -902,7 +902,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
                         }
                 }
                 const uint8_t *rowp = a.rows + (row_ok ? my_row : 0) * a.stride_bytes;
-                const int32_t sb = backward_walk<CW>(a, res, last, cursor, slot, 0u, (uint32_t)a.stride_bytes, 0u, rowp);
+                // (rows of one piece: rounds of 4 chars -- what ends in 16 bytes is short, and half a round's lookups and chain go)
+                const int32_t sb = n_pieces == 1u ? backward_walk<CW, false, 4>(a, res, last, cursor, slot, 0u, (uint32_t)a.stride_bytes, 0u, rowp)
+                                                  : backward_walk<CW>(a, res, last, cursor, slot, 0u, (uint32_t)a.stride_bytes, 0u, rowp);
                 s = res ? sb : -1;
             } else {
                 // no room for the text slots behind the program: the same walk with an empty window, the text out of L2

@@ -533,7 +533,7 @@ __device__ __forceinline__ BackwardHdr backward_hdr() {
     return h;
 }
 
-template <int CW, bool SWZ = false>
+template <int CW, bool SWZ = false, int STEPS = 8> // STEPS chars per round (4: rows of one 16-byte piece -- their matches are short)
 __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, int32_t en, int32_t bound, uint32_t win_addr, uint32_t win_b0,
                                                  uint32_t win_bytes, uint32_t swz16, const uint8_t *rowp) {
     const BackwardHdr h = backward_hdr();
@@ -546,22 +546,22 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
         const int32_t room = idx0 - bound;                     // chars idx0 .. idx0 - room may be read
         const bool live = bs != 0u && room >= 0;
         if (__ballot(live) == 0ull) break;
-        // ---- the round's text: chars idx0 - 7 .. idx0
+        // ---- the round's text: chars idx0 - (STEPS - 1) .. idx0
         const int32_t rel0 = idx0 * CW - (int32_t)win_b0;      // window offset of char idx0
-        const int32_t lo = idx0 - 7 > bound ? idx0 - 7 : bound; // the lowest char this lane can need
+        const int32_t lo = idx0 - (STEPS - 1) > bound ? idx0 - (STEPS - 1) : bound; // the lowest char this lane can need
         const bool from_mem = live && ((uint32_t)rel0 >= win_bytes || lo * CW < (int32_t)win_b0);
-        uint32_t cs[8];
+        uint32_t cs[STEPS];
         if (!SWZ) {
             // one address per lane, the chars at immediate offsets (a lane outside its window reads the window's start: unused)
             // (a lane that is not walking reads LDS offset 0: all of them the same chars, so that their map / table lookups below are
             // one broadcast address instead of 64 scattered ones -- C5: 70 % of the lanes)
-            uint32_t rd = win_addr + ((uint32_t)rel0 < win_bytes ? (uint32_t)rel0 : 7u * CW) - 7u * CW;
+            uint32_t rd = win_addr + ((uint32_t)rel0 < win_bytes ? (uint32_t)rel0 : (uint32_t)(STEPS - 1) * CW) - (uint32_t)(STEPS - 1) * CW;
             rd = live ? rd : 0u;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cs[k] = (CW == 1) ? lds_u8(rd + (uint32_t)(7 - k)) : lds_u16(rd + (uint32_t)(7 - k) * 2u);
+            for (int k = 0; k < STEPS; ++k) cs[k] = (CW == 1) ? lds_u8(rd + (uint32_t)(STEPS - 1 - k)) : lds_u16(rd + (uint32_t)(STEPS - 1 - k) * 2u);
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < STEPS; ++k) {
                 const uint32_t rel = (uint32_t)(rel0 - k * CW);
                 const uint32_t ad = live ? win_addr + ((rel < win_bytes ? rel : 0u) ^ swz16) : 0u;
                 cs[k] = (CW == 1) ? lds_u8(ad) : lds_u16(ad);
@@ -570,7 +570,9 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
         if (__ballot(from_mem) != 0ull) { // text outside the window (rare): waited for inside the branch, as in walk_tile
             uint32_t m[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = STEPS; k < 8; ++k) m[k] = 0;
+#pragma unroll
+            for (int k = 0; k < STEPS; ++k) {
                 const int32_t p = idx0 - k;
                 m[k] = cs[k];
                 if (live && k <= room && (uint32_t)(p * CW - (int32_t)win_b0) >= win_bytes)
@@ -578,13 +580,13 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
             }
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cs[k] = m[k];
+            for (int k = 0; k < STEPS; ++k) cs[k] = m[k];
         }
-        uint32_t last_k = 8u; // the round's last accepting step (8: none)
+        uint32_t last_k = (uint32_t)STEPS; // the round's last accepting step (STEPS: none)
         if (h.off_bpack) { // wave-uniform: packed backward automaton -- 8 independent char -> F lookups, then the chain
-            uint32_t fb[8];
+            uint32_t fb[STEPS];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < STEPS; ++k) {
                 if (CW == 1) {
                     fb[k] = lds_u32(h.off_bpack + (cs[k] << 2));
                 } else {
@@ -593,7 +595,7 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < STEPS; ++k) {
                 uint32_t nb = __builtin_amdgcn_ubfe(fb[k], bs, 5);
                 nb = room >= k ? nb : 0u;
                 last_k = nb >= bacc ? (uint32_t)k : last_k;
@@ -601,14 +603,14 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
             }
         } else {
             // the backward automaton's char -> column maps, at absolute LDS addresses: all eight ahead of the dependent chain
-            uint32_t col[8];
+            uint32_t col[STEPS];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < STEPS; ++k) {
                 if (CW == 1) col[k] = lds_u8(h.off_bcmap + cs[k]);
                 else col[k] = lds_u8(h.off_bpages + ((lds_u8(h.off_bptab + (cs[k] >> 8)) << 8) | (cs[k] & 255u)));
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < STEPS; ++k) {
                 if (bs != 0u) { // (the lanes that are done stay out of the LDS)
                     uint32_t nb;
                     if (h.off_bsp_bm) { // wave-uniform: popcount-compressed rows in LDS (needle_device.h)
@@ -628,8 +630,8 @@ __device__ __forceinline__ int32_t backward_walk(const ScanArgs &a, bool act, in
                 }
             }
         }
-        lastb = last_k < 8u ? idx0 - (int32_t)last_k : lastb;
-        idx0 = idx0 - 8 > -1 ? idx0 - 8 : -1; // (lanes that are done do not run away below their rows)
+        lastb = last_k < (uint32_t)STEPS ? idx0 - (int32_t)last_k : lastb;
+        idx0 = idx0 - STEPS > -1 ? idx0 - STEPS : -1; // (lanes that are done do not run away below their rows)
     }
     return lastb;
 }
