@@ -39,11 +39,11 @@ hipError_t launch_dict(int op, const ScanArgs &a, int n_cus, hipStream_t stream)
 bool ngram_shape_ok(const ScanArgs &a);
 size_t ngram_lds_bytes(const ProgHeader &h, const NgramParams &ng);
 hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
-                        int char_width = 1);
+                        int char_width = 1, int page = 0, int sub = 0xFF);
 size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng);
 hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
                                  int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
-                                 hipStream_t stream, int char_width = 1);
+                                 hipStream_t stream, int char_width = 1, int page = 0, int sub = 0xFF);
 int ngram_level(); // needle_lower.cpp (NEEDLE_PREFILTER)
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
@@ -178,6 +178,16 @@ struct needle_pattern {
     } pf_cache[4];
     std::mutex pf_mu;
     std::atomic<int> pf_mode{0}; // needle_pattern_set_prefilter: 0 auto (the flood watch decides), 1 on (never suspended), 2 off (never used)
+    // UTF-16 rows behind a BYTE program (utf16_route): the pattern's one page and the byte that stands for every char outside it;
+    // the tables rebased to that page (page_tables: what the byte programs of a page other than 0 are lowered from)
+    std::mutex u16_mu;
+    int u16_state = 0, u16_page = -1, u16_sub = 0; // state 0: not looked at yet
+    struct PageTables {
+        RefTables t;
+        bool have_ml = false;
+        MatchLengths ml;
+    };
+    std::map<int, PageTables> page_tables; // (under `mu`)
     std::mutex ml_mu;       // guards the one-time match-length analysis only: scans of programs that exist already do not wait for it
     int ml_state = 0;       // 0: not analysed yet, 1: find-all can report starts as end - length (ml), -1: it cannot
     MatchLengths ml;
@@ -216,16 +226,39 @@ static const MatchLengths *pattern_ml(const needle_pattern *cp) {
 static int get_program(needle_pattern *p, int which, int cw, int variant, const DevProgram **out, int *n_cus) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    // cw = 1 | page << 8: the BYTE program of the pattern rebased to one page of the BMP (UTF-16 rows narrowed on the fly: utf16_route)
+    const int page = cw >> 8, cw_key = cw;
+    cw &= 0xFF;
     const bool wants_ml = variant == 6 || variant == 7 || variant == 8 || (variant == 9 && which == W_FORWARDS && p->t.fixed_len < 0);
     const MatchLengths *ml67 = wants_ml ? pattern_ml(p) : nullptr; // (before p->mu: see ml_mu)
     std::lock_guard<std::mutex> lk(p->mu);
+    const RefTables *tt = &p->t;
+    if (page) { // chars page << 8 | b become bytes b: the class map's page in front, every automaton's maxChar moved along
+        auto pit = p->page_tables.find(page);
+        if (pit == p->page_tables.end()) {
+            needle_pattern::PageTables pt;
+            pt.t = p->t;
+            for (int b = 0; b < 256; ++b) pt.t.class_map[b] = p->t.class_map[(size_t)(page << 8) | b];
+            auto rebase = [&](int32_t mc) { const int32_t r = mc - (page << 8); return r > 255 ? 255 : (r < -1 ? -1 : r); };
+            for (int w = 0; w < 4; ++w) pt.t.dfa[w].max_char = rebase(p->t.dfa[w].max_char);
+            pit = p->page_tables.emplace(page, std::move(pt)).first;
+        }
+        if (ml67 && !pit->second.have_ml) {
+            pit->second.ml = *ml67;
+            const int32_t r = ml67->dfa.max_char - (page << 8);
+            pit->second.ml.dfa.max_char = r > 255 ? 255 : (r < -1 ? -1 : r);
+            pit->second.have_ml = true;
+        }
+        tt = &pit->second.t;
+        if (ml67) ml67 = &pit->second.ml;
+    }
     if (!p->cus.count(dev)) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         p->cus[dev] = prop.multiProcessorCount;
     }
     if (n_cus) *n_cus = p->cus[dev];
-    auto key = std::make_tuple(dev, which, cw, variant);
+    auto key = std::make_tuple(dev, which, cw_key, variant);
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
@@ -234,7 +267,7 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
                 *out = nullptr;
                 return NEEDLE_OK;
             }
-            dp.prog = lower_filter_hbm(p->t, (Which)which, ml67);
+            dp.prog = lower_filter_hbm(*tt, (Which)which, ml67);
             if (dp.prog.blob.empty() || !dp.prog.ng.p.on) { // (no filter: the ordinary program is what runs)
                 p->cache.emplace(key, DevProgram());
                 *out = nullptr;
@@ -247,15 +280,15 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
                 *out = nullptr;
                 return NEEDLE_OK;
             }
-            dp.prog = variant == 8 ? lower_find_all_transducer(p->t, *ml67, cw, max_prog_lds())
-                                   : lower_match_lengths(p->t, *ml67, cw, max_prog_lds(), variant == 6);
+            dp.prog = variant == 8 ? lower_find_all_transducer(*tt, *ml67, cw, max_prog_lds())
+                                   : lower_match_lengths(*tt, *ml67, cw, max_prog_lds(), variant == 6);
             if (dp.prog.blob.empty()) { // (does not fit the LDS as a plain table: the ordinary program with backward walks)
                 p->cache.emplace(key, DevProgram());
                 *out = nullptr;
                 return NEEDLE_OK;
             }
         } else
-        dp.prog = lower(p->t, (Which)which, cw, variant == 3 ? 0 : max_prog_lds(), variant == 1, variant == 2 || variant == 5, variant >= 4);
+        dp.prog = lower(*tt, (Which)which, cw, variant == 3 ? 0 : max_prog_lds(), variant == 1, variant == 2 || variant == 5, variant >= 4);
         HIP_TRY(hipMalloc((void **)&dp.d_blob, dp.prog.blob.size()));
         if (hipError_t ce = hipMemcpy(dp.d_blob, dp.prog.blob.data(), dp.prog.blob.size(), hipMemcpyHostToDevice); ce != hipSuccess) {
             (void)hipFree(dp.d_blob);
@@ -422,12 +455,88 @@ static hipError_t ngram_watch_after_launch(const DevProgram *fp, hipStream_t str
     return e;
 }
 
-// UTF-16 rows behind the BYTE program's n-gram filter (needle_ngram.h narrow16): patterns whose chars all lie below 0xFF -- the anchored
-// automaton's maxChar is the pattern's own largest char (the searching automata loop on every char) -- so that a char above 0xFE is "beyond
-// maxChar" exactly as byte 0xFF is for the program lowered for 8-bit rows.  NEEDLE_PREFILTER_UTF16=0: never.
-static bool utf16_filter_ok(const needle_pattern *p) {
+// UTF-16 rows behind a BYTE program's n-gram filter (needle_ngram.h narrow16).  The pattern must live on ONE page of the BMP: every char
+// outside page P shares one class ("other": in no range of the pattern -- the class with the most chars), and some char P << 8 | sub of the
+// page is of that class too.  Then a char outside the page behaves exactly as byte `sub` does in the program lowered from the tables
+// REBASED to the page (get_program, cw = 1 | P << 8; page 0: the ordinary 8-bit program) -- the searching automata the filter runs have
+// maxChar 0xFFFF, so "beyond maxChar" never comes into it.  ASCII / Latin-1 dictionaries: page 0, sub 0xFF; Cyrillic: page 4; ...
+// NEEDLE_PREFILTER_UTF16=0: never.
+struct Utf16Route {
+    int page = -1, sub = 0;
+};
+static Utf16Route utf16_route(const needle_pattern *cp) {
     static const bool off = getenv("NEEDLE_PREFILTER_UTF16") && atoi(getenv("NEEDLE_PREFILTER_UTF16")) == 0;
-    return !off && p->t.dfa[W_MATCHES].max_char < 0xFF;
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    Utf16Route r;
+    if (off) return r;
+    std::lock_guard<std::mutex> lk(p->u16_mu);
+    if (p->u16_state == 0) {
+        p->u16_state = 1;
+        const std::vector<uint8_t> &cm = p->t.class_map;
+        if (cm.size() == 65536 && p->t.dfa[W_CONTAINED_IN].max_char == 0xFFFF && p->t.dfa[W_FORWARDS].max_char == 0xFFFF) {
+            // classes with the same column in all four automata are one class here (the reference numbers every gap between two of the
+            // pattern's ranges separately: "below 'a'" and "above 'z'" are two classes with identical columns)
+            const int N = p->t.stride;
+            std::vector<int> canon(256, 0);
+            {
+                std::vector<uint64_t> sig((size_t)N, 1469598103934665603ull);
+                for (int w = 0; w < 4; ++w) {
+                    const RefDfa &d = p->t.dfa[w];
+                    for (int k = 0; k < N; ++k) {
+                        uint64_t h = sig[(size_t)k];
+                        for (int32_t st = 0; st < d.n_states; ++st) h = (h ^ (uint64_t)(uint16_t)d.table[(size_t)st * N + k]) * 1099511628211ull;
+                        sig[(size_t)k] = h * 31u + (uint64_t)w;
+                    }
+                }
+                for (int k = 0; k < N; ++k) {
+                    canon[k] = k;
+                    for (int j = 0; j < k; ++j) {
+                        if (sig[(size_t)j] != sig[(size_t)k]) continue;
+                        bool same = true; // (the hash only nominates: compared entry by entry)
+                        for (int w = 0; w < 4 && same; ++w) {
+                            const RefDfa &d = p->t.dfa[w];
+                            for (int32_t st = 0; st < d.n_states && same; ++st) same = d.table[(size_t)st * N + j] == d.table[(size_t)st * N + k];
+                        }
+                        if (same) {
+                            canon[k] = canon[j];
+                            break;
+                        }
+                    }
+                }
+            }
+            // (a char beyond an automaton's maxChar takes the `c > maxChar` exit there: only classes whose column is dead in that
+            // automaton reach beyond it, so class equality covers it -- checked below for the chars the rule relies on)
+            uint32_t n_of[256] = {0};
+            for (uint8_t c : cm) ++n_of[canon[c]];
+            int other = 0;
+            for (int k = 1; k < 256; ++k)
+                if (n_of[k] > n_of[other]) other = k;
+            int page = -1;
+            bool one = true;
+            for (int c = 0; c < 65536 && one; ++c)
+                if (canon[cm[c]] != other) {
+                    if (page < 0) page = c >> 8;
+                    else one = page == (c >> 8);
+                }
+            // "dead beyond maxChar" must be what the other class does anyway in the automata that have a maxChar below 0xFFFF
+            for (int w = 0; w < 4 && one; ++w) {
+                const RefDfa &d = p->t.dfa[w];
+                if (d.max_char >= 0xFFFF) continue;
+                for (int k = 0; k < N && one; ++k)
+                    if (canon[k] == other)
+                        for (int32_t st = 0; st < d.n_states && one; ++st) one = d.table[(size_t)st * N + k] < 0;
+            }
+            if (one && page >= 0) {
+                for (int b = 255; b >= 0; --b)
+                    if (canon[cm[(size_t)(page << 8) | b]] == other) {
+                        p->u16_page = page, p->u16_sub = b;
+                        break;
+                    }
+            }
+        }
+    }
+    r.page = p->u16_page, r.sub = p->u16_sub;
+    return r;
 }
 
 // NEEDLE_FIND_LENGTHS: 0 = find() always by forward + backward walks, 1 (default) = the "lengths" automaton where the ordinary
@@ -617,21 +726,23 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // n-gram filter, the text narrowed as it is loaded (needle_ngram.h narrow16; a char above 0xFE is "beyond maxChar", the reference's
     // `c > maxChar` exit, exactly as byte 0xFF is for the byte program).  The program is chosen as for 8-bit rows below; whatever rules the
     // filter out there (no filter for this automaton, the shape, the flood watch) leaves these rows to the UTF-16 kernels.
-    if (v->char_width == 2 && op != OP_MATCHES && !d_from && !d_end_state && !no_backward && ngram_level() > 0 && dict_env == 0 && utf16_filter_ok(p) &&
+    const Utf16Route u16 = v->char_width == 2 ? utf16_route(p) : Utf16Route();
+    if (v->char_width == 2 && op != OP_MATCHES && !d_from && !d_end_state && !no_backward && ngram_level() > 0 && dict_env == 0 && u16.page >= 0 &&
         v->row_stride * 2 < 8 * (uint64_t)kStripeBytes) {
         const DevProgram *tp = nullptr;
-        rc = get_program(p, which, 1, need_backward ? 2 : 0, &tp, &n_cus);
+        const int cw8 = 1 | (u16.page << 8); // the byte program of the pattern's page
+        rc = get_program(p, which, cw8, need_backward ? 2 : 0, &tp, &n_cus);
         if (rc) return rc;
         bool ok = false;
         if (tp->prog.hdr.mode == MODE_HYBRID || tp->prog.hdr.mode == MODE_GLOBAL) {
-            rc = get_program(p, which, 1, 9, &tp, nullptr);
+            rc = get_program(p, which, cw8, 9, &tp, nullptr);
             if (rc) return rc;
             ok = tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0);
         } else {
             bool lengths8 = false;
             if (need_backward && find_lengths_for(tp->prog.hdr.mode)) {
                 const DevProgram *lp = nullptr;
-                rc = get_program(p, W_FORWARDS, 1, 7, &lp, nullptr);
+                rc = get_program(p, W_FORWARDS, cw8, 7, &lp, nullptr);
                 if (rc) return rc;
                 if (lp && !(tp->prog.hdr.mode == MODE_PAIR && lp->prog.hdr.mode != MODE_PAIR)) tp = lp, lengths8 = true;
             }
@@ -640,7 +751,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
         if (ok) {
             const ScanArgs a = filter_scan_args(v, v->row_stride /* chars */, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed);
             if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
-                HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream, 2));
+                HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream, 2, u16.page, u16.sub));
                 HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
                 return NEEDLE_OK;
             }
@@ -1607,14 +1718,16 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     // the counting pass and the compact filing alike).  NEEDLE_FIND_ALL_FILTER=0: off (A/B, tests).
     static const bool fa_filter = !(getenv("NEEDLE_FIND_ALL_FILTER") && atoi(getenv("NEEDLE_FIND_ALL_FILTER")) == 0);
     // (UTF-16 rows of a pattern below 0xFF: the same byte programs, the text narrowed as it is loaded -- utf16_filter_ok)
-    if (fa_filter && (count_only || d_offsets || slots) && (v->char_width == 1 || (v->char_width == 2 && utf16_filter_ok(p))) && ngram_level() > 0 &&
+    const Utf16Route u16 = v->char_width == 2 ? utf16_route(p) : Utf16Route();
+    if (fa_filter && (count_only || d_offsets || slots) && (v->char_width == 1 || (v->char_width == 2 && u16.page >= 0)) && ngram_level() > 0 &&
         (p->t.fixed_len >= 0 || find_lengths_for(MODE_SPARSE))) {
         const DevProgram *sp = nullptr;
         int cus = 0;
-        rc = get_program(p, W_FORWARDS, 1, p->t.fixed_len >= 0 ? 0 : 7, &sp, &cus);
+        const int cw8 = 1 | ((v->char_width == 2 ? u16.page : 0) << 8);
+        rc = get_program(p, W_FORWARDS, cw8, p->t.fixed_len >= 0 ? 0 : 7, &sp, &cus);
         if (rc) return rc;
         if (!(sp && sp->d_ng && sp->prog.ng.p.on)) { // an automaton that fits the LDS in no form: the filter with its walks out of HBM / L2
-            rc = get_program(p, W_FORWARDS, 1, 9, &sp, &cus);
+            rc = get_program(p, W_FORWARDS, cw8, 9, &sp, &cus);
             if (rc) return rc;
         }
         if (sp && sp->d_ng && sp->prog.ng.p.on && ngram_find_all_lds_bytes(sp->prog.hdr, sp->prog.ng.p)) {
@@ -1624,7 +1737,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
                 int32_t *d_more = nullptr;
                 HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
                 hipError_t e = hipMemsetAsync(d_more, 0, 4, stream);
-                if (e == hipSuccess) e = launch_ngram_find_all(a, sp->prog.ng.p, sp->d_ng, sp->d_ng_stats, slots, d_counts, d_start, d_end, d_packed, d_more, d_offsets, count_only, cus, stream, (int)v->char_width);
+                if (e == hipSuccess) e = launch_ngram_find_all(a, sp->prog.ng.p, sp->d_ng, sp->d_ng_stats, slots, d_counts, d_start, d_end, d_packed, d_more, d_offsets, count_only, cus, stream, (int)v->char_width, u16.page > 0 ? u16.page : 0, v->char_width == 2 ? u16.sub : 0xFF);
                 if (e == hipSuccess) e = ngram_watch_after_launch(sp, stream);
                 int32_t m = 0;
                 if (e == hipSuccess && more) {

@@ -152,29 +152,37 @@ __device__ __forceinline__ uint32_t ngram_piece(uint32_t log, uint32_t pw, uint3
     return log;
 }
 
-// ---- UTF-16 rows (Java's native strings) behind the byte filter.  Where every char of the pattern is below 0xFF (ASCII / Latin-1
-// dictionaries: DFA.maxChar < 255), a char >= 0xFF behaves like byte 0xFF: beyond maxChar, the reference's `c > maxChar` exit
-// (DFAClassBuilder.java:440, :565).  So the filter kernel NARROWS the text as it loads it -- 16 chars = 32 bytes -> 16 bytes, the
-// low bytes picked by four v_perm_b32 -- and everything behind the load (windows, bitmaps, queues, the byte program's walks, positions in
-// chars) is the 8-bit kernel.  Chars above 0xFF become 0xFF: the high bytes are or-ed together (v_or3_b32) and tested once per 16 chars;
-// the per-byte patch runs only for the loads where some lane holds one.
+// ---- UTF-16 rows (Java's strings) behind the byte filter.  Where the pattern lives on ONE page P of the BMP -- every char outside the
+// page is of the pattern's "other" class, and so is the page's char P << 8 | sub (needle_api.cpp utf16_route) -- a char outside the page
+// behaves like byte `sub` of the program lowered from the tables rebased to the page.  So the filter kernel NARROWS the text as it loads
+// it -- 16 chars = 32 bytes -> 16 bytes, the low bytes picked by four v_perm_b32 -- and everything behind the load (windows, bitmaps,
+// queues, the byte program's walks, positions in chars) is the 8-bit kernel.  Chars outside the page become `sub`.  Page 0 (ASCII /
+// Latin-1 patterns: sub = 0xFF, "beyond maxChar" -- DFAClassBuilder.java:440, :565 -- for the pattern as for its byte program): the high
+// bytes are or-ed together (v_or3_b32) and tested once per 16 chars, the per-byte patch runs only for the loads where some lane holds a
+// char above 0xFF.  Other pages (Cyrillic, Greek, Hebrew, ...: their text is full of spaces and digits of page 0): always the patch.
+// page4 / sub4: the page's / the substitute's byte in all four bytes of a dword.
 __device__ __forceinline__ uint32_t narrow_pair(uint32_t x, uint32_t y) { // chars {x.lo16, x.hi16, y.lo16, y.hi16} -> their low bytes
     return __builtin_amdgcn_perm(y, x, 0x06040200u);
 }
-__device__ __forceinline__ uint32_t narrow_pair_patched(uint32_t x, uint32_t y) { // ... chars above 0xFF -> 0xFF
-    const uint32_t lo = __builtin_amdgcn_perm(y, x, 0x06040200u), hi = __builtin_amdgcn_perm(y, x, 0x07050301u);
-    uint32_t m = (((hi & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | hi) & 0x80808080u; // bit 7 of every byte whose high byte is not zero
+__device__ __forceinline__ uint32_t narrow_pair_patched(uint32_t x, uint32_t y, uint32_t page4 = 0u, uint32_t sub4 = 0xFFFFFFFFu) { // ... chars outside the page -> sub
+    const uint32_t lo = __builtin_amdgcn_perm(y, x, 0x06040200u), hi = __builtin_amdgcn_perm(y, x, 0x07050301u) ^ page4;
+    uint32_t m = (((hi & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | hi) & 0x80808080u; // bit 7 of every byte whose high byte is not the page's
     m |= m - (m >> 7);                                                      // -> 0xFF there
-    return lo | m;
+    return (lo & ~m) | (sub4 & m);                                          // v_bfi_b32
 }
 typedef uint32_t ng_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ ng_u32x4 narrow16(const ng_u32x4 &A, const ng_u32x4 &B) {
+__device__ __forceinline__ ng_u32x4 narrow16(const ng_u32x4 &A, const ng_u32x4 &B, uint32_t page4 = 0u, uint32_t sub4 = 0xFFFFFFFFu) {
     ng_u32x4 o;
+    if (page4 != 0u) { // wave-uniform
+        o[0] = narrow_pair_patched(A[0], A[1], page4, sub4), o[1] = narrow_pair_patched(A[2], A[3], page4, sub4);
+        o[2] = narrow_pair_patched(B[0], B[1], page4, sub4), o[3] = narrow_pair_patched(B[2], B[3], page4, sub4);
+        return o;
+    }
     o[0] = narrow_pair(A[0], A[1]), o[1] = narrow_pair(A[2], A[3]), o[2] = narrow_pair(B[0], B[1]), o[3] = narrow_pair(B[2], B[3]);
     const uint32_t any_hi = ((A[0] | A[1] | A[2]) | (A[3] | B[0] | B[1]) | (B[2] | B[3])) & 0xFF00FF00u;
     if (__builtin_expect(__ballot(any_hi != 0u) != 0ull, 0)) {
-        o[0] = narrow_pair_patched(A[0], A[1]), o[1] = narrow_pair_patched(A[2], A[3]);
-        o[2] = narrow_pair_patched(B[0], B[1]), o[3] = narrow_pair_patched(B[2], B[3]);
+        o[0] = narrow_pair_patched(A[0], A[1], 0u, sub4), o[1] = narrow_pair_patched(A[2], A[3], 0u, sub4);
+        o[2] = narrow_pair_patched(B[0], B[1], 0u, sub4), o[3] = narrow_pair_patched(B[2], B[3], 0u, sub4);
     }
     return o;
 }

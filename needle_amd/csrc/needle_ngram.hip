@@ -41,6 +41,7 @@ struct NgramArgs {
     uint32_t stride_log2;   // stride_bytes is a power of two (else 0xFFFFFFFF)
     uint32_t stride_recip;  // floor(2^32 / stride_bytes)
     uint32_t char_width;    // 2: UTF-16 rows narrowed on the fly (needle_ngram.h narrow16); a.stride_bytes / a.total_bytes then count CHARS
+    uint32_t page4, sub4;   // ... the pattern's page of the BMP and the byte that stands for every char outside it, in all four bytes of a dword
 };
 
 static_assert(kNgWaves == (uint32_t)kWavesPerBlock, "ngram_layout assumes the scan kernels' workgroup");
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     // 16 chars of text at p (unaligned) as 16 bytes
     auto text16 = [&](const uint8_t *p) __attribute__((always_inline)) -> u32x4 {
         if (CW == 1) return *(const u32x4_u *)p;
-        return narrow16(*(const u32x4_u *)p, *(const u32x4_u *)(p + 16));
+        return narrow16(*(const u32x4_u *)p, *(const u32x4_u *)(p + 16), A.page4, A.sub4);
     };
 
     // Run the automaton for one row per lane from the start state: chars [r, ..) of row `row` of group grp, looking for a FIRST accept
@@ -310,9 +311,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             c5 = deep ? (uint32_t)rowp[qn - 5u] : 0u;
         } else {
             typedef uint16_t u16_u __attribute__((aligned(1)));
-            w = narrow_pair_patched(*(const u32_u *)(rowp + (qn - 4u) * 2u), *(const u32_u *)(rowp + (qn - 2u) * 2u));
+            w = narrow_pair_patched(*(const u32_u *)(rowp + (qn - 4u) * 2u), *(const u32_u *)(rowp + (qn - 2u) * 2u), A.page4, A.sub4);
             c5 = deep ? (uint32_t)*(const u16_u *)(rowp + (qn - 5u) * 2u) : 0u;
-            c5 = c5 > 0xFFu ? 0xFFu : c5;
+            c5 = (c5 >> 8) == (A.page4 & 0xFFu) ? (c5 & 0xFFu) : (A.sub4 & 0xFFu);
         }
         return !deep || ngram_probe2(w, c5, mm, m3, amask2, bm2_base) != 0u;
     };
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 asm volatile("" ::: "memory");
                 R[k] = load_next();
                 asm volatile("" ::: "memory");
-                const u32x4 v = CW == 1 ? raw.lo : narrow16(raw.lo, raw.hi);
+                const u32x4 v = CW == 1 ? raw.lo : narrow16(raw.lo, raw.hi, A.page4, A.sub4);
                 const uint32_t pw = ngram_prev_dword(v[3], carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);
                 log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], mm, amask, bm_base);
@@ -553,13 +554,13 @@ bool ngram_shape_ok(const ScanArgs &a) {
 }
 
 static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
-                                   const NgramArgs *fa, int char_width = 1);
+                                   const NgramArgs *fa, int char_width = 1, int page = 0, int sub = 0xFF);
 
 // char_width 2: UTF-16 rows behind the BYTE program's filter (patterns below 0xFF only: the caller checks) -- a.stride_bytes and
 // a.total_bytes count chars then
 hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
-                        int char_width) {
-    return launch_ngram_any(op, a, ng, d_bitmap, d_stats, n_cus, stream, nullptr, char_width);
+                        int char_width, int page, int sub) {
+    return launch_ngram_any(op, a, ng, d_bitmap, d_stats, n_cus, stream, nullptr, char_width, page, sub);
 }
 
 // LDS of the find-all form; 0 = does not fit
@@ -573,20 +574,21 @@ size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
 // rows and the lengths program, the outputs are the find-all ones.
 hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
                                  int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
-                                 hipStream_t stream, int char_width) {
+                                 hipStream_t stream, int char_width, int page, int sub) {
     NgramArgs F;
     memset(&F, 0, sizeof(F));
     F.fa_slots = slots, F.fa_counts = counts, F.fa_starts = starts, F.fa_ends = ends, F.fa_packed = packed, F.fa_more = more;
     F.fa_offsets = offsets, F.fa_count_only = count_only ? 1u : 0u;
-    return launch_ngram_any(OP_NG_FIND_ALL, a, ng, d_bitmap, d_stats, n_cus, stream, &F, char_width);
+    return launch_ngram_any(OP_NG_FIND_ALL, a, ng, d_bitmap, d_stats, n_cus, stream, &F, char_width, page, sub);
 }
 
 static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, int n_cus, hipStream_t stream,
-                                   const NgramArgs *fa, int char_width) {
+                                   const NgramArgs *fa, int char_width, int page, int sub) {
     NgramArgs A;
     memset(&A, 0, sizeof(A));
     if (fa) A = *fa;
     A.char_width = (uint32_t)char_width;
+    A.page4 = (uint32_t)(page & 255) * 0x01010101u, A.sub4 = (uint32_t)(sub & 255) * 0x01010101u;
     A.a = a;
     A.ng = ng;
     A.ng_bitmap = d_bitmap;

@@ -15,11 +15,12 @@ def narrow_pair(x, y):
     return v_perm_b32(y, x, 0x06040200)
 
 
-def narrow_pair_patched(x, y):
-    lo, hi = v_perm_b32(y, x, 0x06040200), v_perm_b32(y, x, 0x07050301)
+def narrow_pair_patched(x, y, page=0, sub=0xFF):
+    page4, sub4 = np.uint32(page * 0x01010101), np.uint32(sub * 0x01010101)
+    lo, hi = v_perm_b32(y, x, 0x06040200), v_perm_b32(y, x, 0x07050301) ^ page4
     m = (((hi & np.uint32(0x7F7F7F7F)) + np.uint32(0x7F7F7F7F)) | hi) & np.uint32(0x80808080)
     m = m | (m - (m >> np.uint32(7)))
-    return lo | m
+    return (lo & ~m) | (sub4 & m)
 
 
 def test_narrowing_is_min_of_char_and_0xff():
@@ -39,3 +40,17 @@ def test_narrowing_is_min_of_char_and_0xff():
     # the fast path's test: some high byte of the 8 dwords not zero <=> some char above 0xFF
     any_hi = ((x | y) & np.uint32(0xFF00FF00)) != 0
     assert (any_hi == ~latin).all()
+
+
+def test_narrowing_to_another_page():
+    """chars of page P -> their low byte, every other char -> the page's substitute (needle_api.cpp utf16_route)"""
+    rng = np.random.default_rng(12)
+    for page, sub in ((0x04, 0x2F), (0x05, 0x00), (0xFF, 0x80), (0x00, 0xFF)):
+        chars = rng.integers(0, 0x10000, size=(20000, 4), dtype=np.uint32)
+        chars[:8000] = (page << 8) | rng.integers(0, 0x100, size=(8000, 4), dtype=np.uint32)
+        chars[8000:9000] = rng.choice(np.array([0x0000, 0x0020, 0x00FF, ((page ^ 1) << 8) | 0x30, ((page ^ 0x80) << 8) | 0x30, 0xFFFF, (page << 8) | sub], dtype=np.uint32), size=(1000, 4))
+        x = (chars[:, 0] | chars[:, 1] << 16).astype(np.uint32)
+        y = (chars[:, 2] | chars[:, 3] << 16).astype(np.uint32)
+        want = np.where((chars >> 8) == page, chars & 0xFF, sub).astype(np.uint32)
+        want = want[:, 0] | want[:, 1] << 8 | want[:, 2] << 16 | want[:, 3] << 24
+        assert (narrow_pair_patched(x, y, page, sub) == want).all(), (page, sub)
