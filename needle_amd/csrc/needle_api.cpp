@@ -722,10 +722,10 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     const DevProgram *fp = nullptr, *bp = nullptr;
     int n_cus = 0;
     const bool need_backward = op == OP_FIND && p->t.fixed_len < 0;
-    // UTF-16 rows (Java's strings) of a pattern whose chars all lie below 0xFF -- ASCII / Latin-1 dictionaries: behind the BYTE program's
-    // n-gram filter, the text narrowed as it is loaded (needle_ngram.h narrow16; a char above 0xFE is "beyond maxChar", the reference's
-    // `c > maxChar` exit, exactly as byte 0xFF is for the byte program).  The program is chosen as for 8-bit rows below; whatever rules the
-    // filter out there (no filter for this automaton, the shape, the flood watch) leaves these rows to the UTF-16 kernels.
+    // UTF-16 rows (Java's strings) of a pattern that lives on one page of the BMP -- ASCII / Latin-1, Cyrillic, Greek ... dictionaries: behind
+    // the n-gram filter of the BYTE program of that page, the text narrowed as it is loaded (utf16_route above; needle_ngram.h narrow16).
+    // The program is chosen as for 8-bit rows below; whatever rules the filter out there (no filter for this automaton, the shape, the
+    // flood watch) leaves these rows to the UTF-16 kernels.
     const Utf16Route u16 = v->char_width == 2 ? utf16_route(p) : Utf16Route();
     if (v->char_width == 2 && op != OP_MATCHES && !d_from && !d_end_state && !no_backward && ngram_level() > 0 && dict_env == 0 && u16.page >= 0 &&
         v->row_stride * 2 < 8 * (uint64_t)kStripeBytes) {
@@ -1717,7 +1717,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     // kernel's find-all form files every verified candidate and each row sorts its own out against its moving cursor (dense slots,
     // the counting pass and the compact filing alike).  NEEDLE_FIND_ALL_FILTER=0: off (A/B, tests).
     static const bool fa_filter = !(getenv("NEEDLE_FIND_ALL_FILTER") && atoi(getenv("NEEDLE_FIND_ALL_FILTER")) == 0);
-    // (UTF-16 rows of a pattern below 0xFF: the same byte programs, the text narrowed as it is loaded -- utf16_filter_ok)
+    // (UTF-16 rows of a pattern on one page of the BMP: that page's byte programs, the text narrowed as it is loaded -- utf16_route)
     const Utf16Route u16 = v->char_width == 2 ? utf16_route(p) : Utf16Route();
     if (fa_filter && (count_only || d_offsets || slots) && (v->char_width == 1 || (v->char_width == 2 && u16.page >= 0)) && ngram_level() > 0 &&
         (p->t.fixed_len >= 0 || find_lengths_for(MODE_SPARSE))) {
