@@ -23,6 +23,7 @@ while len(words) < n_kw:
     elif r < 0.25 and len(w) > 3: words.add(w[rng.randint(1, len(w) - 2):])                    # a proper suffix
     elif r < 0.30: words.add(w + "".join(rng.choice(alpha) for _ in range(rng.randint(1, 3))))  # an extension
 import os
+import os
 fuzz_min = int(os.environ.get("FUZZ_MIN_LEN", "0"))  # keep only keywords of at least this many chars (5: the n-gram filter's stride 2
 if fuzz_min:                                            # becomes possible, 7: stride 4) and plant near misses (keyword tails) as well
     words = {w for w in words if len(w) >= fuzz_min}
@@ -30,7 +31,8 @@ if fuzz_min:                                            # becomes possible, 7: s
         words.add("".join(rng.choice(alpha) for _ in range(rng.randint(fuzz_min, fuzz_min + 3))))
 words = sorted(words)
 rng.shuffle(words)
-rx = "|".join(words)
+cyr = int(os.environ.get("FUZZ_UTF16", "0")) == 2  # 2: the dictionary in Cyrillic letters (page 4 of the BMP) over UTF-16 rows
+rx = "|".join("".join(chr(0x0430 + ord(c) - 97) for c in w) for w in words) if cyr else "|".join(words)
 p = DFACompiler.compile(rx, "t", 0)
 o, _ = oracle_for(rx, 0)
 pi = p.program_info("forwards", 1)
@@ -53,6 +55,11 @@ if fuzz_min:  # near misses: a keyword's tail behind a wrong first char (passes 
 utf16 = int(os.environ.get("FUZZ_UTF16", "0"))  # the same rows as UTF-16 (Java's strings), chars above 0xFF sprinkled over text and keywords:
 if utf16:                                        # dictionaries with a filter take the byte program's filter kernel, the text narrowed on the fly
     rows = rows.astype(np.uint16)
+    if cyr:
+        low = (rows >= 97) & (rows <= 122)
+        rows[low] += 0x0430 - 97
+        rows[low & (nr.random(rows.shape) < 0.01)] += 0x0100   # page 5 under a keyword char's low byte
+        rows[nr.random(rows.shape) < 0.01] = 0x0061             # page 0
     m = nr.random(rows.shape) < 0.01
     rows[m] = nr.integers(0x0100, 0xFFFF, size=int(m.sum()), dtype=np.uint16)
     rows[nr.random(rows.shape) < 0.01] |= 0x0100
