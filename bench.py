@@ -798,7 +798,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16"], help="the headline workload")
     ap.add_argument("--also", default=None, help="comma list of further workloads measured into \"workloads\" "
-                    "(default: c3,c3s,c3x,c5,c5w,c3x16 at 1 GPU, c3 at N > 1; 'none' for profiling runs; c3s16 / c3x16: the c3s / c3x dictionaries over UTF-16 rows)")
+                    "(default: c3,c3s,c3x,c5,c5w,c3s16,c3x16 at 1 GPU, c3 at N > 1; 'none' for profiling runs; c3s16 / c3x16: the c3s / c3x dictionaries over UTF-16 rows)")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--graph", default="off", choices=["off", "scan"], help="launch the scan as a HIP graph (experiment; plain launches are faster)")
@@ -858,7 +858,7 @@ def main():
         if int(ok.item()) == 0:
             ctx.comm = None
     if args.also is None:
-        also = ["c3", "c3s", "c3x", "c5", "c5w", "c3x16"] if world == 1 else ["c3"]
+        also = ["c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16"] if world == 1 else ["c3"]
         if args.regex or args.op or args.rows != 10_000_000:
             also = []
     else:

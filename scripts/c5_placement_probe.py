@@ -46,7 +46,9 @@ for i in range(nbuf):
         r.copy_(rows0)
         keep.append(r)
     med, lo, hi = timed(r, out0)
-    print("rows buffer %d at 0x%x (results fixed): median %.4f ms  min %.4f  max %.4f" % (i, r.data_ptr(), med, lo, hi))
+    # (does a plain streaming read of the buffer see the same thing?  bench.py's read-ceiling probe on this buffer)
+    print("rows buffer %d at 0x%x (results fixed): median %.4f ms  min %.4f  max %.4f   streaming read of it: %.0f GB/s" %
+          (i, r.data_ptr(), med, lo, hi, bench.measured_read_ceiling(r) or 0.0))
 keep_o = [out0]
 for i in range(nbuf):
     o = outs()
