@@ -224,6 +224,16 @@ public final class GpuPattern implements Pattern, AutoCloseable {
         return st[2];
     }
 
+    /**
+     * The page of the BMP this pattern lives on (0: ASCII / Latin-1, 4: Cyrillic, ...), or -1 when it spans several: String batches
+     * (UTF-16) of one-page dictionaries run behind the n-gram filter of that page's byte program (needle_pattern_utf16_route).
+     */
+    public int utf16Page() {
+        int[] out = new int[2];
+        check(Native.utf16Route(handle, out), null);
+        return out[0];
+    }
+
     /** The library's NEEDLE_* environment switches (needle_tuning_info). */
     public static String tuningInfo() {
         return Native.tuningInfo();

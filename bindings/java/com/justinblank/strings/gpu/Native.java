@@ -99,6 +99,9 @@ final class Native {
      */
     static native int prefilterState(long handle, int which, int[] state, float[] rate, long[] counts);
 
+    /** needle_pattern_utf16_route: out[0] = the pattern's one page of the BMP (-1: it spans several), out[1] = the substitute byte. */
+    static native int utf16Route(long handle, int[] out);
+
     /** needle_pattern_serialize / needle_pattern_deserialize: the precompiled-pattern blob (Precompile's analogue). */
     static native byte[] serialize(long handle);
 

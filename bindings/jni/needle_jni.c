@@ -263,6 +263,18 @@ NATIVE(jint, prefilterState)(JNIEnv *env, jclass c, jlong h, jint which, jintArr
     return NEEDLE_OK;
 }
 
+/* needle_pattern_utf16_route: out[0] = page (-1: none), out[1] = substitute byte */
+NATIVE(jint, utf16Route)(JNIEnv *env, jclass c, jlong h, jintArray out) {
+    int32_t page = -1, sub = 0;
+    const int rc = needle_pattern_utf16_route((const needle_pattern *)(intptr_t)h, &page, &sub);
+    if (rc != NEEDLE_OK) return rc;
+    if (int_room(env, out, 2)) {
+        const jint v[2] = {page, sub};
+        (*env)->SetIntArrayRegion(env, out, 0, 2, v);
+    }
+    return NEEDLE_OK;
+}
+
 NATIVE(jint, packedHost)(JNIEnv *env, jclass c, jlong h, jint op, jcharArray data, jlongArray offsets, jlongArray bitmap, jintArray start, jintArray end) {
     needle_packed_view v;
     memset(&v, 0, sizeof(v));

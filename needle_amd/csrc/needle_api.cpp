@@ -1415,6 +1415,13 @@ int needle_pattern_set_prefilter(needle_pattern *p, int mode) {
 
 // What the flood watch of this pattern's filter program(s) for `which` on the CURRENT device knows (no device needed to ask; all zero
 // before the first scan).  Several programs may carry a filter (plain / lengths / HBM-table forms): the one that ran last is reported.
+int needle_pattern_utf16_route(const needle_pattern *p, int32_t *page, int32_t *sub) {
+    if (!p || !page || !sub) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    const Utf16Route r = utf16_route(p);
+    *page = r.page, *sub = r.page >= 0 ? r.sub : 0;
+    return NEEDLE_OK;
+}
+
 int needle_pattern_prefilter_state(const needle_pattern *cp, int which, needle_prefilter_state *o) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");

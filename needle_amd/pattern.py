@@ -213,6 +213,13 @@ class Pattern:
         _check(_lib.lib().needle_pattern_prefilter_state(self._h, list(WHICH).index(which), ctypes.byref(st)))
         return {k: getattr(st, k) for k, _ in st._fields_}
 
+    def utf16_route(self):
+        """needle_pattern_utf16_route: (page, sub) -- UTF-16 rows of this pattern can run behind the byte program of BMP page `page` (0: ASCII /
+        Latin-1, 4: Cyrillic ...), every char outside the page narrowed to byte `sub`; None when the pattern spans several pages.  No GPU needed."""
+        page, sub = ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(_lib.lib().needle_pattern_utf16_route(self._h, ctypes.byref(page), ctypes.byref(sub)))
+        return None if page.value < 0 else (page.value, sub.value)
+
     def match_length_automaton(self):
         """The refined forward automaton behind find-all's "lengths" form (needle_pattern_match_lengths), or None when the
         pattern does not allow it -> {"n_states", "n_dead", "max_char", "table" int16[n, stride + 1] (last column: chars beyond max_char), "accepting"

@@ -56,3 +56,18 @@ def test_oracle_on_utf16_rows_equals_oracle_on_narrowed_rows(rx):
     # (patterns reaching 0xFF and beyond may or may not agree: the route is off for them -- utf16_filter_ok; nothing to assert but that
     # the criterion is what the library reports)
     assert (max_char < 0xFF) == (rx not in ("[^a]bc", "abcÿd")), (rx, max_char)
+
+
+def test_route_reports_the_patterns_page():
+    """needle_pattern_utf16_route (host-side, from the tables alone): page 0 / sub 0xFF for ASCII dictionaries, page 4 for Cyrillic ones with a
+    substitute of the "other" class on that page, nothing for a pattern on two pages or one that leaves its page no "other" char."""
+    def cyr(w): return "".join(chr(0x0430 + ord(c) - 97) for c in w)
+    words = W.keywords(200, min_len=6, max_len=8)
+    assert DFACompiler.compile("|".join(words), "t", 0).utf16_route() == (0, 0xFF)
+    pc = DFACompiler.compile("|".join(cyr(w) for w in words), "t", 0)
+    page, sub = pc.utf16_route()
+    assert page == 4 and not (0x30 <= sub <= 0x49)   # (0x0430 .. 0x0449 are the pattern's own letters a .. z)
+    assert DFACompiler.compile("|".join(words[:50] + [cyr(w) for w in words[50:100]]), "t", 0).utf16_route() is None
+    assert DFACompiler.compile("[Ѐ-ӿ]{4}[Ѐ-ӿ]*x?", "t", 0).utf16_route() is None  # two pages (x), and page 4 has no other char
+    r = DFACompiler.compile("abcdefÿgh|bcdefgh", "t", 0).utf16_route()
+    assert r is not None and r[0] == 0 and r[1] != 0xFF
