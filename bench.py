@@ -791,6 +791,33 @@ def slim_line(out):
     return line
 
 
+def error_line(args, msg, emit=True):
+    """A run that cannot start still prints ONE JSON line (the contract's keys, `value` null, the reason under "error")."""
+    if emit:
+        print(json.dumps({"metric": "GB/s haystack scanned (10M x 256-char batch, DFA table walk)", "value": None, "unit": "GB/s", "n_gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
+                          "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": {"workload": args.workload}, "error": msg}), flush=True)
+
+
+def self_launch(args, torch):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: re-run this command line as N ranks under torch.distributed.run on
+    127.0.0.1 with a free port; the children inherit stdout / stderr, so rank 0's line is this process's line.  Returns the exit code."""
+    import socket
+    import subprocess
+    if args.all_on_device is None and torch.cuda.device_count() < args.gpus:
+        error_line(args, "--gpus %d but %d device(s) visible" % (args.gpus, torch.cuda.device_count()))
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -819,12 +846,20 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver (and README.md) call it at N = 1: start the N ranks ourselves, one process
+        # per GPU, and let rank 0 print the ONE line.  Under torch.distributed.run (RANK / WORLD_SIZE set) this is skipped.
+        raise SystemExit(self_launch(args, torch))
     ctx = Ctx()
     ctx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     ctx.rank = rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 through torch.distributed.run" % (args.gpus, world))
+        error_line(args, "--gpus %d but WORLD_SIZE=%d: the launcher's --nproc-per-node must equal --gpus" % (args.gpus, world), rank == 0)
+        raise SystemExit(2)
+    if args.all_on_device is None and torch.cuda.device_count() < max(args.gpus, 1):
+        error_line(args, "--gpus %d but %d device(s) visible" % (args.gpus, torch.cuda.device_count()), rank == 0)
+        raise SystemExit(3)
     if args.all_on_device is not None:
         local = args.all_on_device
     torch.cuda.set_device(local)

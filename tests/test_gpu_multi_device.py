@@ -187,6 +187,7 @@ def test_c4_rehearsal_eight_ranks_full_batch_on_one_gpu():
     and what row sharding itself costs: 8 x the slowest rank's shard kernel (timed alone on the device) within 15 % of the N = 1
     kernel.  Rows are independent units (DFAClassBuilder.java:669-699: a Matcher per haystack), so nothing else can differ."""
     import json
+    import os
     import subprocess
     import sys
     from conftest import ROOT
@@ -195,9 +196,11 @@ def test_c4_rehearsal_eight_ranks_full_batch_on_one_gpu():
         one = subprocess.run(base, capture_output=True, text=True, cwd=ROOT, timeout=900)
         assert one.returncode == 0, one.stderr[-2000:]
         d1 = json.loads(one.stdout.strip().splitlines()[-1])
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29547",
-               "bench.py", "--gpus", "8", "--backend", "gloo", "--all-on-device", "0"] + base[2:]
-        eight = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=1800)
+        # the command form the driver uses at N = 1, with --gpus 8: NO launcher and no RANK / WORLD_SIZE in the environment --
+        # bench.py starts its eight ranks itself (bench.self_launch) and rank 0's line is the only line on stdout
+        cmd = [sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--all-on-device", "0"] + base[2:]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        eight = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=1800, env=env)
         assert eight.returncode == 0, eight.stderr[-3000:]
         lines = [ln for ln in eight.stdout.strip().splitlines() if ln.startswith("{")]
         assert len(lines) == 1
@@ -209,6 +212,12 @@ def test_c4_rehearsal_eight_ranks_full_batch_on_one_gpu():
             assert "one dword per row" in d8["config"]["result"]
         assert abs(d8["matched_fraction"] - d1["matched_fraction"]) < 1e-12
         assert d8["scan_ms"] > 0 and "gather_ms" in d8 and d8["value"] > 0
+        if workload == "c2":
+            # N = 1 through the same entry point stays the plain run (no launcher, no process group): within 3 % of it
+            again = subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+            assert again.returncode == 0, again.stderr[-2000:]
+            da = json.loads(again.stdout.strip().splitlines()[-1])
+            assert da["n_gpus"] == 1 and abs(da["roofline"]["kernel_ms"] / d1["roofline"]["kernel_ms"] - 1.0) < 0.03, (da["roofline"], d1["roofline"])
         # what sharding itself costs: one GPU's shard (1 250 048 rows) scanned by ONE process on the same device, x 8, against the
         # N = 1 kernel.  (The ranks' own solo timings inside the 8-process run are reported too, but with eight processes holding
         # queues on one device they include the driver's switching between them: an upper bound only.)
