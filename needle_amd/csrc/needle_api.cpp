@@ -43,7 +43,7 @@ hipError_t launch_ngram(int op, const ScanArgs &a, const NgramParams &ng, const 
 size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng);
 hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
                                  int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
-                                 hipStream_t stream, int char_width = 1, int page = 0, int sub = 0xFF);
+                                 hipStream_t stream, int char_width, int page, int sub, uint32_t kshift);
 int ngram_level(); // needle_lower.cpp (NEEDLE_PREFILTER)
 hipError_t launch_unpack(const void *data, const uint64_t *offsets, uint64_t n_rows, uint32_t cw, void *out,
                          uint64_t stride_bytes, uint32_t *lengths, int32_t *overflow, int n_cus, hipStream_t stream);
@@ -1693,7 +1693,7 @@ static int find_all_rounds(const needle_pattern *p, const needle_batch_view *v, 
 // (needle_find_all.hip).  Dense slots (offsets == nullptr), compact filing at caller-computed offsets, or counting only.
 static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts, int32_t *d_start,
                              int32_t *d_end, const uint64_t *d_offsets, bool count_only, int *more, hipStream_t stream,
-                             uint32_t *d_packed = nullptr) {
+                             uint32_t *d_packed = nullptr, uint32_t kshift = 0) {
     const uint64_t stride_bytes = v->row_stride * v->char_width;
     if (stride_bytes >= (1ull << 26)) return fail(NEEDLE_ERR_UNSUPPORTED, "rows of 64 MiB or more: only needle_find_all_dev (round per match) takes them");
     const DevProgram *fp = nullptr, *bp = nullptr;
@@ -1744,7 +1744,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
                 int32_t *d_more = nullptr;
                 HIP_TRY(scratch_malloc((void **)&d_more, 16, stream));
                 hipError_t e = hipMemsetAsync(d_more, 0, 4, stream);
-                if (e == hipSuccess) e = launch_ngram_find_all(a, sp->prog.ng.p, sp->d_ng, sp->d_ng_stats, slots, d_counts, d_start, d_end, d_packed, d_more, d_offsets, count_only, cus, stream, (int)v->char_width, u16.page > 0 ? u16.page : 0, v->char_width == 2 ? u16.sub : 0xFF);
+                if (e == hipSuccess) e = launch_ngram_find_all(a, sp->prog.ng.p, sp->d_ng, sp->d_ng_stats, slots, d_counts, d_start, d_end, d_packed, d_more, d_offsets, count_only, cus, stream, (int)v->char_width, u16.page > 0 ? u16.page : 0, v->char_width == 2 ? u16.sub : 0xFF, kshift);
                 if (e == hipSuccess) e = ngram_watch_after_launch(sp, stream);
                 int32_t m = 0;
                 if (e == hipSuccess && more) {
@@ -1780,6 +1780,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
             fl.s.hdr = tp->prog.hdr;
             fl.s.fixed_len = -1;
             fl.slots = slots;
+            fl.kshift = kshift;
             fl.offsets = d_offsets;
             fl.count_only = count_only ? 1u : 0u;
             fl.counts = d_counts;
@@ -1824,6 +1825,7 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
         a.bhdr = bp->prog.hdr;
     }
     fa.slots = slots;
+    fa.kshift = kshift;
     fa.offsets = d_offsets;
     fa.count_only = count_only ? 1u : 0u;
     static const bool no_defer = getenv("NEEDLE_FIND_ALL_DEFER") && atoi(getenv("NEEDLE_FIND_ALL_DEFER")) == 0; // A/B, tests
@@ -1883,6 +1885,20 @@ int needle_find_all_packed16_dev(const needle_pattern *cp, const needle_batch_vi
     if (!d_counts || (slots && !d_start_end16)) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
     if (!offsets16_ok(v, 65535u)) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit start / end: rows of at most 65535 chars");
     return find_all_one_pass(p, v, slots, d_counts, nullptr, nullptr, nullptr, false, more, (hipStream_t)stream_, d_start_end16);
+}
+
+// needle_find_all_packed16_dev with GROUP-BLOCKED slots: match k of row r at d_blocks[((r >> 6) * slots + k) * 64 + (r & 63)].
+int needle_find_all_blocked16_dev(const needle_pattern *cp, const needle_batch_view *v, uint32_t slots, uint32_t *d_counts,
+                                  uint32_t *d_blocks, int *more, void *stream_) {
+    needle_pattern *p = const_cast<needle_pattern *>(cp);
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_view(v, true);
+    if (rc) return rc;
+    if (more) *more = 0;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!d_counts || (slots && !d_blocks)) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    if (!offsets16_ok(v, 65535u)) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit start / end: rows of at most 65535 chars");
+    return find_all_one_pass(p, v, slots, d_counts, nullptr, nullptr, nullptr, false, more, (hipStream_t)stream_, d_blocks, 6u);
 }
 
 int needle_count_matches_dev(const needle_pattern *cp, const needle_batch_view *v, uint32_t *d_counts, void *stream_) {

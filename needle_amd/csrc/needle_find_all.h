@@ -22,6 +22,9 @@ struct FindAllArgs {
     const uint64_t *offsets; // != nullptr: compact (CSR) filing -- match k of row r at offsets[r] + k, room for
                              // offsets[r + 1] - offsets[r] matches; slots is not used
     uint32_t count_only;     // 1: nothing is filed (starts / ends may be null), every match is counted
+    uint32_t kshift;         // 0: a row's slots are consecutive ([row][slot]); 6: GROUP-BLOCKED slots -- match k of row r at
+                             // ((r >> 6) * slots + k) * 64 + (r & 63): slot k of a group's 64 rows is one 256-byte run, so the lanes'
+                             // stores fill whole lines in L2 instead of 4 bytes of one line per row (needle_find_all_blocked16_dev)
     uint32_t lmode;          // 1: the program is the "lengths" automaton (needle_lower.h): start = end - pend[end state], read
                              // from LDS at hdr.fa_len_off; the search also ends in the states fa_dead_lo .. + fa_dead_n - 1
 };

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
         last = a.hdr.root_accepting ? 0 : -1; // :356 literal 0 (cursor 0: the same whether 0 < length or not)
         pi = 0;
         count = 0;
-        out0 = my_row * fa.slots;
+        out0 = fa.kshift ? (my_row >> 6) * fa.slots * 64u + (my_row & 63u) : my_row * fa.slots;
         cap = fa.count_only ? 0xFFFFFFFFu : fa.slots;
         if (fa.offsets) {
             out0 = row_ok ? fa.offsets[my_row] : 0;
@@ -278,10 +278,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 done = done || (hit && !file);
                 if (file && !fa.count_only) {
                     if (fa.packed) {
-                        fa.packed[out0 + count] = (uint32_t)(en - mlen) | ((uint32_t)en << 16);
+                        fa.packed[out0 + ((uint64_t)count << fa.kshift)] = (uint32_t)(en - mlen) | ((uint32_t)en << 16);
                     } else {
-                        fa.starts[out0 + count] = en - mlen;
-                        fa.ends[out0 + count] = en;
+                        fa.starts[out0 + ((uint64_t)count << fa.kshift)] = en - mlen;
+                        fa.ends[out0 + ((uint64_t)count << fa.kshift)] = en;
                     }
                 }
                 count += file ? 1u : 0u;
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                 if (hit && !file) *fa.more = 1;
                 done = done || (hit && !file);
                 if (file && !fa.count_only) { // (counting: nothing is filed)
-                    if (fa.packed) fa.packed[out0 + count] = (uint32_t)en << 16; // (the start joins it in starts_phase)
-                    else fa.ends[out0 + count] = en;
+                    if (fa.packed) fa.packed[out0 + ((uint64_t)count << fa.kshift)] = (uint32_t)en << 16; // (the start joins it in starts_phase)
+                    else fa.ends[out0 + ((uint64_t)count << fa.kshift)] = en;
                 }
                 count += file ? 1u : 0u;
                 cursor = file ? en : cursor;
@@ -321,10 +321,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
                     if (count < cap) {
                         if (!fa.count_only) {
                             if (fa.packed) {
-                                fa.packed[out0 + count] = (uint32_t)s | ((uint32_t)en << 16);
+                                fa.packed[out0 + ((uint64_t)count << fa.kshift)] = (uint32_t)s | ((uint32_t)en << 16);
                             } else {
-                                fa.starts[out0 + count] = s;
-                                fa.ends[out0 + count] = en;
+                                fa.starts[out0 + ((uint64_t)count << fa.kshift)] = s;
+                                fa.ends[out0 + ((uint64_t)count << fa.kshift)] = en;
                             }
                         }
                         ++count;
@@ -382,11 +382,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             int32_t en = 1, bound = 0;
             if (act) {
                 if (fa.packed) {
-                    en = (int32_t)(__hip_atomic_load(&fa.packed[o_out0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
-                    if (k) bound = (int32_t)(__hip_atomic_load(&fa.packed[o_out0 + k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
+                    en = (int32_t)(__hip_atomic_load(&fa.packed[o_out0 + ((uint64_t)k << fa.kshift)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
+                    if (k) bound = (int32_t)(__hip_atomic_load(&fa.packed[o_out0 + ((uint64_t)(k - 1) << fa.kshift)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16);
                 } else {
-                    en = __hip_atomic_load(&fa.ends[o_out0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (k) bound = __hip_atomic_load(&fa.ends[o_out0 + k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    en = __hip_atomic_load(&fa.ends[o_out0 + ((uint64_t)k << fa.kshift)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (k) bound = __hip_atomic_load(&fa.ends[o_out0 + ((uint64_t)(k - 1) << fa.kshift)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             const uint32_t pa = ((uint32_t)(en - 1) * CW) >> 4; // window: the piece holding char en - 1 and the one before it
@@ -402,8 +402,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_kernel(const Fin
             const uint32_t w_addr = pa ? tile.row_addr : tile.row_addr + 16u;
             const int32_t st_k = fa.defer == 2u ? bound : backward_walk<CW>(a, act, en, bound, w_addr, win_b0, pa ? 32u : 16u, 0u, o_rowp); // (2: measurement aid)
             if (act) {
-                if (fa.packed) fa.packed[o_out0 + k] = (uint32_t)st_k | ((uint32_t)en << 16);
-                else fa.starts[o_out0 + k] = st_k;
+                if (fa.packed) fa.packed[o_out0 + ((uint64_t)k << fa.kshift)] = (uint32_t)st_k | ((uint32_t)en << 16);
+                else fa.starts[o_out0 + ((uint64_t)k << fa.kshift)] = st_k;
             }
         }
     };

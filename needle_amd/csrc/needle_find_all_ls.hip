@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
     const uint32_t pad_addr = wk.pad_e + (CW == 1 ? (uint32_t)kLdsTable1 : wk.table_off);
     const uint32_t codes_off = a.hdr.ft_codes_off;
     const uint32_t e_start = a.hdr.start << 4;
+    const uint32_t kshift4 = fa.offsets ? 2u : fa.kshift + 2u; // bytes between a row's consecutive matches: 4, or 256 in the group-blocked layout
 
     Tile tile;
     {
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
         if (n_chunks == 0) n_chunks = 1;
         e = row_ok ? e_start : 0u;
         count = 0;
-        gbase = (grp << 6) * fa.slots;
-        voff = (uint32_t)lane * fa.slots * 4u;
+        gbase = (grp << 6) * fa.slots; // (group-blocked slots: the same first slot -- group * slots * 64)
+        voff = fa.kshift ? (uint32_t)lane * 4u : (uint32_t)lane * fa.slots * 4u;
         cap = fa.count_only ? 0xFFFFFFFFu : fa.slots;
         if (fa.offsets) {
             const uint64_t o0 = row_ok ? fa.offsets[my_row] : 0ull;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
     };
     auto file = [&](bool hit, uint32_t pos, uint32_t d) __attribute__((always_inline)) {
         if (hit && count < cap && !fa.count_only) {
-            const uint32_t off = voff + count * 4u;
+            const uint32_t off = voff + (count << kshift4); // (v_lshl_add_u32 with the shift in an SGPR)
             if (fa.packed) {
                 store32(fa.packed + gbase, off, __umul24(pos, 0x10001u) - d); // start | end << 16
             } else {
@@ -293,7 +294,7 @@ static hipError_t launch_ls_h(const FindAllArgs &fa, int chb, int grid, int wave
 // The kernel forms a match's result address as (uniform 64-bit group base) + (32-bit byte offset of the lane's row inside the group):
 // dense slots: 64 rows x slots x 4 B; compact filing: the group's matches x 4 B -- at most one match per char.
 bool find_all_lockstep_shape_ok(const FindAllArgs &fa) {
-    return (uint64_t)fa.slots < (1ull << 23) && fa.s.stride_bytes < (1ull << 23);
+    return (uint64_t)fa.slots < (1ull << 23) && fa.s.stride_bytes < (1ull << 23);  // (blocked: slots * 256 B per group -- the same bound)
 }
 
 // One persistent workgroup per CU; the shape (waves x tile bytes) follows the transducer's LDS footprint.

@@ -30,6 +30,7 @@ struct NgramArgs {
     uint32_t *stats;        // optional: [0] += candidates, [1] += KiB units of text seen by this launch
     // OP_NG_FIND_ALL (every non-overlapping match of every row, dense per-row slots: needle_find_all.h FindAllArgs)
     uint32_t fa_slots;
+    uint32_t fa_kshift; // 6: group-blocked slots (needle_find_all.h FindAllArgs::kshift)
     uint32_t *fa_counts;
     int32_t *fa_starts, *fa_ends;
     uint32_t *fa_packed;
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             bool slow = row_ok && n_mine > kNgRowSlots;
             uint32_t cursor = 0, cnt = 0;
             bool more_f = false;
-            uint64_t out0 = ((g << 6) + lane) * (uint64_t)A.fa_slots;
+            uint64_t out0 = A.fa_kshift ? g * (uint64_t)A.fa_slots * 64u + (uint64_t)lane : ((g << 6) + lane) * (uint64_t)A.fa_slots;
             uint32_t cap = A.fa_count_only ? 0xFFFFFFFFu : A.fa_slots;
             if (A.fa_offsets) {
                 out0 = row_ok ? A.fa_offsets[(g << 6) + lane] : 0ull;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 const bool file = hit && cnt < cap;
                 more_f = more_f || (hit && !file);
                 if (file && !A.fa_count_only) {
-                    const uint64_t o = out0 + cnt;
+                    const uint64_t o = out0 + ((uint64_t)cnt << (A.fa_offsets ? 0u : A.fa_kshift));
                     if (A.fa_packed) {
                         A.fa_packed[o] = (uint32_t)start | (last << 16);
                     } else {
@@ -574,9 +575,10 @@ size_t ngram_find_all_lds_bytes(const ProgHeader &h, const NgramParams &ng) {
 // rows and the lengths program, the outputs are the find-all ones.
 hipError_t launch_ngram_find_all(const ScanArgs &a, const NgramParams &ng, const uint32_t *d_bitmap, uint32_t *d_stats, uint32_t slots, uint32_t *counts,
                                  int32_t *starts, int32_t *ends, uint32_t *packed, int32_t *more, const uint64_t *offsets, bool count_only, int n_cus,
-                                 hipStream_t stream, int char_width, int page, int sub) {
+                                 hipStream_t stream, int char_width, int page, int sub, uint32_t kshift) {
     NgramArgs F;
     memset(&F, 0, sizeof(F));
+    F.fa_kshift = offsets ? 0u : kshift;
     F.fa_slots = slots, F.fa_counts = counts, F.fa_starts = starts, F.fa_ends = ends, F.fa_packed = packed, F.fa_more = more;
     F.fa_offsets = offsets, F.fa_count_only = count_only ? 1u : 0u;
     return launch_ngram_any(OP_NG_FIND_ALL, a, ng, d_bitmap, d_stats, n_cus, stream, &F, char_width, page, sub);

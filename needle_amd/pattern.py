@@ -437,6 +437,34 @@ class Pattern:
                                                   ctypes.byref(more) if want_more else None, s))
         return counts, se, (bool(more.value) if want_more else None)
 
+    def find_all_blocked16(self, rows, max_per_row, lengths=None, stream=None, out=None, want_more=True):
+        """needle_find_all_blocked16_dev: find_all_dense_packed16 with GROUP-BLOCKED slots -- match k of row r at
+        blocks[r >> 6, k, r & 63].  -> (counts int32[n], blocks int32[ceil(n / 64), max_per_row, 64], more)
+        (unblock16(blocks, n) gives the [n, max_per_row] view of find_all_dense_packed16)."""
+        import torch
+        L = _lib.lib()
+        v, n = self._dev_view(rows, lengths), rows.shape[0]
+        ng = (n + 63) // 64
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            if out is not None:
+                counts, blocks = out
+                assert counts.shape == (n,) and blocks.shape == (ng, max_per_row, 64)
+                assert all(t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() for t in out)
+            else:
+                counts = torch.zeros(n, dtype=torch.int32, device=rows.device)
+                blocks = torch.full((ng, max_per_row, 64), -1, dtype=torch.int32, device=rows.device)
+            more = ctypes.c_int(0)
+            _check(L.needle_find_all_blocked16_dev(self._h, ctypes.byref(v), int(max_per_row), counts.data_ptr(), blocks.data_ptr(),
+                                                   ctypes.byref(more) if want_more else None, s))
+        return counts, blocks, (bool(more.value) if want_more else None)
+
+    @staticmethod
+    def unblock16(blocks, n_rows):
+        """[groups, slots, 64] group-blocked slots -> [n_rows, slots] row-major (a copy)."""
+        g, k, _ = blocks.shape
+        return blocks.permute(0, 2, 1).reshape(g * 64, k)[:n_rows].contiguous()
+
     def _dev_view(self, rows, lengths):
         import torch
         assert isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dim() == 2 and rows.is_contiguous()

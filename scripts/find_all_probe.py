@@ -31,17 +31,24 @@ while time.perf_counter() - tp < 0.15:
     torch.cuda.synchronize()
 del scratch
 packed = bool(os.environ.get("FIND_ALL_PROBE_PACKED"))  # needle_find_all_packed16_dev: one dword per match
-out["form"] = "packed16" if packed else "start/end int32"
+blocked = bool(os.environ.get("FIND_ALL_PROBE_BLOCKED"))  # needle_find_all_blocked16_dev: one dword per match, group-blocked slots
+if blocked:
+    st = torch.full(((n + 63) // 64, slots, 64), -1, dtype=torch.int32, device="cuda:0")
+out["form"] = "blocked16" if blocked else "packed16" if packed else "start/end int32"
 for rep in range(4):
     t0 = time.perf_counter()
-    if packed:
+    if blocked:
+        counts, st, more = pattern.find_all_blocked16(rows, slots, out=(counts, st))
+    elif packed:
         counts, st, more = pattern.find_all_dense_packed16(rows, slots, out=(counts, st))
     else:
         counts, st, en, more = pattern.find_all_dense(rows, slots, out=(counts, st, en))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     best = dt if best is None or (rep and dt < best) else best
-if packed:
+if blocked:
+    st = pattern.unblock16(st, n)
+if packed or blocked:
     st, en = st & 0xFFFF, (st >> 16) & 0xFFFF
 out["ms"] = round(best * 1e3, 3)
 total = int(counts.sum().item())

@@ -40,6 +40,11 @@ def check(p, o, rows, lens, tag, every=1):
         filed = np.arange(slots)[None, :] < counts[:, None]
         assert ((sev & 0xFFFF)[filed] == st[filed]).all() and ((sev >> 16)[filed] == en[filed]).all(), (tag, "packed form")
         assert (st[~filed] == -1).all() and (en[~filed] == -1).all(), (tag, "slots beyond the count are untouched")
+        c3, blocks, more3 = p.find_all_blocked16(rows, slots, lens)  # group-blocked slots: the same matches at [r >> 6, k, r & 63]
+        bv = p.unblock16(blocks, n).cpu().numpy().view(np.uint32)
+        assert (c3.cpu().numpy() == counts).all() and more3 == more, (tag, "blocked counts")
+        assert (bv[filed] == sev[filed]).all() and (bv[~filed] == 0xFFFFFFFF).all(), (tag, "blocked form")
+        assert (blocks.cpu().numpy().reshape(-1, slots, 64).transpose(0, 2, 1).reshape(-1, slots)[n:] == -1).all(), (tag, "rows beyond the batch")
         for i, w in want.items():
             k = min(len(w), slots)
             assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == w[:k], (tag, slots, i, counts[i], st[i].tolist(), en[i].tolist(), w[:8])

@@ -54,6 +54,9 @@ def check(p, o, rows, lens, tag):
         sev = se.cpu().numpy().view(np.uint32)
         filed = np.arange(slots)[None, :] < counts[:, None]
         assert ((sev & 0xFFFF)[filed] == st[filed]).all() and ((sev >> 16)[filed] == en[filed]).all(), (tag, "find-all packed")
+        c3, blocks, more3 = p.find_all_blocked16(rows, slots, lens)  # group-blocked slots behind the filter
+        bv = p.unblock16(blocks, n).cpu().numpy().view(np.uint32)
+        assert (c3.cpu().numpy() == counts).all() and more3 == more and (bv[filed] == sev[filed]).all() and (bv[~filed] == 0xFFFFFFFF).all(), (tag, "find-all blocked")
         for i, w in want.items():
             k = min(len(w), slots)
             assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == w[:k], (tag, "find-all", i, counts[i], st[i], en[i], w[:6])
