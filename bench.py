@@ -74,6 +74,11 @@ def make_pattern(workload):
         return (DFACompiler.compile("|".join(words), "Keywords3k"),
                 "union-of-3k-keywords (12 270 states) find() over UTF-16 rows (Java's strings): the byte program's n-gram filter, text narrowed as it is "
                 "loaded, candidates' walks out of L2", words)
+    if workload == "c3m16":
+        words = W.keywords_mixed(1000)
+        return (DFACompiler.compile("|".join(words), "KeywordsMixed3k"),
+                "union of 1000 Latin + 1000 Cyrillic + 1000 CJK keywords (6..8 code units; ~25 pages of the BMP) find() over mixed-script UTF-16 rows: "
+                "the WIDE n-gram filter (windows of four 16-bit code units), candidates' walks on the UTF-16 table out of L2", words)
     if workload == "c3x":
         words = W.keywords(3000, min_len=6, max_len=8)
         return (DFACompiler.compile("|".join(words), "Keywords3k"),
@@ -109,7 +114,7 @@ def make_rows(workload, words, row0, n_rows, device):
     """Shard [row0, row0 + n_rows) of the synthetic batch, generated on the GPU in slabs (into the process's one batch buffer)."""
     import torch
     from needle_amd import workload as W
-    dtype = torch.int16 if workload in ("c5", "c5w", "c3s16", "c3x16") else torch.uint8
+    dtype = torch.int16 if workload in ("c5", "c5w", "c3s16", "c3x16", "c3m16") else torch.uint8
     out = batch_buffer(n_rows, dtype, device)
     slab = 1 << 19
     for s in range(0, n_rows, slab):
@@ -118,6 +123,8 @@ def make_rows(workload, words, row0, n_rows, device):
             out[s:s + n] = W.digits_batch(torch, row0 + s, n, 256, device=device)
         elif workload in ("c3", "c3s", "c3x", "c3s16", "c3x16"):
             out[s:s + n] = W.keyword_batch(torch, words, row0 + s, n, 256, device=device)
+        elif workload == "c3m16":
+            out[s:s + n] = W.mixed_keyword_batch(torch, words, row0 + s, n, 256, device=device)
         elif workload == "c5w":
             out[s:s + n] = W.scriptseq_batch(torch, row0 + s, n, 256, device=device)
         else:
@@ -435,6 +442,9 @@ def measure(workload, args, ctx, headline):
     # needle_pattern_prefilter_state say whether they did)
     utf16_route = cw == 2 and which != "matches" and inf["max_char"]["matches"] < 0xFF and pattern.prefilter_state(which)["filter_launches"] > 0
     pre = pattern.prefilter_info(which) if (cw == 1 or utf16_route) and which != "matches" else {"on": 0}
+    # (UTF-16 rows of a pattern on several pages of the BMP: the WIDE filter -- windows of four code units)
+    if cw == 2 and not utf16_route and which != "matches" and pattern.utf16_route() is None and pattern.prefilter_state(which)["filter_launches"] > 0:
+        pre = pattern.prefilter_info(which, wide=True)
     kernel_name = "needle::ngram_kernel" if pre["on"] else "needle::scan_kernel"
     mode_names = {0: "packed functions", 1: "LDS table u8", 2: "LDS table u16", 3: "HBM table", 4: "LDS pair table", 5: "LDS hot rows + HBM table",
                   6: "compressed automaton in LDS (dense rows + exception records)"}
@@ -676,7 +686,7 @@ def measure(workload, args, ctx, headline):
                                            "note": "steady state of scan k + 1 on the launch stream beside the D2H of step k's results on a copy stream (two result sets); "
                                                    "find(): the one-dword form" if use_packed else "two result sets, D2H under the next scan"}
         del dsets, hsets
-    if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s", "c3x", "c3s16", "c3x16") and is_find:
+    if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s", "c3x", "c3s16", "c3x16", "c3m16") and is_find:
         # EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
         # the batch (needle_find_all.hip; for dictionaries behind the n-gram candidate filter -- c3s -- that kernel's find-all form,
         # needle_ngram.hip): counts + dense per-row slots.  Its own figure, never the `value`.
@@ -710,6 +720,23 @@ def measure(workload, args, ctx, headline):
         out["find_all"]["packed16"] = {"ms_per_step": dtp * 1e3, "matches_per_s": n_matches / dtp,
                                        "algorithmic_bytes": n_rows * (256 * cw + 4) + 4 * n_matches,
                                        "frac_of_hbm_peak": (n_rows * (256 * cw + 4) + 4 * n_matches) / dtp / 1e9 / HBM_PEAK_GBS}
+        # one dword per match in GROUP-BLOCKED slots (needle_find_all_blocked16_dev: slot k of 64 consecutive rows is one 256-byte run --
+        # the lanes of a group fill the same lines): the same matches, checked against the row-major form
+        fb = torch.full(((n_rows + 63) // 64, slots, 64), -1, dtype=torch.int32, device=dev)
+        pattern.find_all_blocked16(rows, slots, out=(fc, fb), want_more=False)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(k2):
+            pattern.find_all_blocked16(rows, slots, out=(fc, fb), want_more=False)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t) / k2
+        assert int(fc.sum().item()) == n_matches
+        for k in range(2):  # slots 0 and 1 of every row against the row-major form
+            assert fb[:, k, :].reshape(-1)[:n_rows][fc > k].eq(fs[:, k][fc > k]).all()
+        out["find_all"]["blocked16"] = {"ms_per_step": dtb * 1e3, "matches_per_s": n_matches / dtb,
+                                        "algorithmic_bytes": n_rows * (256 * cw + 4) + 4 * n_matches,
+                                        "frac_of_hbm_peak": (n_rows * (256 * cw + 4) + 4 * n_matches) / dtb / 1e9 / HBM_PEAK_GBS}
+        del fb
         # the counting pass alone (needle_count_matches_dev): the walk without filing
         t = time.perf_counter()
         for _ in range(k2):
@@ -751,8 +778,9 @@ def slim(w):
     fa = w.get("find_all")
     if fa:
         o["find_all"] = {"ms": _r(fa["ms_per_step"]), "frac": _r(fa["frac_of_hbm_peak"]), "packed16_ms": _r(fa["packed16"]["ms_per_step"]),
-                         "packed16_frac": _r(fa["packed16"]["frac_of_hbm_peak"]), "count_ms": _r(fa.get("count_pass_ms")),
-                         "Gmatch_s": _r(fa["packed16"]["matches_per_s"] / 1e9, 2), "matches": fa["matches"], "kernel": fa["kernel"].replace("needle::", "")}
+                         "packed16_frac": _r(fa["packed16"]["frac_of_hbm_peak"]), "blocked16_ms": _r(fa["blocked16"]["ms_per_step"]),
+                         "blocked16_frac": _r(fa["blocked16"]["frac_of_hbm_peak"]), "count_ms": _r(fa.get("count_pass_ms")),
+                         "Gmatch_s": _r(fa["blocked16"]["matches_per_s"] / 1e9, 2), "matches": fa["matches"], "kernel": fa["kernel"].replace("needle::", "")}
     cb = w.get("cpu_baseline")
     if cb:
         o["cpu_GBs"] = {"all": _r(cb["value"], 2), "cores": cb["cores"], "one": _r(cb["single_core"]["value"], 2), "kind": cb["kind"]}
@@ -823,7 +851,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16"], help="the headline workload")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16", "c3m16"], help="the headline workload")
     ap.add_argument("--also", default=None, help="comma list of further workloads measured into \"workloads\" "
                     "(default: c3,c3s,c3x,c5,c5w,c3s16,c3x16 at 1 GPU, c3 at N > 1; 'none' for profiling runs; c3s16 / c3x16: the c3s / c3x dictionaries over UTF-16 rows)")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")
@@ -893,7 +921,7 @@ def main():
         if int(ok.item()) == 0:
             ctx.comm = None
     if args.also is None:
-        also = ["c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16"] if world == 1 else ["c3"]
+        also = ["c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16", "c3m16"] if world == 1 else ["c3"]
         if args.regex or args.op or args.rows != 10_000_000:
             also = []
     else:

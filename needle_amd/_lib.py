@@ -10,7 +10,7 @@ NEEDLE_OK, ERR_INVALID, ERR_SYNTAX, ERR_COMPILE, ERR_UNSUPPORTED, ERR_DEVICE = 0
 
 EXPORTS = [
     "needle_version", "needle_last_error", "needle_device_count", "needle_trim_scratch", "needle_tuning_info", "needle_compile", "needle_pattern_from_tables",
-    "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_program_info", "needle_pattern_prefilter_info", "needle_pattern_set_prefilter", "needle_pattern_prefilter_state", "needle_pattern_utf16_route", "needle_pattern_match_lengths", "needle_pattern_find_all_transducer", "needle_pattern_get_class_map", "needle_pattern_get_table",
+    "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_program_info", "needle_pattern_prefilter_info", "needle_pattern_prefilter_info2", "needle_pattern_set_prefilter", "needle_pattern_prefilter_state", "needle_pattern_utf16_route", "needle_pattern_match_lengths", "needle_pattern_find_all_transducer", "needle_pattern_get_class_map", "needle_pattern_get_table",
     "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_find_packed16_dev", "needle_find_next_dev", "needle_find_all_dev", "needle_find_all_packed16_dev", "needle_find_all_blocked16_dev", "needle_count_matches_dev", "needle_find_all_csr_dev", "needle_find_all_host", "needle_find_all_packed16_host", "needle_find_all_csr_host",
     "needle_pack_start_end16_dev", "needle_unpack_start_end16_dev", "needle_matches_host",
     "needle_contained_in_host", "needle_find_host", "needle_find_compact_dev", "needle_find_compact_host", "needle_find_packed16_host", "needle_matcher_create", "needle_matcher_destroy",
@@ -65,6 +65,10 @@ class PrefilterInfo(ctypes.Structure):
                 [(k, ctypes.c_int32) for k in ("on2", "n_windows2", "bitmap2_bytes")] + [(k, ctypes.c_uint32) for k in ("m3", "addr_mask2")])
 
 
+class PrefilterInfo2(ctypes.Structure):
+    _fields_ = [("base", PrefilterInfo), ("wide", ctypes.c_int32), ("m1b", ctypes.c_uint32), ("m2b", ctypes.c_uint32)]
+
+
 _lib = None
 
 
@@ -99,6 +103,7 @@ def lib():
     L.needle_pattern_find_all_transducer.argtypes = [VP, ctypes.c_int, P(ctypes.c_int32), P(ctypes.c_int32), VP, ctypes.c_size_t, P(ctypes.c_size_t)]
     L.needle_pattern_program_info.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, P(ProgramInfo)]
     L.needle_pattern_prefilter_info.argtypes = [VP, ctypes.c_int, P(PrefilterInfo), VP]
+    L.needle_pattern_prefilter_info2.argtypes = [VP, ctypes.c_int, ctypes.c_int, P(PrefilterInfo2), VP, ctypes.c_size_t]
     L.needle_pattern_set_prefilter.argtypes = [VP, ctypes.c_int]
     L.needle_pattern_prefilter_state.argtypes = [VP, ctypes.c_int, P(PrefilterState)]
     L.needle_pattern_utf16_route.argtypes = [VP, P(ctypes.c_int32), P(ctypes.c_int32)]

@@ -168,14 +168,17 @@ struct needle_pattern {
     //          8 the find-all transducer (lock-step find-all, needle_find_all_ls.hip; absent when the pattern does not allow it)
     //          9 the filter program of an automaton that fits the LDS in no form (lower_filter_hbm: HBM-table layout + n-gram filter;
     //            W_CONTAINED_IN, or W_FORWARDS in the lengths form / for one-length patterns; absent when no filter can be built)
+    //          10 the WIDE filter program (lower_filter_wide: char_width 2 only -- UTF-16 rows of a pattern on several pages of the BMP:
+    //            windows of four code units, UTF-16 HBM-table program); absent when no filter can be built
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
     std::map<int, int> cus; // device -> CU count
     // needle_pattern_prefilter_info answers (lowering a big dictionary takes seconds): per `which`, filled once
     struct PrefilterCache {
         bool have = false;
         needle_prefilter_info info;
+        uint32_t m1b = 0, m2b = 0;
         std::vector<uint32_t> bitmap;
-    } pf_cache[4];
+    } pf_cache[8]; // [which]: the byte programs' filter; [4 + which]: the WIDE filter's (needle_pattern_prefilter_info2)
     std::mutex pf_mu;
     std::atomic<int> pf_mode{0}; // needle_pattern_set_prefilter: 0 auto (the flood watch decides), 1 on (never suspended), 2 off (never used)
     // UTF-16 rows behind a BYTE program (utf16_route): the pattern's one page and the byte that stands for every char outside it;
@@ -229,7 +232,7 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     // cw = 1 | page << 8: the BYTE program of the pattern rebased to one page of the BMP (UTF-16 rows narrowed on the fly: utf16_route)
     const int page = cw >> 8, cw_key = cw;
     cw &= 0xFF;
-    const bool wants_ml = variant == 6 || variant == 7 || variant == 8 || (variant == 9 && which == W_FORWARDS && p->t.fixed_len < 0);
+    const bool wants_ml = variant == 6 || variant == 7 || variant == 8 || ((variant == 9 || variant == 10) && which == W_FORWARDS && p->t.fixed_len < 0);
     const MatchLengths *ml67 = wants_ml ? pattern_ml(p) : nullptr; // (before p->mu: see ml_mu)
     std::lock_guard<std::mutex> lk(p->mu);
     const RefTables *tt = &p->t;
@@ -262,12 +265,12 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        if (variant == 9) {
-            if (wants_ml && !ml67) {
+        if (variant == 9 || variant == 10) {
+            if ((wants_ml && !ml67) || (variant == 10 && cw != 2)) {
                 *out = nullptr;
                 return NEEDLE_OK;
             }
-            dp.prog = lower_filter_hbm(*tt, (Which)which, ml67);
+            dp.prog = variant == 10 ? lower_filter_wide(*tt, (Which)which, ml67) : lower_filter_hbm(*tt, (Which)which, ml67);
             if (dp.prog.blob.empty() || !dp.prog.ng.p.on) { // (no filter: the ordinary program is what runs)
                 p->cache.emplace(key, DevProgram());
                 *out = nullptr;
@@ -552,6 +555,17 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
                    int32_t *d_end, void *stream, const int32_t *d_from = nullptr, uint32_t *d_end_state = nullptr,
                    bool no_backward = false, uint32_t *d_packed = nullptr);
 
+// The WIDE filter (lower_filter_wide) stands in for the UTF-16 scan kernels where the ordinary UTF-16 program is NOT a plain LDS table
+// (compressed automaton, hot rows + HBM table, HBM table): a latency-bound or collapsing walk.  NEEDLE_PREFILTER=2: for every
+// automaton that allows a filter (tests, A/B), as for 8-bit rows.  NEEDLE_PREFILTER_WIDE=0: never.
+static bool wide_filter_wanted(uint32_t ordinary_mode) {
+    // (NEEDLE_PREFILTER_UTF16=0: no filter in front of UTF-16 rows at all -- the one-page route and this one)
+    static const bool off = (getenv("NEEDLE_PREFILTER_WIDE") && atoi(getenv("NEEDLE_PREFILTER_WIDE")) == 0) ||
+                            (getenv("NEEDLE_PREFILTER_UTF16") && atoi(getenv("NEEDLE_PREFILTER_UTF16")) == 0);
+    if (off || ngram_level() <= 0) return false;
+    return ordinary_mode == MODE_SPARSE || ordinary_mode == MODE_HYBRID || ordinary_mode == MODE_GLOBAL || ngram_level() > 1;
+}
+
 // Few, long rows of an automaton too big for function composition: speculative stripes (needle_stripe.hip).  Returns
 // NEEDLE_OK with *done = false when the path does not apply or did not reach its fixpoint (the caller then walks the
 // rows one lane each).
@@ -759,6 +773,24 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     }
     rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
+    // UTF-16 rows of a pattern that lives on SEVERAL pages of the BMP (Latin + Cyrillic + CJK dictionaries: DFA.java:438-463, the reference's
+    // class map covers every code unit of any pattern) and whose automaton is too big for a plain LDS table: the WIDE filter -- windows of
+    // four 16-bit code units hashed as they stand, candidates verified on the UTF-16 HBM-table program (lower_filter_wide).  Without it these
+    // rows take hot rows + HBM table: 9.3 ms on the 10M-row batch where the one-page route runs at 1.1.  NEEDLE_PREFILTER_WIDE=0: never.
+    if (v->char_width == 2 && u16.page < 0 && wide_filter_wanted(fp->prog.hdr.mode) && op != OP_MATCHES && !d_from && !d_end_state && !no_backward &&
+        dict_env == 0 && v->row_stride * 2 < 8 * (uint64_t)kStripeBytes) {
+        const DevProgram *tp = nullptr;
+        rc = get_program(p, which, 2, 10, &tp, nullptr);
+        if (rc) return rc;
+        if (tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0)) {
+            const ScanArgs a = filter_scan_args(v, v->row_stride /* chars */, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed);
+            if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
+                HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream, 2, 0, 0));
+                HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
+                return NEEDLE_OK;
+            }
+        }
+    }
     if (d_end_state && (fp->prog.hdr.mode == MODE_HYBRID || fp->prog.hdr.mode == MODE_SPARSE)) {
         // the speculative-stripe pass wants every stripe's end state in the numbering of the HBM-table layout its fix-up
         // kernel walks (variant 3); the hot-rows and compressed forms number / encode states their own way
@@ -1388,22 +1420,39 @@ int needle_pattern_program_info(const needle_pattern *p, int which, int char_wid
 
 // The n-gram candidate filter (needle_ngram_host.h) of the program containedIn() (which = 1) / find() (which = 2) runs on 8-bit
 // rows, as run_dev chooses it: whether there is one, its parameters, why not, and (bitmap != NULL) the bitmap itself.
-static int prefilter_info_uncached(const needle_pattern *p, int which, needle_prefilter_info *o, std::vector<uint32_t> *bitmap_out);
+static int prefilter_info_uncached(const needle_pattern *p, int which, needle_prefilter_info *o, std::vector<uint32_t> *bitmap_out, bool wide,
+                                   uint32_t *m1b, uint32_t *m2b);
 
-int needle_pattern_prefilter_info(const needle_pattern *cp, int which, needle_prefilter_info *o, uint32_t *bitmap) {
+// wide: the filter of UTF-16 rows of a pattern on several pages of the BMP (lower_filter_wide).  At most cap_words bitmap words are written.
+int needle_pattern_prefilter_info2(const needle_pattern *cp, int which, int wide, needle_prefilter_info2 *o, uint32_t *bitmap, size_t cap_words) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
     if (which != W_CONTAINED_IN && which != W_FORWARDS) return fail(NEEDLE_ERR_INVALID, "which must be 1 (contained_in) or 2 (forwards)");
     std::lock_guard<std::mutex> lk(p->pf_mu);
-    needle_pattern::PrefilterCache &c = p->pf_cache[which];
+    needle_pattern::PrefilterCache &c = p->pf_cache[(wide ? 4 : 0) + which];
     if (!c.have) {
-        const int rc = prefilter_info_uncached(p, which, &c.info, &c.bitmap);
+        const int rc = prefilter_info_uncached(p, which, &c.info, &c.bitmap, wide != 0, &c.m1b, &c.m2b);
         if (rc) return rc;
         c.have = true;
     }
-    *o = c.info;
-    if (bitmap && c.info.on) memcpy(bitmap, c.bitmap.data(), c.bitmap.size() * 4);
+    memset(o, 0, sizeof(*o));
+    o->base = c.info;
+    o->wide = wide ? 1 : 0;
+    o->m1b = c.m1b, o->m2b = c.m2b;
+    if (bitmap && c.info.on) memcpy(bitmap, c.bitmap.data(), std::min(cap_words, c.bitmap.size()) * 4);
     return NEEDLE_OK;
+}
+
+// (the original contract: the FIRST level's bitmap_bytes / 4 words only -- the second level's come through needle_pattern_prefilter_info2,
+// which takes the caller's capacity)
+int needle_pattern_prefilter_info(const needle_pattern *cp, int which, needle_prefilter_info *o, uint32_t *bitmap) {
+    if (!o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    needle_prefilter_info2 i2;
+    int rc = needle_pattern_prefilter_info2(cp, which, 0, &i2, nullptr, 0);
+    if (rc) return rc;
+    *o = i2.base;
+    if (bitmap && o->on) rc = needle_pattern_prefilter_info2(cp, which, 0, &i2, bitmap, (size_t)o->bitmap_bytes / 4);
+    return rc;
 }
 
 int needle_pattern_set_prefilter(needle_pattern *p, int mode) {
@@ -1449,12 +1498,20 @@ int needle_pattern_prefilter_state(const needle_pattern *cp, int which, needle_p
     return NEEDLE_OK;
 }
 
-static int prefilter_info_uncached(const needle_pattern *p, int which, needle_prefilter_info *o, std::vector<uint32_t> *bitmap_out) {
+static int prefilter_info_uncached(const needle_pattern *p, int which, needle_prefilter_info *o, std::vector<uint32_t> *bitmap_out, bool wide,
+                                   uint32_t *m1b, uint32_t *m2b) {
     memset(o, 0, sizeof(*o));
+    *m1b = *m2b = 0;
     const bool backward = which == W_FORWARDS && p->t.fixed_len < 0;
-    Program pr = lower(p->t, (Which)which, 1, max_prog_lds(), false, backward);
+    Program pr;
     bool usable = which == W_CONTAINED_IN || p->t.fixed_len >= 0;
-    if (backward && find_lengths_for(pr.hdr.mode)) {
+    if (wide) { // (as run_dev / find_all_one_pass build it; whether a batch takes it also depends on the ordinary UTF-16 program's mode)
+        const MatchLengths *ml = backward ? pattern_ml(p) : nullptr;
+        if (p->t.class_map.size() == 65536 && (!backward || ml)) pr = lower_filter_wide(p->t, (Which)which, ml), usable = true;
+        else memset(&pr.hdr, 0, sizeof(pr.hdr)), memset(&pr.ng.p, 0, sizeof(pr.ng.p)), pr.hdr.mode = MODE_GLOBAL;
+    } else
+    pr = lower(p->t, (Which)which, 1, max_prog_lds(), false, backward);
+    if (!wide && backward && find_lengths_for(pr.hdr.mode)) {
         if (const MatchLengths *ml = pattern_ml(p)) {
             Program lp = lower_match_lengths(p->t, *ml, 1, max_prog_lds(), false);
             static const bool force_tables = getenv("NEEDLE_FIND_LENGTHS") && atoi(getenv("NEEDLE_FIND_LENGTHS")) > 1;
@@ -1462,7 +1519,7 @@ static int prefilter_info_uncached(const needle_pattern *p, int which, needle_pr
             if (!lp.blob.empty() && !pair_lost) pr = std::move(lp), usable = true;
         }
     }
-    if ((pr.hdr.mode == MODE_HYBRID || pr.hdr.mode == MODE_GLOBAL) && ngram_level() > 0) {
+    if (!wide && (pr.hdr.mode == MODE_HYBRID || pr.hdr.mode == MODE_GLOBAL) && ngram_level() > 0) {
         // an automaton that fits the LDS in no form: the filter program walks its table out of HBM / L2 (lower_filter_hbm)
         const MatchLengths *ml = backward ? pattern_ml(p) : nullptr;
         if (!backward || ml) {
@@ -1483,6 +1540,7 @@ static int prefilter_info_uncached(const needle_pattern *p, int which, needle_pr
     o->n_windows = (int32_t)f.p.n_grams;
     o->bitmap_bytes = (int32_t)f.p.bm_bytes;
     o->m1 = f.p.m1, o->m2 = f.p.m2, o->addr_shift = f.p.addr_shift, o->addr_mask = f.p.addr_mask;
+    *m1b = f.p.m1b, *m2b = f.p.m2b;
     o->on2 = (int32_t)(o->on && f.p.on2 ? 1 : 0);
     if (o->on2) o->n_windows2 = (int32_t)f.p.n_grams2, o->bitmap2_bytes = (int32_t)f.p.bm2_bytes, o->m3 = f.p.m3, o->addr_mask2 = f.p.addr_mask2;
     snprintf(o->why, sizeof(o->why), "%s", f.p.on ? "" : (f.why.empty() ? (ngram_level() > 0 ? "not a mode the filter is built for" : "NEEDLE_PREFILTER=0") : f.why.c_str()));
@@ -1726,16 +1784,25 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     static const bool fa_filter = !(getenv("NEEDLE_FIND_ALL_FILTER") && atoi(getenv("NEEDLE_FIND_ALL_FILTER")) == 0);
     // (UTF-16 rows of a pattern on one page of the BMP: that page's byte programs, the text narrowed as it is loaded -- utf16_route)
     const Utf16Route u16 = v->char_width == 2 ? utf16_route(p) : Utf16Route();
-    if (fa_filter && (count_only || d_offsets || slots) && (v->char_width == 1 || (v->char_width == 2 && u16.page >= 0)) && ngram_level() > 0 &&
-        (p->t.fixed_len >= 0 || find_lengths_for(MODE_SPARSE))) {
+    if (fa_filter && (count_only || d_offsets || slots) && ngram_level() > 0 && (p->t.fixed_len >= 0 || find_lengths_for(MODE_SPARSE))) {
         const DevProgram *sp = nullptr;
         int cus = 0;
+        if (v->char_width == 2 && u16.page < 0) { // several pages of the BMP: the WIDE filter, where find() would take it (run_dev)
+            const DevProgram *op16 = nullptr;
+            rc = get_program(p, W_FORWARDS, 2, p->t.fixed_len < 0 ? 2 : 0, &op16, &cus);
+            if (rc) return rc;
+            if (op16 && wide_filter_wanted(op16->prog.hdr.mode)) {
+                rc = get_program(p, W_FORWARDS, 2, 10, &sp, &cus);
+                if (rc) return rc;
+            }
+        } else {
         const int cw8 = 1 | ((v->char_width == 2 ? u16.page : 0) << 8);
         rc = get_program(p, W_FORWARDS, cw8, p->t.fixed_len >= 0 ? 0 : 7, &sp, &cus);
         if (rc) return rc;
         if (!(sp && sp->d_ng && sp->prog.ng.p.on)) { // an automaton that fits the LDS in no form: the filter with its walks out of HBM / L2
             rc = get_program(p, W_FORWARDS, cw8, 9, &sp, &cus);
             if (rc) return rc;
+        }
         }
         if (sp && sp->d_ng && sp->prog.ng.p.on && ngram_find_all_lds_bytes(sp->prog.hdr, sp->prog.ng.p)) {
             // (UTF-16 rows: the stride in CHARS -- launch_ngram_find_all with char_width 2)

@@ -426,6 +426,7 @@ namespace {
 struct LowerAux {
     std::vector<uint16_t> next;
     std::vector<uint8_t> cmap8;
+    std::vector<uint8_t> cmap16; // UTF-16 lowerings: the column of every code unit (65 536 entries)
     int n_dev = 0, n_cols = 0, start = 0, accept_lo = 0, dead_hi = 0;
     bool ml_in_hbm = false; // lower_filter_hbm: a lengths program may keep the HBM-table layout (pend[] then rides behind the table, in HBM)
 };
@@ -469,6 +470,22 @@ Program lower_filter_hbm(const RefTables &t, Which which, const MatchLengths *ml
     if (p.blob.empty() || p.hdr.mode != MODE_GLOBAL || ngram_level() <= 0) return p;
     p.ng = build_ngram_filter(aux.next.data(), aux.n_dev, aux.n_cols, aux.cmap8.data(), aux.start, aux.accept_lo, aux.dead_hi, which == W_CONTAINED_IN,
                               p.hdr.lds_bytes);
+    return p;
+}
+
+// The WIDE filter program (needle_ngram.h): UTF-16 rows of a pattern that lives on MORE than one page of the BMP (Latin + Cyrillic + CJK
+// keyword dictionaries: DFA.java:438-463 -- the reference's class map covers all 65 536 code units of any pattern, its prefilters run on any
+// String, DFAClassBuilder.java:365-376).  The filter hashes windows of four 16-bit code units as they stand (no narrowing to a byte
+// program); its candidates are verified on the UTF-16 HBM-table program -- the two-level page map (512 bytes + 256 per distinct page) is
+// all the LDS holds of the automaton.  ng.p.on = 0: no filter.
+Program lower_filter_wide(const RefTables &t, Which which, const MatchLengths *ml) {
+    LowerAux aux;
+    aux.ml_in_hbm = true;
+    Program p = lower_core(t, which, 2, 0, false, false, false, ml, &aux);
+    memset(&p.ng.p, 0, sizeof(p.ng.p));
+    if (p.blob.empty() || p.hdr.mode != MODE_GLOBAL || ngram_level() <= 0 || aux.cmap16.size() != 65536) return p;
+    p.ng = build_ngram_filter(aux.next.data(), aux.n_dev, aux.n_cols, aux.cmap8.data(), aux.start, aux.accept_lo, aux.dead_hi, which == W_CONTAINED_IN,
+                              p.hdr.lds_bytes, aux.cmap16.data());
     return p;
 }
 
@@ -550,6 +567,10 @@ static Program lower_core(const RefTables &t, Which which, int char_width, size_
     const ColumnMaps cm = column_maps(t, d, char_width);
     p.hdr.n_pages = (uint32_t)(cm.pages.size() / 256);
     if (aux) aux->cmap8 = cm.cmap8;
+    if (aux && char_width == 2) {
+        aux->cmap16.resize(65536);
+        for (int c = 0; c < 65536; ++c) aux->cmap16[(size_t)c] = cm.pages[(size_t)cm.ptab[c >> 8] * 256 + (c & 255)];
+    }
 
     if (global_walk) {
         // backward automaton of find(): only the uint16 table, read from HBM/L2 (its column maps travel inside the

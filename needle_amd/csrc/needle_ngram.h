@@ -37,6 +37,10 @@ struct NgramParams {
     uint32_t addr_mask2;  // byte offset of the word inside the second bitmap = u2 & addr_mask2
     uint32_t bm2_bytes;   // its size (power of two; it follows the first bitmap in the device buffer)
     uint32_t n_grams2;    // distinct 5-byte windows (informational)
+    // WIDE filter (UTF-16 rows of a pattern on several pages of the BMP): a window is four 16-bit code units = two dwords x0 (units 0, 1)
+    // and x1 (units 2, 3); u = dot2(x0, m1 | m2 << 16) + dot2(x1, m1b | m2b << 16) -- two v_dot2_u32_u16, the second one accumulating;
+    // the second level adds unit(q - 5) * m3.  Everything else (bitmaps, bits, queues) as for bytes.
+    uint32_t wide, m1b, m2b;
 };
 
 // LDS of the filter kernel (needle_ngram.hip), per wave: the candidate queue + one u64 result slot per row of the group
@@ -77,6 +81,9 @@ inline bool ngram_layout(uint32_t prog_bytes, uint32_t bm_bytes, NgramLayout *ou
 // and 2 as they stand (SDWA).  With ~2000 windows in 8192 words a text window that is not in the set passes with probability
 // ~0.12 % (one bit: 0.76 %) -- every pass costs a 16-byte re-read of the row and a share of an automaton run.
 inline uint32_t ngram_hash_host(uint32_t x, uint32_t m1, uint32_t m2) { return (x & 0xFFFFu) * m1 + (x >> 16) * m2; }
+inline uint32_t ngram_hash16_host(uint32_t x0, uint32_t x1, uint32_t m1, uint32_t m2, uint32_t m1b, uint32_t m2b) {
+    return (x0 & 0xFFFFu) * m1 + (x0 >> 16) * m2 + (x1 & 0xFFFFu) * m1b + (x1 >> 16) * m2b;
+}
 inline uint32_t ngram_word_index(uint32_t u, uint32_t addr_mask) { return (u & addr_mask) >> 2; }
 inline uint32_t ngram_word_bits(uint32_t u, uint32_t addr_shift) { return 1u << ((u >> addr_shift) & 31u) | 1u << ((u >> (addr_shift - 8u)) & 31u); }
 
@@ -100,6 +107,18 @@ inline uint32_t ngram_hash2_host(uint32_t x, uint32_t c5, uint32_t m1, uint32_t 
 __device__ __forceinline__ uint32_t ngram_probe2(uint32_t x, uint32_t c5, uint32_t m, uint32_t m3, uint32_t addr_mask2, uint32_t bm2_base) {
     uint32_t u;
     asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(u) : "v"(x), "v"(m));
+    u += c5 * m3;
+    const uint32_t a = (u & addr_mask2) | bm2_base;
+    const uint32_t w = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a;
+    return (w >> ((u >> 24) & 31u)) & (w >> ((u >> 16) & 31u)) & 1u;
+}
+
+// WIDE second level: the window's two dwords x0, x1 + the code unit c5 in front of them.
+__device__ __forceinline__ uint32_t ngram_probe2_16(uint32_t x0, uint32_t x1, uint32_t c5, uint32_t mA, uint32_t mB, uint32_t m3, uint32_t addr_mask2,
+                                                    uint32_t bm2_base) {
+    uint32_t u;
+    asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(u) : "v"(x0), "v"(mA));
+    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(u) : "v"(x1), "v"(mB), "v"(u));
     u += c5 * m3;
     const uint32_t a = (u & addr_mask2) | bm2_base;
     const uint32_t w = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a;
@@ -147,6 +166,41 @@ __device__ __forceinline__ uint32_t ngram_piece(uint32_t log, uint32_t pw, uint3
         uint32_t r1, r2;
         asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r1) : "v"(u[i]), "v"(wv[i])); // w >> (u >> 24 & 31)
         asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r2) : "v"(u[i]), "v"(wv[i])); // w >> (u >> 16 & 31)
+        log = __builtin_amdgcn_alignbit(r1 & r2, log, 1);
+    }
+    return log;
+}
+
+// The WIDE form: 16 UTF-16 code units held by one lane as eight dwords (lo, hi; pw = the dword before them: the previous lane's hi[3]).  A
+// window is four code units = two dwords (x0, x1), u = dot2(x0, mA) + dot2(x1, mB): with S = 2 every window is a pair of adjacent dwords and
+// each dword's first product serves the next window -- two v_dot2_u32_u16 per dword, no v_alignbit; S = 4: the pairs (0, 1), (2, 3), ...
+// Same log layout as ngram_piece: 16 / S verdicts shifted in from the top, the piece's last window at bit 31.
+typedef uint32_t ng_u32x4_t __attribute__((ext_vector_type(4)));
+template <int S>
+__device__ __forceinline__ uint32_t ngram_piece16(uint32_t log, uint32_t pw, const ng_u32x4_t &lo, const ng_u32x4_t &hi, uint32_t mA, uint32_t mB,
+                                                  uint32_t addr_mask, uint32_t bm_base) {
+    static_assert(S == 2 || S == 4, "one window every 2 or 4 code units");
+    constexpr int NWIN = 16 / S;
+    const uint32_t d[9] = {pw, lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; // d[i + 1] = dword i of the 16 units
+    uint32_t u[NWIN], wv[NWIN];
+#pragma unroll
+    for (int i = 0; i < NWIN; ++i) {
+        const uint32_t x0 = S == 2 ? d[i] : d[2 * i + 1], x1 = S == 2 ? d[i + 1] : d[2 * i + 2];
+        uint32_t t;
+        asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(t) : "v"(x0), "v"(mA));
+        asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(u[i]) : "v"(x1), "v"(mB), "v"(t));
+        uint32_t a;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(u[i]), "s"(addr_mask), "v"(bm_base));
+        wv[i] = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): all of the piece's bitmap words
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NWIN; ++i) {
+        uint32_t r1, r2;
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r1) : "v"(u[i]), "v"(wv[i]));
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r2) : "v"(u[i]), "v"(wv[i]));
         log = __builtin_amdgcn_alignbit(r1 & r2, log, 1);
     }
     return log;

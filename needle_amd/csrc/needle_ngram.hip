@@ -60,8 +60,12 @@ typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 
 // CW = 2: UTF-16 rows of a pattern whose chars all lie below 0xFF -- every offset, stride and length below is in CHARS, the text is
 // narrowed to bytes where it is loaded (the probe stream, the candidates' pieces, the second-level windows), nothing else differs.
-template <int OP, int MODE, int S, int CW = 1>
+// WIDE (CW = 2 only): the pattern lives on several pages of the BMP -- nothing is narrowed: the windows are four 16-bit code units hashed as
+// they stand (needle_ngram.h ngram_piece16), the candidates walk the UTF-16 program (two-level page map in LDS, table out of HBM / L2).
+template <int OP, int MODE, int S, int CW = 1, bool WIDE = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramArgs A) {
+    static_assert(!WIDE || (CW == 2 && MODE == MODE_GLOBAL), "the wide filter verifies on the UTF-16 HBM-table program");
+    constexpr int TW = WIDE ? 2 : 1; // width of the code units the probes and the walks see
     const ScanArgs &a = A.a;
     constexpr int NW = 16 / S; // windows per 16-byte piece
     const int tid = threadIdx.x;
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     const uint32_t sbase = qbase + ((FA && !A.ng.on2) ? 1u : 2u) * kNgQueue * 4u; // find / containedIn: the rows' slots; find-all: two candidate slots per row ...
     const uint32_t cbase = sbase + 64u * kNgRowSlots * 8u; // ... and a counter per row
     const uint32_t mm = A.ng.m1 | A.ng.m2 << 16, amask = A.ng.addr_mask;
+    const uint32_t mmB = A.ng.m1b | A.ng.m2b << 16; // (wide: the multipliers of a window's second dword)
     const uint32_t K = A.ng.warm;
 #ifdef NEEDLE_TUNING
     const uint32_t dbg = A.dbg & 15u, full_set = (A.dbg & 16u) ? 32u : 64u;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         base = (uint64_t)base < room ? base : (uint32_t)room;
         auto step = [&](uint32_t colv, uint32_t pos) __attribute__((always_inline)) {
             const bool go = !over && pos >= cur && pos < lim;
-            const uint32_t ns = apply<MODE, 1>(wk, st, colv);
+            const uint32_t ns = apply<MODE, TW>(wk, st, colv);
             st = go ? ns : st;
             const bool acc_any = go && st >= accept_lo;
             const bool acc = acc_any && pos + 1u >= qn;
@@ -225,12 +230,22 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             }
         };
         for (;;) {
+            uint32_t col[16];
+            if (WIDE) { // 16 code units = two 16-byte pieces, their columns through the page map
+                const u32x4 t0 = *(const u32x4_u *)(rowp + base * 2u), t1 = *(const u32x4_u *)(rowp + base * 2u + 16u);
+                const uint32_t w0[4] = {t0[0], t0[1], t0[2], t0[3]}, w1[4] = {t1[0], t1[1], t1[2], t1[3]};
+                uint32_t c0[8], c1[8];
+                piece_lookups<MODE, 2, false>(wk, w0, 0u, 0u, 0u, c0);
+                piece_lookups<MODE, 2, false>(wk, w1, 0u, 0u, 0u, c1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) col[k] = c0[k], col[8 + k] = c1[k];
+            } else {
             u32x4 tx = {0, 0, 0, 0};
             if (dbg != 3u) tx = text16(rowp + base * CW);
             if (dbg == 2u) over = over || tx[0] != 0x12345678u; // (the text is waited for, the walk is not taken)
             const uint32_t w[4] = {tx[0], tx[1], tx[2], tx[3]};
-            uint32_t col[16];
             piece_lookups<MODE, 1, false>(wk, w, 0u, 0u, 0u, col);
+            }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 step(col[k], base + (uint32_t)k);
@@ -307,7 +322,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         const uint8_t *rowp = a.rows + ((grp << 6) + row) * a.stride_bytes * CW;
         const bool deep = qn >= 5u;
         uint32_t w, c5;
-        if (CW == 1) {
+        if (WIDE) { // the window's two dwords as they stand (qn is even: they are aligned) + the unit in front of them
+            typedef uint16_t u16_u __attribute__((aligned(1)));
+            const uint32_t x0 = *(const u32_u *)(rowp + (qn - 4u) * 2u), x1 = *(const u32_u *)(rowp + (qn - 2u) * 2u);
+            c5 = deep ? (uint32_t)*(const u16_u *)(rowp + (qn - 5u) * 2u) : 0u;
+            return !deep || ngram_probe2_16(x0, x1, c5, mm, mmB, m3, amask2, bm2_base) != 0u;
+        } else if (CW == 1) {
             w = *(const u32_u *)(rowp + qn - 4u);
             c5 = deep ? (uint32_t)rowp[qn - 5u] : 0u;
         } else {
@@ -353,10 +373,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 asm volatile("" ::: "memory");
                 R[k] = load_next();
                 asm volatile("" ::: "memory");
+                if (WIDE) {
+                    const uint32_t pw = ngram_prev_dword(raw.hi[3], carry);
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)raw.hi[3], 63);
+                    log = ngram_piece16<S>(log, pw, raw.lo, raw.hi, mm, mmB, amask, bm_base);
+                } else {
                 const u32x4 v = CW == 1 ? raw.lo : narrow16(raw.lo, raw.hi, A.page4, A.sub4);
                 const uint32_t pw = ngram_prev_dword(v[3], carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);
                 log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], mm, amask, bm_base);
+                }
             }
             const uint32_t po0 = (u0 << 10) + lane16; // byte offset of this lane's piece of the batch's first unit
             if (NW * kNgPF < 32) log >>= 32 - NW * kNgPF; // window wi of unit j at bit j * NW + wi
@@ -513,9 +539,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     }
 }
 
-template <int OP, int MODE, int S, int CW>
+template <int OP, int MODE, int S, int CW, bool WIDE = false>
 static hipError_t launch_ng(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
-    auto k = ngram_kernel<OP, MODE, S, CW>;
+    auto k = ngram_kernel<OP, MODE, S, CW, WIDE>;
     static thread_local uint64_t configured = 0;
     if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(n_cus), dim3(kWavesPerBlock * 64), lds, stream, A);
@@ -530,6 +556,10 @@ static hipError_t launch_ng_s(const NgramArgs &A, int n_cus, size_t lds, hipStre
 
 template <int OP>
 static hipError_t launch_ng_m(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
+    if (A.ng.wide) { // UTF-16 rows, windows of four code units, walks on the UTF-16 HBM-table program (lower_filter_wide)
+        if (A.char_width != 2 || A.a.hdr.mode != MODE_GLOBAL) return hipErrorInvalidValue;
+        return A.ng.stride == 4 ? launch_ng<OP, MODE_GLOBAL, 4, 2, true>(A, n_cus, lds, stream) : launch_ng<OP, MODE_GLOBAL, 2, 2, true>(A, n_cus, lds, stream);
+    }
     switch (A.a.hdr.mode) {
     case MODE_TABLE8: return launch_ng_s<OP, MODE_TABLE8>(A, n_cus, lds, stream);
     case MODE_TABLE16: return launch_ng_s<OP, MODE_TABLE16>(A, n_cus, lds, stream);

@@ -29,7 +29,11 @@ uint64_t splitmix(uint64_t &s) {
 } // namespace
 
 NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, const uint8_t *cmap8, int start, int accept_lo, int dead_hi,
-                               bool absorbing, size_t prog_lds_bytes) {
+                               bool absorbing, size_t prog_lds_bytes, const uint8_t *cmap16) {
+    // cmap16 != nullptr: the WIDE filter -- windows of four UTF-16 code units (needle_ngram.h), columns expanded to the units of the BMP
+    const bool wide = cmap16 != nullptr;
+    const int n_sym = wide ? 65536 : 256;
+    const uint8_t *cmap = wide ? cmap16 : cmap8;
     NgramFilter f;
     memset(&f.p, 0, sizeof(f.p));
     auto no = [&](const char *why) {
@@ -42,11 +46,11 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     if (n_dev <= 1 || start <= 0 || start >= n_dev) return no("no automaton");
     if (start >= accept_lo) return no("the start state accepts");
     if (!ngram_layout((uint32_t)prog_lds_bytes, 4096u, nullptr)) return no("no LDS left for a bitmap");
-    // columns some byte maps to, and their bytes
-    std::vector<std::vector<uint8_t>> bytes_of(n_cols);
-    for (int c = 0; c < 256; ++c) {
-        if (cmap8[c] >= n_cols) return no("column map out of range");
-        bytes_of[cmap8[c]].push_back((uint8_t)c);
+    // columns some code unit maps to, and their units
+    std::vector<std::vector<uint16_t>> bytes_of(n_cols);
+    for (int c = 0; c < n_sym; ++c) {
+        if (cmap[c] >= n_cols) return no("column map out of range");
+        bytes_of[cmap[c]].push_back((uint16_t)c);
     }
     std::vector<int> cols;
     for (int k = 0; k < n_cols; ++k)
@@ -170,23 +174,30 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     if (!enum_labels(kN, labels)) return no("too many window paths");
     if (labels.empty()) return no("no windows");
 
-    // ---- expand columns to bytes
-    std::vector<uint32_t> grams;
+    // ---- expand columns to code units (16 bits per position; 8-bit programs: values below 256)
+    std::vector<uint64_t> grams;
     for (uint64_t lab : labels) {
-        const std::vector<uint8_t> *b[kN];
+        const std::vector<uint16_t> *b[kN];
         size_t n = 1;
         for (int i = 0; i < kN; ++i) {
             b[i] = &bytes_of[(lab >> (8 * i)) & 255u];
             n *= b[i]->size();
+            if (n > kMaxWindows) return no("too many byte windows");
         }
         if (grams.size() + n > kMaxWindows) return no("too many byte windows");
-        for (uint8_t c0 : *b[0])
-            for (uint8_t c1 : *b[1])
-                for (uint8_t c2 : *b[2])
-                    for (uint8_t c3 : *b[3]) grams.push_back((uint32_t)c0 | (uint32_t)c1 << 8 | (uint32_t)c2 << 16 | (uint32_t)c3 << 24);
+        for (uint16_t c0 : *b[0])
+            for (uint16_t c1 : *b[1])
+                for (uint16_t c2 : *b[2])
+                    for (uint16_t c3 : *b[3]) grams.push_back((uint64_t)c0 | (uint64_t)c1 << 16 | (uint64_t)c2 << 32 | (uint64_t)c3 << 48);
     }
     std::sort(grams.begin(), grams.end());
     grams.erase(std::unique(grams.begin(), grams.end()), grams.end());
+    // the hash of a window (needle_ngram.h): 8-bit text: the four bytes as one dword, two 16-bit multipliers; wide: two dwords, four
+    auto sym = [](uint64_t g, int i) -> uint32_t { return (uint32_t)(g >> (16 * i)) & 0xFFFFu; };
+    auto hash_of = [&](uint64_t g, uint32_t m1, uint32_t m2, uint32_t m1b, uint32_t m2b) -> uint32_t {
+        if (wide) return ngram_hash16_host(sym(g, 0) | sym(g, 1) << 16, sym(g, 2) | sym(g, 3) << 16, m1, m2, m1b, m2b);
+        return ngram_hash_host(sym(g, 0) | sym(g, 1) << 8 | sym(g, 2) << 16 | sym(g, 3) << 24, m1, m2);
+    };
 
     // ---- bitmap size: the largest power of two that fits behind the program (ngram_layout), at most 64 KiB; useless when it fills up
     size_t bm_bytes = 65536;
@@ -200,15 +211,14 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
 
     // ---- multipliers: the text is not ours to know; judge a pair by the windows over the SAME bytes (per position) that are
     // not in the set -- near misses are what real text is made of
-    std::vector<uint8_t> alpha[kN];
+    std::vector<uint16_t> alpha[kN];
     {
-        bool seen[kN][256];
-        memset(seen, 0, sizeof(seen));
-        for (uint32_t g : grams)
-            for (int i = 0; i < kN; ++i) seen[i][(g >> (8 * i)) & 255u] = true;
+        std::vector<uint8_t> seen((size_t)kN * 65536, 0);
+        for (uint64_t g : grams)
+            for (int i = 0; i < kN; ++i) seen[(size_t)i * 65536 + sym(g, i)] = 1;
         for (int i = 0; i < kN; ++i)
-            for (int c = 0; c < 256; ++c)
-                if (seen[i][c]) alpha[i].push_back((uint8_t)c);
+            for (int c = 0; c < n_sym; ++c)
+                if (seen[(size_t)i * 65536 + c]) alpha[i].push_back((uint16_t)c);
     }
     // (16-bit odd multipliers: the word's address is bits 2 .. of u, its bit u's bits 24 .. 28 -- both halves of the window reach both)
     static const uint32_t kMul[][2] = {{0x9E37u, 0x85EBu}, {0xB529u, 0x68E3u}, {0x7FEBu, 0xC2B3u}, {0xD35Bu, 0x1B87u}, {0xA24Bu, 0xE655u}, {0x2C1Bu, 0x5BD1u},
@@ -216,50 +226,55 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
                                        {0x629Bu, 0x367Du}, {0x9159u, 0x152Fu}, {0xF70Fu, 0x4FA5u}, {0x8EB5u, 0x7B3Du}};
     size_t best_fp = (size_t)-1;
     std::vector<uint32_t> bm(bm_bytes / 4);
-    for (const auto &mm : kMul) {
+    const size_t n_mul = sizeof(kMul) / sizeof(kMul[0]);
+    for (size_t mi = 0; mi < n_mul; ++mi) {
+        const uint32_t *mm = kMul[mi], *mb = kMul[(mi + 5) % n_mul]; // (wide: the second dword of a window has multipliers of its own)
         std::fill(bm.begin(), bm.end(), 0u);
-        for (uint32_t g : grams) {
-            const uint32_t u = ngram_hash_host(g, mm[0], mm[1]);
+        for (uint64_t g : grams) {
+            const uint32_t u = hash_of(g, mm[0], mm[1], mb[0], mb[1]);
             bm[ngram_word_index(u, f.p.addr_mask)] |= ngram_word_bits(u, f.p.addr_shift);
         }
         uint64_t seed = 0x5EED1234u;
         size_t fp = 0;
         for (int t = 0; t < 65536; ++t) {
             const uint64_t r = splitmix(seed);
-            uint32_t x = 0;
-            for (int i = 0; i < kN; ++i) x |= (uint32_t)alpha[i][(r >> (16 * i)) % alpha[i].size()] << (8 * i);
-            const uint32_t u = ngram_hash_host(x, mm[0], mm[1]), bits = ngram_word_bits(u, f.p.addr_shift);
+            uint64_t x = 0;
+            for (int i = 0; i < kN; ++i) x |= (uint64_t)alpha[i][(r >> (16 * i)) % alpha[i].size()] << (16 * i);
+            const uint32_t u = hash_of(x, mm[0], mm[1], mb[0], mb[1]), bits = ngram_word_bits(u, f.p.addr_shift);
             fp += (bm[ngram_word_index(u, f.p.addr_mask)] & bits) == bits;
         }
         if (fp < best_fp) {
             best_fp = fp;
             f.p.m1 = mm[0], f.p.m2 = mm[1];
+            f.p.m1b = wide ? mb[0] : 0u, f.p.m2b = wide ? mb[1] : 0u;
             f.bitmap = bm;
         }
     }
+    f.p.wide = wide ? 1u : 0u;
     // ---- second level (needle_ngram.h): the 5-byte windows, same construction one column deeper -- when every match is long enough
     // for them to lie inside it (else their first column is "any char" and they select nothing)
     f.p.on2 = 0;
     static const bool level2_on = !(getenv("NEEDLE_PREFILTER_LEVEL2") && atoi(getenv("NEEDLE_PREFILTER_LEVEL2")) == 0);
     if (level2_on && min_len >= kN + 1 + S - 1) {
         std::unordered_set<uint64_t> labels5;
-        std::vector<uint64_t> grams5; // bytes 0 .. 4, 8 bits each: byte 0 = the char in front of the 4-byte window
+        std::vector<std::pair<uint64_t, uint32_t>> grams5; // (the 4-unit window, the unit in front of it)
         bool ok5 = enum_labels(kN + 1, labels5) && !labels5.empty();
         for (uint64_t lab : labels5) {
             if (!ok5) break;
-            const std::vector<uint8_t> *b[kN + 1];
+            const std::vector<uint16_t> *b[kN + 1];
             size_t n = 1;
             for (int i = 0; i <= kN; ++i) {
                 b[i] = &bytes_of[(lab >> (8 * i)) & 255u];
                 n *= b[i]->size();
+                if (n > kMaxWindows) break;
             }
-            if (grams5.size() + n > kMaxWindows) { ok5 = false; break; }
-            for (uint8_t c0 : *b[0])
-                for (uint8_t c1 : *b[1])
-                    for (uint8_t c2 : *b[2])
-                        for (uint8_t c3 : *b[3])
-                            for (uint8_t c4 : *b[4])
-                                grams5.push_back((uint64_t)c0 | (uint64_t)c1 << 8 | (uint64_t)c2 << 16 | (uint64_t)c3 << 24 | (uint64_t)c4 << 32);
+            if (n > kMaxWindows || grams5.size() + n > kMaxWindows) { ok5 = false; break; }
+            for (uint16_t c0 : *b[0])
+                for (uint16_t c1 : *b[1])
+                    for (uint16_t c2 : *b[2])
+                        for (uint16_t c3 : *b[3])
+                            for (uint16_t c4 : *b[4])
+                                grams5.emplace_back((uint64_t)c1 | (uint64_t)c2 << 16 | (uint64_t)c3 << 32 | (uint64_t)c4 << 48, (uint32_t)c0);
         }
         if (ok5) {
             std::sort(grams5.begin(), grams5.end());
@@ -275,8 +290,8 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
                 f.p.addr_mask2 = (uint32_t)(bm2 - 1) & ~3u;
                 f.p.n_grams2 = (uint32_t)grams5.size();
                 f.bitmap2.assign(bm2 / 4, 0u);
-                for (uint64_t g5 : grams5) {
-                    const uint32_t u = ngram_hash2_host((uint32_t)(g5 >> 8), (uint32_t)(g5 & 255u), f.p.m1, f.p.m2, f.p.m3);
+                for (const auto &g5 : grams5) {
+                    const uint32_t u = hash_of(g5.first, f.p.m1, f.p.m2, f.p.m1b, f.p.m2b) + g5.second * f.p.m3; // (ngram_hash2_host)
                     f.bitmap2[ngram_word_index(u, f.p.addr_mask2)] |= ngram_word_bits(u, 24u);
                 }
             }

@@ -17,7 +17,9 @@ struct NgramFilter {
 // The automaton as the kernels walk it, BEFORE any mode-specific encoding: next[state * n_cols + column] in device numbering
 // (0 = sink; states <= dead_hi end a search; states >= accept_lo accept), cmap8[byte] = column of an 8-bit code unit.
 // `absorbing`: containedIn (the first accepting state ends the walk).  prog_lds_bytes: the LDS the program itself takes (the
-// bitmap is sized so that ngram_layout() places it and the waves' queues behind it).
+// bitmap is sized so that ngram_layout() places it and the waves' queues behind it).  cmap16 != nullptr (65 536 entries: column of every
+// UTF-16 code unit): the WIDE filter -- the same analysis with windows of four code units, for UTF-16 rows of patterns that live on more
+// than one page of the BMP (DFA.java:438-463: the reference's class map covers all 65 536 units).
 //
 // What is established ON THE TABLE, not argued from the regex (any failure => no filter for this program):
 //  * the start state does not accept, and the shortest accepted string has min_len >= 4 chars;
@@ -31,6 +33,6 @@ struct NgramFilter {
 //    its row also has [i - o - 5, i - o) in the second bitmap (candidates nearer the row's start are not asked).
 //    NEEDLE_PREFILTER_LEVEL2=0: no second level (A/B, tests).
 NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, const uint8_t *cmap8, int start, int accept_lo, int dead_hi,
-                               bool absorbing, size_t prog_lds_bytes);
+                               bool absorbing, size_t prog_lds_bytes, const uint8_t *cmap16 = nullptr);
 
 } // namespace needle

@@ -183,18 +183,22 @@ class Pattern:
         _check(_lib.lib().needle_pattern_program_info(self._h, list(WHICH).index(which), char_width, int(with_backward), ctypes.byref(i)))
         return {k: getattr(i, k) for k, _ in i._fields_}
 
-    def prefilter_info(self, which="forwards", with_bitmap=False):
+    def prefilter_info(self, which="forwards", with_bitmap=False, wide=False):
         """The n-gram candidate filter behind which containedIn() / find() run on batches of 8-bit rows (SURVEY.md s8 f-4;
         host-side diagnostics: needs no GPU): {"on", "mode", "stride", "warm", "min_len", "n_windows", "bitmap_bytes", hash
-        parameters, "why" (what ruled it out)} and, with_bitmap, "bitmap" (uint32 words)."""
-        i = _lib.PrefilterInfo()
+        parameters, "why" (what ruled it out)} and, with_bitmap, "bitmap" (uint32 words).  wide: the filter of UTF-16 rows of a
+        pattern on several pages of the BMP (windows of four code units: "m1b", "m2b" -- needle_pattern_prefilter_info2)."""
+        i2 = _lib.PrefilterInfo2()
         L = _lib.lib()
-        _check(L.needle_pattern_prefilter_info(self._h, list(WHICH).index(which), ctypes.byref(i), None))
+        wi = list(WHICH).index(which)
+        _check(L.needle_pattern_prefilter_info2(self._h, wi, int(bool(wide)), ctypes.byref(i2), None, 0))
+        i = i2.base
         out = {k: getattr(i, k) for k, _ in i._fields_}
         out["why"] = out["why"].decode()
+        out["wide"], out["m1b"], out["m2b"] = int(i2.wide), int(i2.m1b), int(i2.m2b)
         if with_bitmap and i.on:
             bm = np.zeros((i.bitmap_bytes + (i.bitmap2_bytes if i.on2 else 0)) // 4, dtype=np.uint32)
-            _check(L.needle_pattern_prefilter_info(self._h, list(WHICH).index(which), ctypes.byref(i), bm.ctypes.data))
+            _check(L.needle_pattern_prefilter_info2(self._h, wi, int(bool(wide)), ctypes.byref(i2), bm.ctypes.data, bm.size))
             out["bitmap"] = bm[:i.bitmap_bytes // 4]
             if i.on2:
                 out["bitmap2"] = bm[i.bitmap_bytes // 4:]  # the second level's (5-byte windows)

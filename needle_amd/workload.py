@@ -97,6 +97,69 @@ def keyword_batch(xp, words, row0, n_rows, n_cols=256, seed=SEED, device=None):
     return out.astype(np.uint8) if xp is np else out.to(xp.uint8)
 
 
+# c3m16: a keyword dictionary over THREE scripts on many pages of the BMP -- Latin (page 0), Cyrillic (page 4), CJK ideographs (20 of them,
+# one per page 0x4E .. 0x9B) -- for UTF-16 rows.  The reference's class map covers all 65 536 code units of any pattern (DFA.java:438-463);
+# 26 + 32 + 20 letters + the gaps between their ranges stay below its 127 usable classes (ByteClassUtil.java:126-128: signed bytes).
+ALPHA_LATIN = [ord(c) for c in "abcdefghijklmnopqrstuvwxyz"]
+ALPHA_CYRILLIC = list(range(0x0430, 0x0450))
+ALPHA_CJK = [0x4E00 + 0x3FD * k for k in range(20)]
+SCRIPTS = [ALPHA_LATIN, ALPHA_CYRILLIC, ALPHA_CJK]
+
+
+def keywords_mixed(n_per_script=1000, seed=SEED, min_len=6, max_len=8):
+    """n_per_script distinct keywords of min_len..max_len code units per script, scripts interleaved (latin, cyrillic, cjk, latin, ...)."""
+    per = []
+    for si, alpha in enumerate(SCRIPTS):
+        out, seen, i = [], set(), 0
+        while len(out) < n_per_script:
+            h = _h32i((seed ^ (0xC3 + 977 * si)) + i * 7919)
+            ln = min_len + h % (max_len - min_len + 1)
+            w = "".join(chr(alpha[_h32i(seed + 13 * si + i * 31 + j * 1000003) % len(alpha)]) for j in range(ln))
+            i += 1
+            if w not in seen:
+                seen.add(w)
+                out.append(w)
+        per.append(out)
+    return [per[k % 3][k // 3] for k in range(3 * n_per_script)]
+
+
+def mixed_keyword_batch(xp, words, row0, n_rows, n_cols=256, seed=SEED, device=None):
+    """c3m16: UTF-16 rows; a row's script is hashed from its number, 85 % of its chars come from that script's letters + space, 15 % from
+    the other two (mixed-script text); one keyword (of any script) planted in 25 % of the rows."""
+    r, c = _grid(xp, row0, n_rows, n_cols, device)
+    h = _hash32(seed + 177 + r * 1315423911 + c * 2654435761)
+    hr = _hash32((seed ^ 0x3C3C16) + r * 40503)
+    alphas = [a + [32] for a in SCRIPTS]
+    size = max(len(a) for a in alphas)
+    tab = np.zeros((3, size), dtype=np.int64)
+    lens = np.zeros(3, dtype=np.int64)
+    for i, a in enumerate(alphas):
+        tab[i, :len(a)] = a
+        lens[i] = len(a)
+    tab, lens = _lut(xp, tab, device), _lut(xp, lens, device)
+    script = (hr >> 3) % 3 + 0 * c
+    stray = (h % 100) >= 85
+    script = xp.where(stray, (script + 1 + (h >> 7) % 2) % 3, script)
+    base = tab[script, (h >> 9) % lens[script]]
+    plant = (hr & 3) == 0
+    maxlen = max(len(w) for w in words)
+    wtab = np.zeros((len(words), maxlen), dtype=np.int64)
+    wlen = np.zeros(len(words), dtype=np.int64)
+    for i, w in enumerate(words):
+        wtab[i, :len(w)] = [ord(ch) for ch in w]
+        wlen[i] = len(w)
+    wtab, wlen = _lut(xp, wtab, device), _lut(xp, wlen, device)
+    k = (hr >> 5) % len(words)
+    ln = wlen[k]
+    pos = (hr >> 15) % (n_cols - ln + 1)
+    rel = c - pos
+    inside = plant & (rel >= 0) & (rel < ln)
+    relc = xp.clip(rel, 0, maxlen - 1) if xp is np else rel.clamp(0, maxlen - 1)
+    planted = wtab[k + 0 * c, relc]
+    out = xp.where(inside, planted, base)
+    return out.astype(np.uint16) if xp is np else out.to(xp.int16)
+
+
 # C5: mixed-script UTF-16.  Ranges the regex recognises (explicit BMP ranges; >= 40 ranges over several scripts)
 SCRIPT_RANGES = [
     (0x0391, 0x03A1), (0x03A3, 0x03A9), (0x03B1, 0x03C1), (0x03C3, 0x03C9),  # Greek

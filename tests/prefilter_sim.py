@@ -18,12 +18,26 @@ def window2_passes(info, bitmap2, x, c5):
     return (w >> ((u >> 24) & 31)) & (w >> ((u >> 16) & 31)) & 1
 
 
+def _probe(info, bitmap, u, mask_key, sh_hi=None):
+    w = int(bitmap[(u & info[mask_key]) >> 2])
+    hi = info["addr_shift"] if sh_hi is None else sh_hi
+    return (w >> ((u >> hi) & 31)) & (w >> ((u >> (hi - 8)) & 31)) & 1
+
+
 def candidate(info, t, e, all_windows):
     """Does the window ending at e make a candidate: its 4 bytes in the bitmap and -- find / containedIn, 5 chars or more into the row --
-    its 5 bytes in the second one."""
-    x = int(t[e - 4] | (t[e - 3] << 8) | (t[e - 2] << 16) | (t[e - 1] << 24))
+    its 5 bytes in the second one.  info["wide"]: the windows are four 16-bit code units (needle_ngram.h ngram_piece16)."""
     if all_windows:
         return True
+    if info.get("wide"):
+        x0, x1 = int(t[e - 4] | (t[e - 3] << 16)), int(t[e - 2] | (t[e - 1] << 16))
+        u = ((x0 & 0xFFFF) * info["m1"] + (x0 >> 16) * info["m2"] + (x1 & 0xFFFF) * info["m1b"] + (x1 >> 16) * info["m2b"]) & 0xFFFFFFFF
+        if not _probe(info, info["bitmap"], u, "addr_mask"):
+            return False
+        if info.get("on2") and e >= 5 and not info.get("no_level2"):
+            return bool(_probe(info, info["bitmap2"], (u + int(t[e - 5]) * info["m3"]) & 0xFFFFFFFF, "addr_mask2", 24))
+        return True
+    x = int(t[e - 4] | (t[e - 3] << 8) | (t[e - 2] << 16) | (t[e - 1] << 24))
     if not window_passes(info, info["bitmap"], x):
         return False
     if info.get("on2") and e >= 5 and not info.get("no_level2"):

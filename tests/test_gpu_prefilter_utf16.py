@@ -4,7 +4,8 @@ maxChar" (DFAClassBuilder.java:440, :565: `c > maxChar`), exactly what byte 0xFF
 oracle's on the UTF-16 rows, bit for bit, and those of the UTF-16 scan kernels with the route switched off (NEEDLE_PREFILTER_UTF16=0);
 `filter_launches` of needle_pattern_prefilter_state proves which kernel ran.  Shapes: full rows, ragged rows, strides of 64 / 192 / 256 /
 1024 chars, batches ending inside a group and inside a unit, keywords at both ends of a row, chars above 0xFF around and inside keywords'
-places (CJK, 0x0100 + a keyword char: same low byte, another char), one-dword results, every match of every row (dense, one dword per match, counting pass, compact filing), the big dictionary whose walks
+places (CJK, 0x0100 + a keyword char: same low byte, another char), dictionaries on SEVERAL pages of the BMP behind the WIDE filter (windows
+of four 16-bit code units: DFA.java:438-463 -- the reference's class map covers every code unit of any pattern), one-dword results, every match of every row (dense, one dword per match, counting pass, compact filing), the big dictionary whose walks
 leave the LDS."""
 import os
 import subprocess
@@ -21,6 +22,8 @@ from needle_amd import workload as W
 from needle_amd.pattern import DFACompiler, unpack_bitmap
 from test_compile_matches_txt import oracle_for
 route_on = int(sys.argv[1])
+import os
+wide_on = os.environ.get("NEEDLE_PREFILTER_WIDE", "1") != "0"
 dev = "cuda"
 rng = np.random.default_rng(7)
 
@@ -143,13 +146,41 @@ for name, words, shapes in (("1000 Cyrillic keywords", big, [(20000, 256), (4099
         lens = rng.integers(0, stride + 1, size=n)
         launches, _, _ = check(p, o, host, lens, (name, n, stride, "ragged"))
         total_launches += launches
-# a pattern on TWO pages (Latin and Cyrillic keywords) has no such program
+# a pattern on TWO pages (Latin and Cyrillic keywords) has no byte program -- it takes the WIDE filter (needle_ngram.h ngram_piece16: windows
+# of four 16-bit code units hashed as they stand, candidates verified on the UTF-16 HBM-table program); NEEDLE_PREFILTER_WIDE=0: the UTF-16
+# scan kernels
 p = DFACompiler.compile("|".join(big[:200] + [cyr(w) for w in big[200:400]]), "t", 0)
 o, _ = oracle_for("|".join(big[:200] + [cyr(w) for w in big[200:400]]), 0)
+assert p.utf16_route() is None
 host = utf16_rows(big[:200], 6000, 256, 77)
 host[::2][(host[::2] >= 97) & (host[::2] <= 122)] += 0x0430 - 97
-launches, hits, _ = check(p, o, host, None, ("two pages",))
-assert launches == 0 and hits > 0
+launches, hits, fa_launches = check(p, o, host, None, ("two pages",))
+assert hits > 0 and (launches >= 3) == bool(route_on and wide_on) and (fa_launches >= 4) == bool(route_on and wide_on), (launches, fa_launches)
+total_launches += launches
+# three scripts on ~25 pages (Latin, Cyrillic, CJK: needle_amd.workload.keywords_mixed), mixed-script rows: full / ragged rows, strides of
+# 64 / 192 / 256 / 1024 chars, batches ending inside a group, keywords of every script at both ends of rows, adjacent matches
+for per, shapes in ((300, [(20000, 256), (4099, 192), (1500, 1024), (7001, 64)]), (1000, [(12000, 256)])):
+    words = W.keywords_mixed(per)
+    rx = "|".join(words)
+    p = DFACompiler.compile(rx, "t", 0)
+    o, _ = oracle_for(rx, 0)
+    assert p.utf16_route() is None
+    for n, stride in shapes:
+        host = W.mixed_keyword_batch(np, words, 4000 + n, n, stride)
+        for i in range(0, n, 9):
+            w = [ord(c) for c in words[(i * 5) % len(words)]]
+            w2 = [ord(c) for c in words[(i * 7 + 1) % len(words)]]
+            host[i, :len(w)] = w
+            host[i, stride - len(w2):] = w2
+            if i % 18 == 0 and stride >= 64: host[i, 20:20 + len(w)] = w; host[i, 20 + len(w):20 + len(w) + len(w2)] = w2
+            if i % 27 == 0: host[i, stride - 2] ^= 0x0100  # ... the keyword at the row's end broken
+        launches, hits, fa_launches = check(p, o, host, None, ("mixed scripts", per, n, stride, "full"))
+        total_launches += launches
+        assert hits > 0 and (launches >= 3) == bool(route_on and wide_on) and (fa_launches >= 4) == bool(route_on and wide_on), (per, n, stride, launches, fa_launches)
+        lens = rng.integers(0, stride + 1, size=n)
+        lens[::5] = stride
+        launches, _, _ = check(p, o, host, lens, ("mixed scripts", per, n, stride, "ragged"))
+        total_launches += launches
 # a pattern with a char at or above 0xFF on page 0 takes the route as long as the page has a char of the "other" class left
 p = DFACompiler.compile("abcdefÿgh|bcdefgh", "t", 0)
 o, _ = oracle_for("abcdefÿgh|bcdefgh", 0)
@@ -161,10 +192,11 @@ print("OK", total_launches)
 '''
 
 
-def run_child(route_on):
+def run_child(route_on, wide_on=True):
     env = dict(os.environ)
     env["NEEDLE_PREFILTER_UTF16"] = "1" if route_on else "0"
-    r = subprocess.run([sys.executable, "-c", CODE, str(route_on)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    env["NEEDLE_PREFILTER_WIDE"] = "1" if wide_on else "0"
+    r = subprocess.run([sys.executable, "-c", CODE, str(route_on)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     return int(r.stdout.strip().split()[-1])
 
@@ -177,3 +209,9 @@ def test_utf16_rows_behind_the_byte_filter_match_the_oracle():
 @pytest.mark.gpu
 def test_utf16_route_off_is_the_same_answer():
     assert run_child(0) == 0
+
+
+@pytest.mark.gpu
+def test_wide_filter_off_is_the_same_answer():
+    """NEEDLE_PREFILTER_WIDE=0: multi-page dictionaries on the UTF-16 scan kernels (the asserts on launch counts flip inside the child)."""
+    assert run_child(1, wide_on=False) > 0
