@@ -635,57 +635,78 @@ def measure(workload, args, ctx, headline):
         # ... and PIPELINED ("results landed in host-visible memory" as a steady-state rate): two result sets; step k's D2H
         # runs on a copy stream under step k + 1's scan.  find(): the one-dword form the scan stores itself (4 B per row over PCIe).
         n_sets = 2
-        use_packed = is_find and rows.shape[1] <= 65534
-        dsets, hsets = [], []
-        for _ in range(n_sets):
-            d = {"bitmap": torch.empty(sh.per_words, dtype=torch.int64, device=dev)}
-            h = {"bitmap": torch.empty(sh.per_words, dtype=torch.int64).pin_memory()}
-            if is_find and use_packed:
-                d["packed"] = torch.empty(n_rows, dtype=torch.int32, device=dev)
-                h["packed"] = torch.empty(n_rows, dtype=torch.int32).pin_memory()
-            elif is_find:
-                d["start"], d["end"] = torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.int32, device=dev)
-                h["start"], h["end"] = torch.empty(n_rows, dtype=torch.int32).pin_memory(), torch.empty(n_rows, dtype=torch.int32).pin_memory()
-            dsets.append(d)
-            hsets.append(h)
         s_scan, s_copy = torch.cuda.current_stream(), torch.cuda.Stream()
-        scan_done = [torch.cuda.Event() for _ in range(n_sets)]
-        copy_done = [torch.cuda.Event() for _ in range(n_sets)]
 
-        def pipelined_steps(k_steps):
-            for i in range(k_steps):
-                k = i % n_sets
-                s_scan.wait_event(copy_done[k])  # set k's previous results have left the device
-                d = dsets[k]
-                if not is_find:
-                    op(rows, out=d["bitmap"])
-                elif use_packed:
-                    pattern.find_packed16_batch(rows, out=(d["bitmap"], d["packed"]))
-                else:
-                    op(rows, out=(d["bitmap"], d["start"], d["end"]))
-                scan_done[k].record(s_scan)
-                s_copy.wait_event(scan_done[k])
-                with torch.cuda.stream(s_copy):
-                    for key, t in d.items():
-                        hsets[k][key].copy_(t, non_blocking=True)
-                    copy_done[k].record(s_copy)
-            torch.cuda.synchronize()
-        for e_ in copy_done:
-            e_.record(s_copy)
-        pipelined_steps(4)
-        kp = max(8, args.steps)
-        best = None
-        for _ in range(2):
-            tq = time.perf_counter()
-            pipelined_steps(kp)
-            dq = (time.perf_counter() - tq) / kp
-            best = dq if best is None else min(best, dq)
-        d2h = sh.per_words * 8 + ((4 if use_packed else 8) * n_rows if is_find else 0)
-        out["host_landed"]["pipelined"] = {"ms_per_step": best * 1e3, "GB/s": bytes_job / best / 1e9, "frac_of_hbm_peak": bytes_job / best / 1e9 / HBM_PEAK_GBS,
-                                           "d2h_bytes_per_step": d2h, "d2h_GB/s": d2h / best / 1e9,
-                                           "note": "steady state of scan k + 1 on the launch stream beside the D2H of step k's results on a copy stream (two result sets); "
-                                                   "find(): the one-dword form" if use_packed else "two result sets, D2H under the next scan"}
-        del dsets, hsets
+        def pipelined(form):
+            """form: None (containedIn / int32 arrays), "packed16" (one dword per row), "packed8" (one uint16 per row: rows <= 256 chars)"""
+            dsets, hsets = [], []
+            for _ in range(n_sets):
+                d = {"bitmap": torch.empty(sh.per_words, dtype=torch.int64, device=dev)}
+                h = {"bitmap": torch.empty(sh.per_words, dtype=torch.int64).pin_memory()}
+                if is_find and form == "packed16":
+                    d["packed"] = torch.empty(n_rows, dtype=torch.int32, device=dev)
+                    h["packed"] = torch.empty(n_rows, dtype=torch.int32).pin_memory()
+                elif is_find and form == "packed8":
+                    d["packed"] = torch.empty(n_rows, dtype=torch.int16, device=dev)
+                    h["packed"] = torch.empty(n_rows, dtype=torch.int16).pin_memory()
+                elif is_find:
+                    d["start"], d["end"] = torch.empty(n_rows, dtype=torch.int32, device=dev), torch.empty(n_rows, dtype=torch.int32, device=dev)
+                    h["start"], h["end"] = torch.empty(n_rows, dtype=torch.int32).pin_memory(), torch.empty(n_rows, dtype=torch.int32).pin_memory()
+                dsets.append(d)
+                hsets.append(h)
+            scan_done = [torch.cuda.Event() for _ in range(n_sets)]
+            copy_done = [torch.cuda.Event() for _ in range(n_sets)]
+
+            def pipelined_steps(k_steps):
+                for i in range(k_steps):
+                    k = i % n_sets
+                    s_scan.wait_event(copy_done[k])  # set k's previous results have left the device
+                    d = dsets[k]
+                    if not is_find:
+                        op(rows, out=d["bitmap"])
+                    elif form == "packed16":
+                        pattern.find_packed16_batch(rows, out=(d["bitmap"], d["packed"]))
+                    elif form == "packed8":
+                        pattern.find_packed8_batch(rows, out=(d["bitmap"], d["packed"]))
+                    else:
+                        op(rows, out=(d["bitmap"], d["start"], d["end"]))
+                    scan_done[k].record(s_scan)
+                    s_copy.wait_event(scan_done[k])
+                    with torch.cuda.stream(s_copy):
+                        for key, t in d.items():
+                            hsets[k][key].copy_(t, non_blocking=True)
+                        copy_done[k].record(s_copy)
+                torch.cuda.synchronize()
+            for e_ in copy_done:
+                e_.record(s_copy)
+            pipelined_steps(4)
+            kp = max(8, args.steps)
+            best = None
+            for _ in range(2):
+                tq = time.perf_counter()
+                pipelined_steps(kp)
+                dq = (time.perf_counter() - tq) / kp
+                best = dq if best is None else min(best, dq)
+            if form == "packed8":  # the 2-byte form against the dword form on the last set scanned (same rows)
+                w16, p16 = pattern.find_packed16_batch(rows)
+                from needle_amd.pattern import Pattern
+                s8, e8 = Pattern.unpack8(dsets[(kp - 1) % n_sets]["packed"][:200000].cpu().numpy())
+                v16 = p16[:200000].cpu().numpy().view(np.uint32)
+                no = v16 == 0xFFFFFFFF
+                assert ((s8 == np.where(no, -1, v16 & 0xFFFF)) & (e8 == np.where(no, -1, v16 >> 16))).all()
+            per_row = {None: 8, "packed16": 4, "packed8": 2}[form] if is_find else 0
+            d2h = sh.per_words * 8 + per_row * n_rows
+            return {"ms_per_step": best * 1e3, "GB/s": bytes_job / best / 1e9, "frac_of_hbm_peak": bytes_job / best / 1e9 / HBM_PEAK_GBS,
+                    "d2h_bytes_per_step": d2h, "d2h_GB/s": d2h / best / 1e9}
+
+        form = None if not is_find else ("packed8" if rows.shape[1] <= 256 else "packed16" if rows.shape[1] <= 65534 else None)
+        out["host_landed"]["pipelined"] = pipelined(form)
+        out["host_landed"]["pipelined"]["form"] = form or ("bitmap" if not is_find else "int32 arrays")
+        out["host_landed"]["pipelined"]["note"] = ("steady state of scan k + 1 on the launch stream beside the D2H of step k's results on a copy stream (two result sets); "
+                                                   "find(): the result form named in `form` -- packed8 = one uint16 per row (needle_find_packed8_dev: rows <= 256 chars), "
+                                                   "packed16 = one dword per row")
+        if form == "packed8":
+            out["host_landed"]["pipelined16"] = pipelined("packed16")  # round 5's figure: 4 result bytes per row over PCIe
     if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s", "c3x", "c3s16", "c3x16", "c3m16") and is_find:
         # SURVEY.md s8f-1: EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
         # the batch (needle_find_all.hip; for dictionaries behind the n-gram candidate filter -- c3s -- that kernel's find-all form,
@@ -772,9 +793,10 @@ def slim(w):
         o["gather_verified"], o["scan_ms"], o["gather_ms"] = w["gather_verified"], _r(w.get("scan_ms")), _r(w.get("gather_ms"))
     hl = w.get("host_landed")
     if hl:
-        o["host_landed_ms"] = {"plain": _r(hl["ms_per_step"]), **{k: _r(hl[k]["ms_per_step"]) for k in ("packed16", "compact", "pipelined") if k in hl}}
+        o["host_landed_ms"] = {"plain": _r(hl["ms_per_step"]), **{k: _r(hl[k]["ms_per_step"]) for k in ("packed16", "compact", "pipelined", "pipelined16") if k in hl}}
         if "pipelined" in hl:
             o["host_landed_ms"]["pipelined_frac"] = _r(hl["pipelined"]["frac_of_hbm_peak"])
+            o["host_landed_ms"]["form"] = hl["pipelined"].get("form")
     fa = w.get("find_all")
     if fa:
         o["find_all"] = {"ms": _r(fa["ms_per_step"]), "frac": _r(fa["frac_of_hbm_peak"]), "packed16_ms": _r(fa["packed16"]["ms_per_step"]),
@@ -807,9 +829,10 @@ def slim_line(out):
         line["must_read_GBs"] = _r(out["must_read"]["GB/s"], 1)
     hl = out.get("host_landed")
     if hl:
-        line["host_landed_ms"] = {"plain": _r(hl["ms_per_step"]), **{k: _r(hl[k]["ms_per_step"]) for k in ("packed16", "compact", "pipelined") if k in hl}}
+        line["host_landed_ms"] = {"plain": _r(hl["ms_per_step"]), **{k: _r(hl[k]["ms_per_step"]) for k in ("packed16", "compact", "pipelined", "pipelined16") if k in hl}}
         if "pipelined" in hl:
             line["host_landed_ms"]["pipelined_frac"] = _r(hl["pipelined"]["frac_of_hbm_peak"])
+            line["host_landed_ms"]["form"] = hl["pipelined"].get("form")
     if "c4_shard_step" in out:
         line["c4_shard_step"] = {w: ({"ms": _r(v["ms_per_step"]), "kernel_ms": _r(v["kernel_ms"]), "overhead": _r(v["overhead_frac"], 3)} if "error" not in v else v)
                                  for w, v in out["c4_shard_step"].items()}

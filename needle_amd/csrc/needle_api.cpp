@@ -553,7 +553,7 @@ static bool find_lengths_for(uint32_t mode) {
 
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
                    int32_t *d_end, void *stream, const int32_t *d_from = nullptr, uint32_t *d_end_state = nullptr,
-                   bool no_backward = false, uint32_t *d_packed = nullptr);
+                   bool no_backward = false, uint32_t *d_packed = nullptr, bool packed8 = false);
 
 // The WIDE filter (lower_filter_wide) stands in for the UTF-16 scan kernels where the ordinary UTF-16 program is NOT a plain LDS table
 // (compressed automaton, hot rows + HBM table, HBM table): a latency-bound or collapsing walk.  NEEDLE_PREFILTER=2: for every
@@ -685,7 +685,7 @@ static int run_speculative_stripes(needle_pattern *p, int op, const needle_batch
 // Launch arguments of the filter kernel (needle_ngram.hip) for program `tp` on batch `v`.  stride: bytes between rows -- or CHARS, for UTF-16
 // rows behind the byte program (launch_ngram with char_width 2 scales the addresses).
 static ScanArgs filter_scan_args(const needle_batch_view *v, uint64_t stride, const DevProgram *tp, int32_t fixed_len, uint64_t *d_bitmap, int32_t *d_start,
-                                 int32_t *d_end, uint32_t *d_packed) {
+                                 int32_t *d_end, uint32_t *d_packed, bool packed8 = false) {
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = (const uint8_t *)v->rows;
@@ -701,6 +701,7 @@ static ScanArgs filter_scan_args(const needle_batch_view *v, uint64_t stride, co
     a.start = d_start;
     a.end = d_end;
     a.packed = d_packed;
+    a.packed8 = packed8 ? 1u : 0u;
     return a;
 }
 
@@ -708,7 +709,7 @@ static ScanArgs filter_scan_args(const needle_batch_view *v, uint64_t stride, co
 // d_start / d_end are not used.  The paths for few long rows (stripes) and the opt-in two-row-set kernel keep their int32
 // arrays: they run into scratch and one pack pass follows.
 static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v, uint64_t *d_bitmap, int32_t *d_start,
-                   int32_t *d_end, void *stream, const int32_t *d_from, uint32_t *d_end_state, bool no_backward, uint32_t *d_packed) {
+                   int32_t *d_end, void *stream, const int32_t *d_from, uint32_t *d_end_state, bool no_backward, uint32_t *d_packed, bool packed8) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
     int rc = check_view(v, true);
@@ -724,6 +725,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // (NEEDLE_LONG_ROWS=1 forces the stripe paths for any stride: they only know the int32 arrays)
     static const bool long_rows_forced = getenv("NEEDLE_LONG_ROWS") && atoi(getenv("NEEDLE_LONG_ROWS")) == 1;
     if (d_packed && (dict_env > 0 || long_rows_forced || v->row_stride * v->char_width >= 8 * (uint64_t)kStripeBytes)) {
+        if (packed8) return fail(NEEDLE_ERR_UNSUPPORTED, "needle_find_packed8_dev: not on the stripe / two-row-set paths (tuning switches)");
         int32_t *tmp = nullptr;
         HIP_TRY(scratch_malloc((void **)&tmp, (size_t)v->n_rows * 8, (hipStream_t)stream));
         rc = run_dev(cp, op, v, d_bitmap, tmp, tmp + v->n_rows, stream, d_from, d_end_state, no_backward, nullptr);
@@ -763,7 +765,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
             ok = tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || lengths8 || p->t.fixed_len >= 0);
         }
         if (ok) {
-            const ScanArgs a = filter_scan_args(v, v->row_stride /* chars */, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed);
+            const ScanArgs a = filter_scan_args(v, v->row_stride /* chars */, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed, packed8);
             if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
                 HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream, 2, u16.page, u16.sub));
                 HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
@@ -783,7 +785,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
         rc = get_program(p, which, 2, 10, &tp, nullptr);
         if (rc) return rc;
         if (tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0)) {
-            const ScanArgs a = filter_scan_args(v, v->row_stride /* chars */, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed);
+            const ScanArgs a = filter_scan_args(v, v->row_stride /* chars */, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed, packed8);
             if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
                 HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream, 2, 0, 0));
                 HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
@@ -816,7 +818,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
         rc = get_program(p, which, 1, 9, &tp, nullptr);
         if (rc) return rc;
         if (tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0)) {
-            const ScanArgs a = filter_scan_args(v, v->row_stride, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed);
+            const ScanArgs a = filter_scan_args(v, v->row_stride, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed, packed8);
             if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
                 HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream));
                 HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
@@ -863,6 +865,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     a.start = d_start;
     a.end = d_end;
     a.packed = d_packed;
+    a.packed8 = packed8 ? 1u : 0u;
     a.end_state = d_end_state;
     bool skip_backward = no_backward; // (speculative pass: only lastMatch is wanted)
 #ifdef NEEDLE_TUNING // measurement builds only (scripts/build_tuning.sh): a switch that changes ANSWERS (start = end) never ships
@@ -1704,6 +1707,13 @@ int needle_find_packed16_dev(const needle_pattern *p, const needle_batch_view *v
     if (v && v->n_rows && !start_end16) return fail(NEEDLE_ERR_INVALID, "start_end16 is NULL");
     if (v && !offsets16_ok(v, 65534u)) return fail(NEEDLE_ERR_UNSUPPORTED, "16-bit offsets: rows of at most 65 534 chars (use needle_find_dev)");
     return run_dev(p, OP_FIND, v, bm, nullptr, nullptr, s, nullptr, nullptr, false, start_end16);
+}
+// find() with a row's result as ONE uint16 -- start | (end - start) << 8, 0xFFFF = no match, 0xFFFE = the match (0, 256) -- stored by the
+// kernels themselves: 2 result bytes per row.  Rows of at most 256 chars.
+int needle_find_packed8_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *bm, uint16_t *start_len8, void *s) {
+    if (v && v->n_rows && !start_len8) return fail(NEEDLE_ERR_INVALID, "start_len8 is NULL");
+    if (v && (v->lengths ? v->row_stride : v->row_len) > 256u) return fail(NEEDLE_ERR_UNSUPPORTED, "8-bit start / length: rows of at most 256 chars (use needle_find_packed16_dev)");
+    return run_dev(p, OP_FIND, v, bm, nullptr, nullptr, s, nullptr, nullptr, false, (uint32_t *)start_len8, true);
 }
 int needle_find_next_dev(const needle_pattern *p, const needle_batch_view *v, const int32_t *cur, uint64_t *bm, int32_t *st,
                          int32_t *en, void *s) {

@@ -281,4 +281,35 @@ int needle_find_packed16_host(const needle_pattern *p, const needle_batch_view *
     return NEEDLE_OK;
 }
 
+// needle_find_host with start / end as ONE dword per row (low half start, high half end, 0xFFFF = no match: the form
+// needle_pack_start_len8_dev writes): 4 bytes per row over PCIe instead of 8.  Rows of at most 65 534 chars.
+int needle_find_packed8_host(const needle_pattern *p, const needle_batch_view *v, uint64_t *bitmap, uint16_t *start_len8) {
+    if (!p) return fail(NEEDLE_ERR_INVALID, "pattern is NULL");
+    int rc = check_host_view(v);
+    if (rc) return rc;
+    if (v->n_rows == 0) return NEEDLE_OK;
+    if (!bitmap || !start_len8) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    if ((v->lengths ? v->row_stride : v->row_len) > 256u) // the caller's own stride: the upload pads it to 16 bytes
+        return fail(NEEDLE_ERR_UNSUPPORTED, "8-bit start / length: rows of at most 256 chars (use needle_find_packed16_host)");
+    const uint64_t per = rows_per_chunk(v);
+    for (uint64_t r0 = 0; r0 < v->n_rows; r0 += per) {
+        const uint64_t cnt = std::min<uint64_t>(per, v->n_rows - r0), words = (cnt + 63) / 64;
+        HostChunk ch;
+        if ((rc = ch.upload(v, r0, cnt))) return rc;
+        uint8_t *d_out = nullptr; // bitmap | packed
+        const uint64_t o_p = (words * 8 + 15) & ~(uint64_t)15;
+        if (hipMalloc((void **)&d_out, o_p + cnt * 2) != hipSuccess) return fail(NEEDLE_ERR_DEVICE, "hipMalloc (find results)");
+        rc = needle_find_packed8_dev(p, &ch.view, (uint64_t *)d_out, (uint16_t *)(d_out + o_p), nullptr);
+        hipError_t e = hipSuccess;
+        if (rc == NEEDLE_OK) {
+            e = hipMemcpy(bitmap + r0 / 64, d_out, words * 8, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(start_len8 + r0, d_out + o_p, cnt * 2, hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(d_out);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(NEEDLE_ERR_DEVICE, std::string("find download: ") + hipGetErrorString(e));
+    }
+    return NEEDLE_OK;
+}
+
 } // extern "C"

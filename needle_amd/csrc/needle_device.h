@@ -136,6 +136,7 @@ struct ScanArgs {
     int32_t *end;
     uint32_t *packed;       // OP_FIND, rows of at most 65 534 chars: when set, a row's result is stored as ONE dword here --
                             // start | end << 16, 0xFFFFFFFF = no match (needle_find_packed16_dev) -- and start / end are not written
+    uint32_t packed8;       // != 0: `packed` points at uint16 results (rows of at most 256 chars, needle_find_packed8_dev): pack8() below
     uint32_t *end_state;    // optional: the automaton state (device id) in which every row's walk stopped
     uint32_t short_window;   // short_kernel (rows <= 64 B), find(): LDS holds an 80-byte slot per lane behind the program -- the
                              // matched rows' text goes there for the backward walk instead of being re-read from memory
@@ -211,6 +212,13 @@ struct StripeArgs {
 //                          map, one VALU op less per char -- but it only leaves room for 64-byte tiles: 0.96 -> 1.00 ms.)
 //                          The packed BACKWARD automaton of find() rides along in the same form with absolute addresses.
 //                  table modes: ptab16[256] at 0 (page * 256), pages8 (col * elem) at 512, table at hdr.off_table
+// find() results of rows of at most 256 chars as ONE uint16 (needle_find_packed8_dev): start | (end - start) << 8; the pairs with
+// start + length > 256 cannot occur and serve as escapes -- 0xFFFF = no match, 0xFFFE = the match (0, 256), the only one of length 256.
+__host__ __device__ inline uint16_t pack8(int32_t s, int32_t e) {
+    if (e < 0) return 0xFFFFu;
+    const uint32_t len = (uint32_t)(e - s);
+    return len > 255u ? (uint16_t)0xFFFEu : (uint16_t)(((uint32_t)s & 0xFFu) | len << 8);
+}
 constexpr uint32_t kLdsF1 = 0, kLdsCmap1 = 0, kLdsTable1 = 512;
 //                  pair mode: cmapA16[256] at 0 (col * n_cols * 2: first char of a pair), cmapB16[256] at 512 (col * 2)
 constexpr uint32_t kLdsCmapB1 = 512, kLdsPairTable1 = 1024;

@@ -515,7 +515,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             if (lane == 0) NEEDLE_NG_PTR(uint64_t, a.bitmap)[g] = word;
             if (row_ok) {
                 uint32_t *const o_packed = NEEDLE_NG_PTR(uint32_t, a.packed);
-                if (o_packed) { // the key's low dword is end << 16 | start already; ~0 = no match
+                if (o_packed && NEEDLE_NG_U32(a.packed8)) { // one uint16 per row (rows <= 256 chars)
+                    ((uint16_t *)o_packed)[(g << 6) + lane] = pack8(res ? (int32_t)(key & 0xFFFFu) : -1, res ? (int32_t)((key >> 16) & 0xFFFFu) : -1);
+                } else if (o_packed) { // the key's low dword is end << 16 | start already; ~0 = no match
                     o_packed[(g << 6) + lane] = (uint32_t)key;
                 } else {
                     NEEDLE_NG_PTR(int32_t, a.start)[(g << 6) + lane] = res ? (int32_t)(key & 0xFFFFu) : -1;

@@ -359,7 +359,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void scan_kernel(const ScanArg
         }
         if (row_ok) {
             uint32_t *const o_packed = kernarg_ptr<uint32_t>(ka, (uint32_t)offsetof(ScanArgs, packed));
-            if (o_packed) { // wave-uniform: one dword per row (no match: s = e = -1 -> 0xFFFFFFFF)
+            if (o_packed && kernarg_u32(ka, (uint32_t)offsetof(ScanArgs, packed8))) { // wave-uniform: one uint16 per row (rows <= 256 chars)
+                ((uint16_t *)o_packed)[my_row] = pack8(s, e);
+            } else if (o_packed) { // wave-uniform: one dword per row (no match: s = e = -1 -> 0xFFFFFFFF)
                 o_packed[my_row] = ((uint32_t)s & 0xFFFFu) | ((uint32_t)e << 16);
             } else {
                 kernarg_ptr<int32_t>(ka, (uint32_t)offsetof(ScanArgs, start))[my_row] = s;

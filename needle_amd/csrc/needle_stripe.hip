@@ -923,7 +923,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void short_kernel(const ScanAr
         cur_len = nxt_len, cur_from = nxt_from;
         if (lane == 0) a.bitmap[g] = word;
         if (OP == OP_FIND && row_ok) {
-            if (a.packed) { // wave-uniform: one dword per row (ScanArgs::packed)
+            if (a.packed && a.packed8) { // wave-uniform: one uint16 per row (needle_find_packed8_dev)
+                ((uint16_t *)a.packed)[my_row] = pack8(s, e);
+            } else if (a.packed) { // wave-uniform: one dword per row (ScanArgs::packed)
                 a.packed[my_row] = ((uint32_t)s & 0xFFFFu) | ((uint32_t)e << 16);
             } else {
                 a.start[my_row] = s;

@@ -16,7 +16,8 @@ struct Switch {
 const Switch kSwitches[] = {
     {"NEEDLE_PREFILTER", "1", "layout", "n-gram candidate filter in front of the automaton (needle_ngram.hip): 0 never, 1 for automata in the compressed form, 2 for every LDS-table automaton that allows one"},
     {"NEEDLE_PREFILTER_LEVEL2", "1", "layout", "0: no second-level window (a candidate's 5-byte window looked up in a second bitmap before the automaton runs on it)"},
-    {"NEEDLE_PREFILTER_UTF16", "1", "layout", "0: UTF-16 rows never take the byte program's filter kernel (patterns on one page of the BMP: text narrowed as it is loaded)"},
+    {"NEEDLE_PREFILTER_UTF16", "1", "layout", "0: UTF-16 rows never take a filter kernel (patterns on one page of the BMP: the byte program's, text narrowed as it is loaded; several pages: the wide filter)"},
+    {"NEEDLE_PREFILTER_WIDE", "1", "layout", "0: UTF-16 rows of patterns on several pages of the BMP never take the wide filter (windows of four 16-bit code units, needle_ngram.h ngram_piece16); NEEDLE_PREFILTER_UTF16=0 switches it off too"},
     {"NEEDLE_PREFILTER_WATCH", "1", "layout", "0: the filter kernel is never suspended (the flood watch: after a launch that saw more than 16 candidates per KiB of text the program's next 32 .. 1024 calls take the ordinary scan kernel)"},
     {"NEEDLE_FIND_LENGTHS", "1", "layout", "find() by the lengths automaton (start = end - length, no backward walk): 0 never (forward + backward walks), 1 where the ordinary program is an LDS table, 2 also instead of a pair table"},
     {"NEEDLE_FIND_LENGTHS_SPARSE", "1", "layout", "0: compressed-form automata keep the two walks"},

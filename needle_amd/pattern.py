@@ -606,6 +606,50 @@ class Pattern:
             _check(_lib.lib().needle_find_packed16_dev(self._h, ctypes.byref(v), words.data_ptr(), se.data_ptr(), s))
         return words, se
 
+    def find_packed8_batch(self, rows, lengths=None, stream=None, out=None):
+        """needle_find_packed8_dev: find() on device rows of at most 256 chars -> (bitmap words, int16[n] tensor whose elements are the
+        uint16 start | (end - start) << 8; 0xFFFF = no match, 0xFFFE = the match (0, 256)): 2 result bytes per row.
+        out: optional caller-owned (bitmap int64, packed int16) device tensors.  unpack8() decodes."""
+        import torch
+        v = self._dev_view(rows, lengths)
+        n = rows.shape[0]
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            if out is not None:
+                words, sl = out
+                assert words.dtype == torch.int64 and words.numel() >= (n + 63) // 64 and sl.dtype == torch.int16 and sl.numel() >= n
+            else:
+                words = torch.empty((n + 63) // 64, dtype=torch.int64, device=rows.device)
+                sl = torch.empty(n, dtype=torch.int16, device=rows.device)
+            _check(_lib.lib().needle_find_packed8_dev(self._h, ctypes.byref(v), words.data_ptr(), sl.data_ptr(), s))
+        return words, sl
+
+    @staticmethod
+    def unpack8(sl):
+        """uint16 entries of needle_find_packed8_* (numpy array, any integer dtype holding the bit pattern) -> (start, end) int32
+        arrays, -1 / -1 where there is no match."""
+        x = np.asarray(sl).astype(np.int64) & 0xFFFF
+        start = np.where(x == 0xFFFF, -1, np.where(x == 0xFFFE, 0, x & 0xFF))
+        end = np.where(x == 0xFFFF, -1, np.where(x == 0xFFFE, 256, (x & 0xFF) + (x >> 8)))
+        return start.astype(np.int32), end.astype(np.int32)
+
+    def find_packed8_host(self, rows, lengths=None):
+        """needle_find_packed8_host: host rows of at most 256 chars -> (bitmap words, uint16[n]: see find_packed8_batch)."""
+        L = _lib.lib()
+        rows = np.ascontiguousarray(rows)
+        if rows.dtype == np.int16:
+            rows = rows.view(np.uint16)
+        n, stride = rows.shape
+        v = BatchView()
+        v.rows, v.char_width, v.n_rows, v.row_stride, v.row_len = rows.ctypes.data, rows.dtype.itemsize, n, stride, stride
+        if lengths is not None:
+            lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+            v.lengths = lengths.ctypes.data
+        words = np.zeros((n + 63) // 64, dtype=np.uint64)
+        sl = np.zeros(n, dtype=np.uint16)
+        _check(L.needle_find_packed8_host(self._h, ctypes.byref(v), words.ctypes.data, sl.ctypes.data))
+        return words, sl
+
     MATCH_REC = np.dtype([("row", np.uint32), ("start", np.uint16), ("end", np.uint16)])  # needle_match_rec
 
     def find_compact(self, rows, lengths=None, stream=None, out=None):
