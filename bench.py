@@ -688,6 +688,7 @@ def measure(workload, args, ctx, headline):
                 dq = (time.perf_counter() - tq) / kp
                 best = dq if best is None else min(best, dq)
             if form == "packed8":  # the 2-byte form against the dword form on the last set scanned (same rows)
+                import numpy as np
                 w16, p16 = pattern.find_packed16_batch(rows)
                 from needle_amd.pattern import Pattern
                 s8, e8 = Pattern.unpack8(dsets[(kp - 1) % n_sets]["packed"][:200000].cpu().numpy())
