@@ -692,7 +692,7 @@ def measure(workload, args, ctx, headline):
                 w16, p16 = pattern.find_packed16_batch(rows)
                 from needle_amd.pattern import Pattern
                 s8, e8 = Pattern.unpack8(dsets[(kp - 1) % n_sets]["packed"][:200000].cpu().numpy())
-                v16 = p16[:200000].cpu().numpy().view(np.uint32)
+                v16 = p16[:200000].cpu().numpy().view(np.uint32).astype(np.int64)
                 no = v16 == 0xFFFFFFFF
                 assert ((s8 == np.where(no, -1, v16 & 0xFFFF)) & (e8 == np.where(no, -1, v16 >> 16))).all()
             per_row = {None: 8, "packed16": 4, "packed8": 2}[form] if is_find else 0
