@@ -1,6 +1,7 @@
 """Random DICTIONARIES against the oracle: keyword unions big enough for the compressed automaton (mode 6) and its lengths program, with
 keywords that are prefixes / suffixes / infixes of one another (states with a match pending that live on: END records, D_L rows as
 default rows), planted at row ends and cut by ragged lengths.  python scripts/dictionary_fuzz.py <seed0> <n>   (FUZZ_MIN_LEN=5 | 7: dictionaries the n-gram filter takes; FUZZ_UTF16=1: the rows as UTF-16)
+FUZZ_UTF16=3: keywords in three scripts (Latin, Cyrillic, CJK) over mixed-script UTF-16 rows -- the WIDE filter (with FUZZ_MIN_LEN >= 5).
 (child processes: NEEDLE_MAX_PROG_LDS is read once per process)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,16 +33,23 @@ if fuzz_min:                                            # becomes possible, 7: s
 words = sorted(words)
 rng.shuffle(words)
 cyr = int(os.environ.get("FUZZ_UTF16", "0")) == 2  # 2: the dictionary in Cyrillic letters (page 4 of the BMP) over UTF-16 rows
+mixed = int(os.environ.get("FUZZ_UTF16", "0")) == 3  # 3: keyword i in script i % 3 -- Latin, Cyrillic, CJK ideographs on 26 pages -- over mixed-script
+SCRIPT = [lambda k: 97 + k, lambda k: 0x0430 + k, lambda k: 0x4E00 + 0x3FD * k]  # UTF-16 rows: no single page, the WIDE filter (FUZZ_MIN_LEN >= 5)
+def enc(i):  # keyword i as the code units the text holds
+    if mixed: return np.array([SCRIPT[i % 3](ord(c) - 97) for c in words[i]], dtype=np.uint16)
+    return np.frombuffer(words[i].encode(), dtype=np.uint8)
 rx = "|".join("".join(chr(0x0430 + ord(c) - 97) for c in w) for w in words) if cyr else "|".join(words)
+if mixed: rx = "|".join("".join(chr(int(u)) for u in enc(i)) for i in range(len(words)))
 p = DFACompiler.compile(rx, "t", 0)
 o, _ = oracle_for(rx, 0)
 pi = p.program_info("forwards", 1)
 n, width = 20011, rng.choice([64, 112, 256])
 nr = np.random.default_rng(seed)
 noise = np.array([ord(c) for c in alpha + " "], dtype=np.uint8)
+if mixed: noise = np.array([f(ord(c) - 97) for f in SCRIPT for c in alpha] + [32, 32, 32], dtype=np.uint16)
 rows = nr.choice(noise, (n, width))
 for r in range(0, n, 3):  # plant: anywhere, at the very end, cut by the end
-    w = np.frombuffer(words[nr.integers(len(words))].encode(), dtype=np.uint8)
+    w = enc(int(nr.integers(len(words))))
     k = r % 9
     if k == 0: rows[r, width - len(w):] = w
     elif k == 3 and len(w) > 1: rows[r, width - len(w) + 1:] = w[:-1]
@@ -49,8 +57,9 @@ for r in range(0, n, 3):  # plant: anywhere, at the very end, cut by the end
         at = int(nr.integers(0, width - len(w) + 1)); rows[r, at:at + len(w)] = w
 if fuzz_min:  # near misses: a keyword's tail behind a wrong first char (passes the filter, matches nothing -- unless it does)
     for r in range(1, n, 3):
-        w = np.frombuffer(words[nr.integers(len(words))].encode(), dtype=np.uint8).copy()
-        w[0] = ord(alpha[nr.integers(len(alpha))])
+        wi = int(nr.integers(len(words)))
+        w = enc(wi).copy()
+        w[0] = SCRIPT[wi % 3](int(nr.integers(len(alpha)))) if mixed else ord(alpha[nr.integers(len(alpha))])
         at = int(nr.integers(0, width - len(w) + 1)); rows[r, at:at + len(w)] = w
 utf16 = int(os.environ.get("FUZZ_UTF16", "0"))  # the same rows as UTF-16 (Java's strings), chars above 0xFF sprinkled over text and keywords:
 if utf16:                                        # dictionaries with a filter take the byte program's filter kernel, the text narrowed on the fly
@@ -92,7 +101,7 @@ for l, dl in ((None, None), (lens, tl)):
     cc = p.count_matches_batch(t, dl).cpu().numpy()
     for i, w in want.items():
         assert cc[i] == len(w), ("count pass", seed, i)
-pf = p.prefilter_info("forwards")
+pf = p.prefilter_info("forwards", wide=mixed)
 ft = p.find_all_transducer(1)  # (the budget is the process's: a transducer reported here is the one find-all walked in lock-step)
 print("DICT-OK seed %d%s: %d keywords over %d letters, %d states, mode %d, lengths form %d, n-gram filter %s, find-all %s, %d of %d rows match" % (
     seed, " (UTF-16 rows, %d filter launches)" % p.prefilter_state("forwards")["filter_launches"] if utf16 else "", len(words), len(alpha), pi["n_states"], pi["mode"], pi["lengths_form"],
