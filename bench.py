@@ -773,6 +773,59 @@ def measure(workload, args, ctx, headline):
     return out, total_rows
 
 
+def measure_ragged(workload, args, ctx):
+    """The ragged variant SURVEY.md s8(d) / BASELINE.md s2 name: the same 10^7 x 256 batch with per-row lengths uniform in [1, 256]
+    (a length table beside the rows; the kernels' GUARD instantiations).  The roofline fraction is over the ACTUAL bytes -- the chars
+    inside the rows' lengths + 4 B of length + the result bytes per row -- not the nominal 256 per row.  c2r: '[0-9]+' containedIn(),
+    c3r: the 1000-keyword union find().  W warm-up steps, K steps between two HIP events on the launch stream."""
+    import torch
+    from needle_amd.pattern import unpack_bitmap
+    base = workload[:-1]
+    pattern, what, words = make_pattern(base)
+    n = args.rows
+    rows = make_rows(base, words, 0, n, ctx.dev)
+    lens = (torch.arange(n, device=ctx.dev, dtype=torch.int64) * 2654435761 % 256 + 1).to(torch.int32)
+    is_find = base != "c2"
+    words_n = (n + 63) // 64
+    bitmap = torch.empty(words_n, dtype=torch.int64, device=ctx.dev)
+    st = torch.empty(n, dtype=torch.int32, device=ctx.dev) if is_find else None
+    en = torch.empty(n, dtype=torch.int32, device=ctx.dev) if is_find else None
+
+    def run():
+        if is_find:
+            pattern.find_batch(rows, lens, out=(bitmap, st, en))
+        else:
+            pattern.contained_in_batch(rows, lens, out=bitmap)
+    for _ in range(max(2, args.warmup)):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    chars = int(lens.sum().item())
+    actual = chars + n * (4 + (8 if is_find else 0)) + words_n * 8
+    matched = int(unpack_bitmap(bitmap, n).sum())
+    out = {"workload": "%s: %s, per-row lengths uniform in [1, 256] over %d x 256 ASCII rows" % (workload, what, n), "ms_per_step": ms,
+           "actual_bytes": actual, "chars": chars, "GB/s": actual / ms / 1e6, "frac_of_hbm_peak": actual / ms / 1e6 / HBM_PEAK_GBS,
+           "nominal_GB/s": n * 256 / ms / 1e6, "matched_fraction": matched / n,
+           "note": "bytes = chars inside the rows' lengths + 4 B length + result bytes per row; the rows stay 256 bytes apart, so the lines a "
+                   "short row shares with nothing else are fetched all the same (nominal_GB/s = 256 B per row / time)"}
+    if not is_find:  # '[0-9]+': recomputed with torch on the device
+        col = torch.arange(256, device=ctx.dev, dtype=torch.int32)[None, :]
+        want = 0
+        for s0 in range(0, n, 1 << 20):
+            r = rows[s0:s0 + (1 << 20)]
+            want += int((((r >= 48) & (r <= 57)) & (col < lens[s0:s0 + (1 << 20), None])).any(dim=1).sum().item())
+        assert want == matched, ("c2r containedIn", want, matched)
+        out["verified"] = "torch recomputation of all %d rows" % n
+    del rows, lens, bitmap
+    return out
+
+
 def _r(x, n=4):
     return round(x, n) if isinstance(x, float) else x
 
@@ -839,6 +892,9 @@ def slim_line(out):
                                  for w, v in out["c4_shard_step"].items()}
     if "workloads" in out:
         line["workloads"] = {w: slim(v) for w, v in out["workloads"].items()}
+    if "ragged" in out:
+        line["ragged"] = {w: ({"ms": _r(v["ms_per_step"]), "GBs": _r(v["GB/s"], 1), "frac": _r(v["frac_of_hbm_peak"]), "nominal_GBs": _r(v["nominal_GB/s"], 1)}
+                              if "error" not in v else v) for w, v in out["ragged"].items()}
     line["full"] = "stderr, bench_full.json"
     return line
 
@@ -995,6 +1051,13 @@ def main():
             except Exception as e:  # noqa: BLE001 -- a further workload must never cost the headline its line
                 r = {"error": "%s: %s" % (type(e).__name__, e)}
             out["workloads"][w] = r
+    if world == 1 and not use_dist and not args.no_extras and args.rows == 10_000_000 and args.regex is None and args.op is None and args.also is None:
+        out["ragged"] = {}
+        for w in ("c2r", "c3r"):
+            try:
+                out["ragged"][w] = measure_ragged(w, args, ctx)
+            except Exception as e:  # noqa: BLE001
+                out["ragged"][w] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         # The driver keeps the last 8 KB of stdout: the ONE line printed there is the contract's fields + roofline + cpu_baseline +
         # a compact digest of every workload (slim()); everything measured, with its notes, goes to stderr and bench_full.json.
