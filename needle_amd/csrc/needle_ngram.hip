@@ -17,6 +17,8 @@
 // that accepts first.  find() takes "lengths" programs (start = end - pend[stop state], needle_lower.h) or patterns of one
 // length (DFAClassBuilder.java:640-646).
 #include <string.h>
+#include <stdio.h>
+#include <vector>
 #include "needle_walk.h"
 #include "needle_ngram.h"
 
@@ -39,6 +41,9 @@ struct NgramArgs {
     uint32_t fa_count_only;     // 1: nothing is filed, every match is counted
     uint32_t dbg;           // measurement builds (-DNEEDLE_TUNING) only: NEEDLE_NG_DBG -- 1: candidates are dropped, 2: text gathered but
                             // no walk, 3: walk on zeros (no gather), +16: runs start as soon as 32 candidates wait; 0 in the product
+    uint64_t *stamps;       // measurement builds only (NEEDLE_NG_STAMPS): per wave 8 x uint64 -- shader cycles (s_memtime) by section of the
+                            // kernel: 0 waiting for the unit's text, 1 hashing / probing (+ issuing the next load), 2 queue pushes and loop
+                            // control, 3 second-level windows, 4 verify walks, 5 a group's begin / end (slots, results), 6 staging, 7 total
     uint32_t stride_log2;   // stride_bytes is a power of two (else 0xFFFFFFFF)
     uint32_t stride_recip;  // floor(2^32 / stride_bytes)
     uint32_t char_width;    // 2: UTF-16 rows narrowed on the fly (needle_ngram.h narrow16); a.stride_bytes / a.total_bytes then count CHARS
@@ -111,9 +116,27 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     const uint32_t K = A.ng.warm;
 #ifdef NEEDLE_TUNING
     const uint32_t dbg = A.dbg & 15u, full_set = (A.dbg & 16u) ? 32u : 64u;
+    // NEEDLE_NG_STAMPS: where a wave's cycles go -- every NG_STAMP(k) books the shader cycles since the previous stamp on section k
+    const bool stamps_on = A.stamps != nullptr;
+    uint64_t T[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t_last = __builtin_amdgcn_s_memtime(), t_first = t_last;
+#define NG_STAMP(k)                                              \
+    if (stamps_on) {                                             \
+        const uint64_t n_ = __builtin_amdgcn_s_memtime();        \
+        T[k] += n_ - t_last;                                     \
+        t_last = n_;                                             \
+    }
+#define NG_WAIT_UNIT()                                                                                   \
+    if (stamps_on) {                                                                                     \
+        if (CW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                    \
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                            \
+    }
 #else
     constexpr uint32_t dbg = 0, full_set = 64u;
+#define NG_STAMP(k)
+#define NG_WAIT_UNIT()
 #endif
+    NG_STAMP(6)
     const uint32_t stride = (uint32_t)a.stride_bytes;
 
     const uint64_t n_groups = (a.n_rows + 63) >> 6;
@@ -346,6 +369,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         const uint32_t gbytes = rows_in * stride;
         const uint32_t units = units_of(g);
         n_units += units;
+        NG_STAMP(5)
         // ---- the group's result slots
         if (FA) *(lds_u32_t *)(uintptr_t)(cbase + (uint32_t)lane * 4u) = 0u;
         else if (OP == OP_FIND) *(lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u) = ~0ull;
@@ -369,6 +393,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             uint32_t log = 0;
 #pragma unroll
             for (int k = 0; k < kNgPF; ++k) {
+                NG_STAMP(2)
+                NG_WAIT_UNIT()
+                NG_STAMP(0)
                 const Raw raw = R[k];
                 asm volatile("" ::: "memory");
                 R[k] = load_next();
@@ -384,6 +411,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], mm, amask, bm_base);
                 }
             }
+            NG_STAMP(1)
             const uint32_t po0 = (u0 << 10) + lane16; // byte offset of this lane's piece of the batch's first unit
             if (NW * kNgPF < 32) log >>= 32 - NW * kNgPF; // window wi of unit j at bit j * NW + wi
             if (gbytes < ((u0 + kNgPF) << 10)) { // wave-uniform: the batch's last group: pieces past its rows hold nothing
@@ -419,9 +447,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                     locate(e, row, qn);
                     const bool valid = act && row < rows_in && qn >= 4u;
                     if (!L2ON) { // ---- run the automaton on them
+                        NG_STAMP(2)
                         run_rows(g, row, valid, qn, qn > K ? qn - K : 0u, qn + (uint32_t)S - 1u);
+                        NG_STAMP(4)
                         continue;
                     }
+                    NG_STAMP(2)
                     // ---- second level: the 5-byte window [qn - 5, qn) -- 8 bytes of the candidate's text from memory, one more probe;
                     // what passes (on random text 1 in 27 of the first level's chance hits, and every real keyword tail) waits in the
                     // second queue until 64 of them make a run worth its ~10 dependent lookups
@@ -430,13 +461,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                     const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                     if (pass) *(lds_u32_t *)(uintptr_t)(q2base + (((q2tail + prank) & (kNgQueue - 1u)) << 2)) = e;
                     q2tail += (uint32_t)__builtin_popcountll(pm);
+                    NG_STAMP(3)
                     drain2((thr == 1u && qtail == qhead) ? 1u : 64u);
+                    NG_STAMP(4)
                 }
+                NG_STAMP(2)
                 if (L2ON && thr == 1u) drain2(1u); // the group's end: whatever still waits
+                NG_STAMP(4)
                 if (!more) break;
             }
         }
         // ---- the group's verdicts: lane = row
+        NG_STAMP(2)
         asm volatile("" ::: "memory");
         if (FA) {
             // Every non-overlapping match of the row, as the reference's repeated find() reports them (DFAClassBuilder.java:616-659): after
@@ -530,6 +566,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         }
         asm volatile("" ::: "memory");
     }
+    NG_STAMP(5)
+#ifdef NEEDLE_TUNING
+    if (stamps_on && lane == 0) {
+        uint64_t *o = A.stamps + ((uint64_t)blockIdx.x * kWavesPerBlock + (uint32_t)wave) * 8u;
+        T[7] = t_last - t_first;
+        for (int k = 0; k < 8; ++k) o[k] = T[k];
+    }
+#endif
     // what the host's flood watch reads (needle_api.cpp): candidates and KiB of text of this launch
     {
         const KernargPtr ka = kernarg_here();
@@ -644,6 +688,36 @@ static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams 
     A.dbg = dbg_env;
 #endif
     const size_t lds = A.lay.total;
+#ifdef NEEDLE_TUNING
+    // NEEDLE_NG_STAMPS=1: every launch is followed by a device synchronisation and one line on stderr -- the waves' shader cycles by
+    // section (the kernel's NG_STAMP points), summed over all waves, as shares of their total lifetime
+    static const bool stamps_env = getenv("NEEDLE_NG_STAMPS") && atoi(getenv("NEEDLE_NG_STAMPS")) != 0;
+    if (stamps_env) {
+        static uint64_t *d_stamps = nullptr;
+        const size_t n_waves = (size_t)n_cus * kWavesPerBlock, bytes = n_waves * 8 * sizeof(uint64_t);
+        if (!d_stamps && hipMalloc((void **)&d_stamps, 4096 * 8 * sizeof(uint64_t)) != hipSuccess) return hipErrorOutOfMemory;
+        if (n_waves > 4096) return hipErrorInvalidValue;
+        (void)hipMemsetAsync(d_stamps, 0, bytes, stream);
+        A.stamps = d_stamps;
+        hipError_t e = op == OP_NG_FIND_ALL ? launch_ng_m<OP_NG_FIND_ALL>(A, n_cus, lds, stream)
+                       : op == OP_FIND      ? launch_ng_m<OP_FIND>(A, n_cus, lds, stream)
+                                            : launch_ng_m<OP_CONTAINED_IN>(A, n_cus, lds, stream);
+        if (e != hipSuccess) return e;
+        std::vector<uint64_t> h(n_waves * 8);
+        e = hipStreamSynchronize(stream);
+        if (e == hipSuccess) e = hipMemcpy(h.data(), d_stamps, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx = 0;
+        for (size_t w = 0; w < n_waves; ++w) {
+            for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k];
+            if ((double)h[w * 8 + 7] > mx) mx = (double)h[w * 8 + 7];
+        }
+        fprintf(stderr, "NG-STAMPS op %d mode %u S %u cw %d wide %u: waves %zu, mean lifetime %.0f cycles (max %.0f); shares: text-wait %.3f probe %.3f queue %.3f level2 %.3f walk %.3f group %.3f staging %.3f\n",
+                op, a.hdr.mode, ng.stride, char_width, ng.wide, n_waves, sum[7] / n_waves, mx, sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7],
+                sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[6] / sum[7]);
+        return hipSuccess;
+    }
+#endif
     if (op == OP_NG_FIND_ALL) return launch_ng_m<OP_NG_FIND_ALL>(A, n_cus, lds, stream);
     return op == OP_FIND ? launch_ng_m<OP_FIND>(A, n_cus, lds, stream) : launch_ng_m<OP_CONTAINED_IN>(A, n_cus, lds, stream);
 }

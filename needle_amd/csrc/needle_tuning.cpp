@@ -56,6 +56,7 @@ const Switch kSwitches[] = {
     {"NEEDLE_DEBUG_NFA", "(unset)", "debug", "dumps the forward Thompson program of needle_compile"},
     {"NEEDLE_DICT", "0", "measurement build", "two 64-row sets per wave for big automata (needle_dict.hip): 1 compressed form, 2 also uint16 tables"},
     {"NEEDLE_NG_DBG", "0", "measurement build", "n-gram filter kernel time breakdown (drops candidates / skips walks: timing only)"},
+    {"NEEDLE_NG_STAMPS", "0", "measurement build", "1: every n-gram filter launch is synchronised and prints where its waves' shader cycles went (text wait / probes / queue / second level / verify walks / group ends)"},
     {"NEEDLE_DEBUG_NO_BACKWARD", "(unset)", "measurement build", "find() with start := end (the bound the lengths automaton was built to reach)"},
 };
 } // namespace
