@@ -410,6 +410,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);
                 log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], mm, amask, bm_base);
                 }
+                NG_STAMP(1)
             }
             NG_STAMP(1)
             const uint32_t po0 = (u0 << 10) + lane16; // byte offset of this lane's piece of the batch's first unit
