@@ -151,11 +151,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         const uint32_t rows_in = (uint32_t)(a.n_rows - (grp << 6));
         return (((rows_in * stride + 1023u) >> 10) + (kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
     };
-    // The prefetch cursor, kNgPF units ahead of the batch being filtered: the byte offset of the next unit to load is carried along
-    // (+ 1 KiB per unit) and only recomputed when the cursor moves to another group, together with a flag that says whether the whole
-    // group lies inside the batch -- a unit of such a group needs no clamping.  (Recomputing (group * 64) * stride + unit * 1024 and
-    // comparing it with the batch's size for EVERY unit cost ~30 scalar and half a dozen vector instructions per KiB: the kernel issued
-    // 61 SALU per unit beside its 98 VALU, through the CU's one scalar unit.)
+    // The prefetch cursor, one batch (kNgPF units) ahead of the one being filtered: the byte offset of its first unit is carried along
+    // (+ 4 KiB per batch) and only recomputed when the cursor moves to another group, together with a flag that says whether the whole
+    // group lies inside the rows -- a unit of such a group needs no clamping.
     const uint32_t lane16 = (uint32_t)lane * 16u;
     uint64_t pf_g = g, pf_base = 0;
     uint32_t pf_u = 0, pf_units = 0;
@@ -166,36 +164,49 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         pf_units = pf_g < n_groups ? units_of(pf_g) : (uint32_t)kNgPF;
         pf_interior = pf_g < n_groups && pf_base + ((uint64_t)pf_units << 10) <= a.total_bytes;
     };
-    // 16 bytes of the cursor's unit.  Always issued (a load under a branch makes the compiler drain vmcnt at the join); units past the
-    // batch are read from its last KiB, lanes past it from its last 16 bytes -- never used.
+    // The cursor stands on a BATCH (kNgPF units of one group); unit k of it is loaded while unit k of the batch before is filtered, and the
+    // cursor moves on after the batch's last unit.  In a group that lies inside the rows entirely (pf_interior: all but the batch's last
+    // groups) a unit's load is ONE instruction -- uniform base (SGPRs), the lane's offset, the unit's as an immediate; elsewhere units past
+    // the rows are read from their last KiB, lanes past them from their last 16 bytes -- never used.  Both arms of the (wave-uniform)
+    // branch issue the same loads, so the compiler's vmcnt bookkeeping is the same on both.  (Round 5's per-UNIT cursor cost ~18
+    // instructions and two branches per KiB -- a quarter of the filter phase: profiles/r06_filter_trace.md.)
     struct Raw { u32x4 lo, hi; }; // 16 chars as loaded (CW = 1: lo only)
-    auto load_next = [&]() __attribute__((always_inline)) -> Raw {
-        uint64_t base = pf_base;
+    auto load_unit = [&](int k) __attribute__((always_inline)) -> Raw {
+        Raw v;
+        if (pf_interior) {
+            const uint8_t *src = a.rows + pf_base * CW + (size_t)k * (1024u * CW);
+            v.lo = *(const u32x4 *)(src + lane16 * CW);
+            if (CW == 2) v.hi = *(const u32x4 *)(src + lane16 * CW + 16);
+            return v;
+        }
+        uint64_t base = pf_base + (uint64_t)k * 1024u;
         uint32_t off = lane16;
-        if (!pf_interior) { // wave-uniform: the batch's last group(s), or a prefetch past the end
-            if (base + 1024u > a.total_bytes) {
-                if (base + 16u > a.total_bytes) base = a.total_bytes - 16u;
-                const uint32_t room = (uint32_t)(a.total_bytes - 16u - base);
-                off = off < room ? off : room;
-            }
+        if (base + 1024u > a.total_bytes) {
+            if (base + 16u > a.total_bytes) base = a.total_bytes - 16u;
+            const uint32_t room = (uint32_t)(a.total_bytes - 16u - base);
+            off = off < room ? off : room;
         }
         // (tried for MODE_GLOBAL, whose walks read the table out of L2: nontemporal text loads -- c3x 1.09 -> 1.19 ms: the candidates' own
         // text then never hits the L2 either)
-        Raw v;
         const uint8_t *src = a.rows + (base + off) * CW;
         v.lo = *(const u32x4 *)src;
         if (CW == 2) v.hi = *(const u32x4 *)(src + 16);
-        pf_base += 1024u;
-        if (++pf_u == pf_units) {
+        asm volatile("" ::: "memory"); // (keeps the two arms' loads apart: merged, the fast arm would form a 64-bit VGPR address too)
+        return v;
+    };
+    auto advance_batch = [&]() __attribute__((always_inline)) {
+        pf_u += (uint32_t)kNgPF;
+        pf_base += 1024u * kNgPF;
+        if (pf_u >= pf_units) {
             pf_g += wave_cnt;
             pf_enter_group();
         }
-        return v;
     };
     pf_enter_group();
     Raw R[kNgPF];
 #pragma unroll
-    for (int k = 0; k < kNgPF; ++k) R[k] = load_next();
+    for (int k = 0; k < kNgPF; ++k) R[k] = load_unit(k);
+    advance_batch();
     // 16 chars of text at p (unaligned) as 16 bytes
     auto text16 = [&](const uint8_t *p) __attribute__((always_inline)) -> u32x4 {
         if (CW == 1) return *(const u32x4_u *)p;
@@ -398,7 +409,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 NG_STAMP(0)
                 const Raw raw = R[k];
                 asm volatile("" ::: "memory");
-                R[k] = load_next();
+                R[k] = load_unit(k);
+                if (k == kNgPF - 1) advance_batch();
                 asm volatile("" ::: "memory");
                 if (WIDE) {
                     const uint32_t pw = ngram_prev_dword(raw.hi[3], carry);
