@@ -165,33 +165,37 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         pf_interior = pf_g < n_groups && pf_base + ((uint64_t)pf_units << 10) <= a.total_bytes;
     };
     // The cursor stands on a BATCH (kNgPF units of one group); unit k of it is loaded while unit k of the batch before is filtered, and the
-    // cursor moves on after the batch's last unit.  In a group that lies inside the rows entirely (pf_interior: all but the batch's last
-    // groups) a unit's load is ONE instruction -- uniform base (SGPRs), the lane's offset, the unit's as an immediate; elsewhere units past
-    // the rows are read from their last KiB, lanes past them from their last 16 bytes -- never used.  Both arms of the (wave-uniform)
-    // branch issue the same loads, so the compiler's vmcnt bookkeeping is the same on both.  (Round 5's per-UNIT cursor cost ~18
+    // cursor moves on after the batch's last unit.  A unit's load is ONE instruction -- the batch's base (SGPRs) + a per-unit lane offset
+    // nb_off[k] that is set when the cursor moves: lane * 16 + k * 1024, clamped to the rows' last 16 bytes in the batch's last group(s)
+    // (units past the rows read their last KiB, lanes past them their last 16 bytes -- never used).  No branch around a load: with one the
+    // compiler's vmcnt bookkeeping gives up and waits for EVERY load in flight (measured: + 4.5 %).  (Round 5's per-UNIT cursor cost ~18
     // instructions and two branches per KiB -- a quarter of the filter phase: profiles/r06_filter_trace.md.)
     struct Raw { u32x4 lo, hi; }; // 16 chars as loaded (CW = 1: lo only)
+    const uint8_t *nb_ptr = a.rows;
+    uint32_t nb_off[kNgPF]; // in bytes
+    auto set_batch = [&]() __attribute__((always_inline)) {
+        uint64_t base = pf_base;
+        uint32_t room = 0xFFFFFFFFu; // chars between the batch's base and the last place a 16-char load may start
+        if (!pf_interior) { // wave-uniform: the rows' last group(s), or a prefetch past their end
+            const uint64_t last = a.total_bytes - 16u;
+            base = base < last ? base : last;
+            const uint64_t r = last - base;
+            room = r < 0x7FFFFFFFull ? (uint32_t)r : 0x7FFFFFFFu;
+        }
+        nb_ptr = a.rows + base * CW;
+#pragma unroll
+        for (int k = 0; k < kNgPF; ++k) {
+            const uint32_t o = lane16 + (uint32_t)k * 1024u;
+            nb_off[k] = (o < room ? o : room) * CW;
+        }
+    };
     auto load_unit = [&](int k) __attribute__((always_inline)) -> Raw {
-        Raw v;
-        if (pf_interior) {
-            const uint8_t *src = a.rows + pf_base * CW + (size_t)k * (1024u * CW);
-            v.lo = *(const u32x4 *)(src + lane16 * CW);
-            if (CW == 2) v.hi = *(const u32x4 *)(src + lane16 * CW + 16);
-            return v;
-        }
-        uint64_t base = pf_base + (uint64_t)k * 1024u;
-        uint32_t off = lane16;
-        if (base + 1024u > a.total_bytes) {
-            if (base + 16u > a.total_bytes) base = a.total_bytes - 16u;
-            const uint32_t room = (uint32_t)(a.total_bytes - 16u - base);
-            off = off < room ? off : room;
-        }
         // (tried for MODE_GLOBAL, whose walks read the table out of L2: nontemporal text loads -- c3x 1.09 -> 1.19 ms: the candidates' own
         // text then never hits the L2 either)
-        const uint8_t *src = a.rows + (base + off) * CW;
+        Raw v;
+        const uint8_t *src = nb_ptr + nb_off[k];
         v.lo = *(const u32x4 *)src;
         if (CW == 2) v.hi = *(const u32x4 *)(src + 16);
-        asm volatile("" ::: "memory"); // (keeps the two arms' loads apart: merged, the fast arm would form a 64-bit VGPR address too)
         return v;
     };
     auto advance_batch = [&]() __attribute__((always_inline)) {
@@ -201,8 +205,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             pf_g += wave_cnt;
             pf_enter_group();
         }
+        set_batch();
     };
     pf_enter_group();
+    set_batch();
     Raw R[kNgPF];
 #pragma unroll
     for (int k = 0; k < kNgPF; ++k) R[k] = load_unit(k);
