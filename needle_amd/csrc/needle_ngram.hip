@@ -97,12 +97,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     wk.win_hi = a.hdr.win_hi_e;
     constexpr bool FINDLIKE = OP != OP_CONTAINED_IN; // find() and find-all: first accept, then on until the automaton dies
     constexpr bool FA = OP == OP_NG_FIND_ALL;
-    // Rows per group.  find / containedIn: 128 -- a group's candidates are verified 64 at a time, and what is left at the group's end runs
-    // with as many lanes as it has: on text where a quarter of the rows holds a keyword that is ~16 of a 64-row group's 64 lanes (a third of
-    // the kernel's instructions went into those runs: profiles/r06_filter_trace.md), with 128 rows twice as many.  The LDS per wave stays
-    // what it was: find()'s slot per row shrinks to one dword (first accept << 16 | last - first << 8 | length: lengths are a byte, pend[]).
-    // find-all keeps 64 (two 8-byte slots + a counter per row).
-    constexpr uint32_t GSH = FA ? 6u : 7u, GR = 1u << GSH;
     wk.dead_hi = FINDLIKE ? a.hdr.fa_dead_hi : 0u;
     wk.sp_chains = a.hdr.sp_chains;
     wk.sp_pad_ident = a.hdr.sp_pad_ident;
@@ -145,16 +139,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     NG_STAMP(6)
     const uint32_t stride = (uint32_t)a.stride_bytes;
 
-    const uint64_t n_groups = (a.n_rows + (GR - 1u)) >> GSH;
+    const uint64_t n_groups = (a.n_rows + 63) >> 6;
     const uint64_t wave_cnt = (uint64_t)gridDim.x * n_waves;
     uint64_t g = (uint64_t)blockIdx.x * n_waves + wave;
     if (g >= n_groups) return;
     // a group is stride / 16 units; batches are kNgPF units: where that does not divide, a group's last batch reaches into the next
     // group's text (read, masked, not used -- ngram_shape_ok bounds the waste)
-    const uint32_t units_full = (((GR * stride) >> 10) + (uint32_t)(kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
+    const uint32_t units_full = (((64u * stride) >> 10) + (uint32_t)(kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
     auto units_of = [&](uint64_t grp) -> uint32_t {
         if (grp + 1 < n_groups) return units_full;
-        const uint32_t rows_in = (uint32_t)(a.n_rows - (grp << GSH));
+        const uint32_t rows_in = (uint32_t)(a.n_rows - (grp << 6));
         return (((rows_in * stride + 1023u) >> 10) + (kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
     };
     // The prefetch cursor, one batch (kNgPF units) ahead of the one being filtered: the byte offset of its first unit is carried along
@@ -166,7 +160,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     bool pf_interior = false;
     auto pf_enter_group = [&]() __attribute__((always_inline)) {
         pf_u = 0;
-        pf_base = (pf_g << GSH) * a.stride_bytes;
+        pf_base = (pf_g << 6) * a.stride_bytes;
         pf_units = pf_g < n_groups ? units_of(pf_g) : (uint32_t)kNgPF;
         pf_interior = pf_g < n_groups && pf_base + ((uint64_t)pf_units << 10) <= a.total_bytes;
     };
@@ -239,7 +233,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         int32_t start;
     };
     auto walk_row = [&](uint64_t grp, uint32_t row, bool valid, uint32_t qn, uint32_t r, uint32_t lim0) __attribute__((always_inline)) -> Hit {
-        const uint64_t grow = (grp << GSH) + row;
+        const uint64_t grow = (grp << 6) + row;
         uint32_t len = a.row_len;
         const KernargPtr ka = kernarg_here();
         const uint32_t *const lens = NEEDLE_NG_PTR(const uint32_t, a.lengths);
@@ -340,13 +334,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 if (ord < kNgRowSlots) *(lds_u64_t *)(uintptr_t)(sbase + (row * kNgRowSlots + ord) * 8u) = ent;
             }
         } else if (OP == OP_FIND) {
-            if (h.found) { // (several windows of a row may find matches: the reference's is the one that accepts first)
-                const uint32_t ext = h.last - h.first, mlen = (uint32_t)((int32_t)h.last - h.start);
-                const uint32_t key = h.first << 16 | (ext < 255u ? ext : 255u) << 8 | (mlen & 255u);
-                __hip_atomic_fetch_min((lds_u32_t *)(uintptr_t)(sbase + row * 4u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (h.found) {
+                const uint64_t key = (uint64_t)h.first << 32 | (uint64_t)h.last << 16 | (uint64_t)(uint32_t)h.start;
+                __hip_atomic_fetch_min((lds_u64_t *)(uintptr_t)(sbase + row * 8u), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         } else if (h.found) {
-            __hip_atomic_fetch_or((lds_u64_t *)(uintptr_t)(sbase + (row >> 6) * 8u), 1ull << (row & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_or((lds_u64_t *)(uintptr_t)sbase, 1ull << row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
 
@@ -366,7 +359,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     const uint32_t bm2_base = A.lay.bm2_base, amask2 = A.ng.addr_mask2, m3 = A.ng.m3;
     auto level2 = [&](uint64_t grp, uint32_t row, uint32_t qn) __attribute__((always_inline)) -> bool {
         typedef uint32_t u32_u __attribute__((aligned(1)));
-        const uint8_t *rowp = a.rows + ((grp << GSH) + row) * a.stride_bytes * CW;
+        const uint8_t *rowp = a.rows + ((grp << 6) + row) * a.stride_bytes * CW;
         const bool deep = qn >= 5u;
         uint32_t w, c5;
         if (WIDE) { // the window's two dwords as they stand (qn is even: they are aligned) + the unit in front of them
@@ -389,17 +382,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     uint32_t qhead = 0, qtail = 0; // wave-uniform
     uint32_t n_cand = 0, n_units = 0; // what this wave saw: candidates, KiB units of text (-> A.stats: the host's flood watch)
     for (; g < n_groups; g += wave_cnt) {
-        const uint32_t rows_in = (g + 1 < n_groups) ? GR : (uint32_t)(a.n_rows - (g << GSH));
+        const uint32_t rows_in = (g + 1 < n_groups) ? 64u : (uint32_t)(a.n_rows - (g << 6));
         const uint32_t gbytes = rows_in * stride;
         const uint32_t units = units_of(g);
         n_units += units;
         NG_STAMP(5)
         // ---- the group's result slots
         if (FA) *(lds_u32_t *)(uintptr_t)(cbase + (uint32_t)lane * 4u) = 0u;
-        else if (OP == OP_FIND) {
-#pragma unroll
-            for (uint32_t hh = 0; hh < GR / 64u; ++hh) *(lds_u32_t *)(uintptr_t)(sbase + (hh * 64u + (uint32_t)lane) * 4u) = ~0u;
-        } else if ((uint32_t)lane < GR / 64u) *(lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u) = 0ull;
+        else if (OP == OP_FIND) *(lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u) = ~0ull;
+        else if (lane == 0) *(lds_u64_t *)(uintptr_t)sbase = 0ull;
         uint32_t carry = 0; // (the window reaching back from a row's first bytes is dropped below: what it holds does not matter)
         // run the automaton on the second queue's candidates, 64 at a time, while at least `at_least` wait
         auto drain2 = [&](uint32_t at_least) __attribute__((always_inline)) {
@@ -571,35 +562,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
             if (row_ok && A.fa_counts) A.fa_counts[(g << 6) + lane] = cnt;
             if (__ballot(more_f) != 0ull && lane == 0) *A.fa_more = 1;
         } else if (OP == OP_FIND) {
+            const uint64_t key = *(const lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u);
+            const bool row_ok = (uint32_t)lane < rows_in;
+            const bool res = row_ok && key != ~0ull;
+            const uint64_t word = __ballot(res);
             const KernargPtr ka = kernarg_here();
-            const int32_t fixed_len = (int32_t)NEEDLE_NG_U32(a.fixed_len);
-#pragma unroll
-            for (uint32_t hh = 0; hh < GR / 64u; ++hh) { // 64 rows at a time: lane = row
-                const uint32_t row = hh * 64u + (uint32_t)lane;
-                const uint64_t grow = (g << GSH) + row;
-                const uint32_t key = *(const lds_u32_t *)(uintptr_t)(sbase + row * 4u);
-                const bool row_ok = row < rows_in;
-                const bool res = row_ok && key != ~0u;
-                const uint64_t word = __ballot(res);
-                if (hh * 64u >= rows_in) break; // (wave-uniform: the batch's last group)
-                if (lane == 0) NEEDLE_NG_PTR(uint64_t, a.bitmap)[(g << (GSH - 6u)) + hh] = word;
-                const int32_t en = (int32_t)((key >> 16) + ((key >> 8) & 255u));
-                const int32_t st_ = en - (fixed_len >= 0 ? fixed_len : (int32_t)(key & 255u));
-                if (row_ok) {
-                    uint32_t *const o_packed = NEEDLE_NG_PTR(uint32_t, a.packed);
-                    if (o_packed && NEEDLE_NG_U32(a.packed8)) { // one uint16 per row (rows <= 256 chars)
-                        ((uint16_t *)o_packed)[grow] = pack8(res ? st_ : -1, res ? en : -1);
-                    } else if (o_packed) { // start | end << 16; ~0 = no match
-                        o_packed[grow] = res ? ((uint32_t)st_ & 0xFFFFu) | (uint32_t)en << 16 : 0xFFFFFFFFu;
-                    } else {
-                        NEEDLE_NG_PTR(int32_t, a.start)[grow] = res ? st_ : -1;
-                        NEEDLE_NG_PTR(int32_t, a.end)[grow] = res ? en : -1;
-                    }
+            if (lane == 0) NEEDLE_NG_PTR(uint64_t, a.bitmap)[g] = word;
+            if (row_ok) {
+                uint32_t *const o_packed = NEEDLE_NG_PTR(uint32_t, a.packed);
+                if (o_packed && NEEDLE_NG_U32(a.packed8)) { // one uint16 per row (rows <= 256 chars)
+                    ((uint16_t *)o_packed)[(g << 6) + lane] = pack8(res ? (int32_t)(key & 0xFFFFu) : -1, res ? (int32_t)((key >> 16) & 0xFFFFu) : -1);
+                } else if (o_packed) { // the key's low dword is end << 16 | start already; ~0 = no match
+                    o_packed[(g << 6) + lane] = (uint32_t)key;
+                } else {
+                    NEEDLE_NG_PTR(int32_t, a.start)[(g << 6) + lane] = res ? (int32_t)(key & 0xFFFFu) : -1;
+                    NEEDLE_NG_PTR(int32_t, a.end)[(g << 6) + lane] = res ? (int32_t)((key >> 16) & 0xFFFFu) : -1;
                 }
             }
-        } else if ((uint32_t)lane < GR / 64u && (uint32_t)lane * 64u < rows_in) {
+        } else if (lane == 0) {
             const KernargPtr ka = kernarg_here();
-            NEEDLE_NG_PTR(uint64_t, a.bitmap)[(g << (GSH - 6u)) + (uint32_t)lane] = *(const lds_u64_t *)(uintptr_t)(sbase + (uint32_t)lane * 8u);
+            NEEDLE_NG_PTR(uint64_t, a.bitmap)[g] = *(const lds_u64_t *)(uintptr_t)sbase;
         }
         asm volatile("" ::: "memory");
     }
