@@ -168,6 +168,8 @@ struct needle_pattern {
     //          8 the find-all transducer (lock-step find-all, needle_find_all_ls.hip; absent when the pattern does not allow it)
     //          9 the filter program of an automaton that fits the LDS in no form (lower_filter_hbm: HBM-table layout + n-gram filter;
     //            W_CONTAINED_IN, or W_FORWARDS in the lengths form / for one-length patterns; absent when no filter can be built)
+    //          11 the RUN transducer (lock-step find-all of patterns without bounded match lengths whose matches are runs: `[0-9]+`;
+    //            needle_lower.h lower_find_all_runs); absent when the pattern is not of that kind
     //          10 the WIDE filter program (lower_filter_wide: char_width 2 only -- UTF-16 rows of a pattern on several pages of the BMP:
     //            windows of four code units, UTF-16 HBM-table program); absent when no filter can be built
     std::map<std::tuple<int, int, int, int>, DevProgram> cache;
@@ -272,6 +274,13 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
             }
             dp.prog = variant == 10 ? lower_filter_wide(*tt, (Which)which, ml67) : lower_filter_hbm(*tt, (Which)which, ml67);
             if (dp.prog.blob.empty() || !dp.prog.ng.p.on) { // (no filter: the ordinary program is what runs)
+                p->cache.emplace(key, DevProgram());
+                *out = nullptr;
+                return NEEDLE_OK;
+            }
+        } else if (variant == 11) { // the RUN transducer (lock-step find-all of `[0-9]+`-like patterns: lower_find_all_runs); absent when the pattern is not one
+            dp.prog = lower_find_all_runs(*tt, cw, max_prog_lds());
+            if (dp.prog.blob.empty()) {
                 p->cache.emplace(key, DevProgram());
                 *out = nullptr;
                 return NEEDLE_OK;
@@ -1586,13 +1595,16 @@ int needle_pattern_find_all_transducer(const needle_pattern *cp, int char_width,
     if (!p || !available || (char_width != 1 && char_width != 2)) return fail(NEEDLE_ERR_INVALID, "bad argument");
     *available = 0;
     const MatchLengths *ml = pattern_ml(p);
-    if (!ml) return NEEDLE_OK;
-    const Program pr = lower_find_all_transducer(p->t, *ml, char_width, max_prog_lds());
+    Program pr;
+    memset(&pr.hdr, 0, sizeof(pr.hdr));
+    if (ml) pr = lower_find_all_transducer(p->t, *ml, char_width, max_prog_lds());
+    // (no transducer on the lengths automaton: the RUN transducer, if the pattern is one of runs -- info[11] = 2)
+    if ((pr.blob.empty() || !pr.hdr.ft_on) && p->t.fixed_len < 0) pr = lower_find_all_runs(p->t, char_width, max_prog_lds());
     if (pr.blob.empty() || !pr.hdr.ft_on) return NEEDLE_OK;
     *available = 1;
     if (info) {
         const ProgHeader &h = pr.hdr;
-        const uint32_t v[12] = {h.n_states, h.n_cols, h.pad_col, h.start, h.win_on, h.win_lo_e, h.win_hi_e, h.off_table, h.ft_codes_off, h.lds_bytes, h.n_pages, 0};
+        const uint32_t v[12] = {h.n_states, h.n_cols, h.pad_col, h.start, h.win_on, h.win_lo_e, h.win_hi_e, h.off_table, h.ft_codes_off, h.lds_bytes, h.n_pages, h.ft_on};
         for (int i = 0; i < 12; ++i) info[i] = (int32_t)v[i];
     }
     if (needed) *needed = pr.blob.size();
@@ -1839,11 +1851,19 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     // LOCK-STEP: one table lookup per char, every lane at the same char, the restarts folded into the automaton (needle_find_all_ls.hip).
     // NEEDLE_FIND_ALL_LOCKSTEP=0: off (A/B, tests: the per-lane one-pass kernel below).
     static const bool lockstep_on = !(getenv("NEEDLE_FIND_ALL_LOCKSTEP") && atoi(getenv("NEEDLE_FIND_ALL_LOCKSTEP")) == 0);
-    if (lockstep_on && lengths_on && slots < (1u << 23) && stride_bytes < (1ull << 23)) { // (find_all_lockstep_shape_ok)
+    if (lockstep_on && slots < (1u << 23) && stride_bytes < (1ull << 23)) { // (find_all_lockstep_shape_ok)
         const DevProgram *tp = nullptr;
         int cus = 0;
-        rc = get_program(p, W_FORWARDS, (int)v->char_width, 8, &tp, &cus);
-        if (rc) return rc;
+        if (lengths_on) {
+            rc = get_program(p, W_FORWARDS, (int)v->char_width, 8, &tp, &cus);
+            if (rc) return rc;
+        }
+        // ... or, without bounded match lengths, the RUN transducer (`[0-9]+`, `[a-z]{3}[a-z]*`: starts from a per-lane run-start register)
+        static const bool runs_on = !(getenv("NEEDLE_FIND_ALL_RUNS") && atoi(getenv("NEEDLE_FIND_ALL_RUNS")) == 0);
+        if (!tp && runs_on && p->t.fixed_len < 0) {
+            rc = get_program(p, W_FORWARDS, (int)v->char_width, 11, &tp, &cus);
+            if (rc) return rc;
+        }
         if (tp) {
             FindAllArgs fl;
             memset(&fl, 0, sizeof(fl));

@@ -21,7 +21,12 @@
 
 namespace needle {
 
-template <int CW, bool GUARD, int CHB>
+// RUNS: the run transducer (needle_lower.h lower_find_all_runs: patterns without bounded match lengths whose matches are runs -- `[0-9]+`,
+// BASELINE's C2 / C5): a code's bit 0 says "a match ends in front of this char", bit 1 "this char may begin a run"; the lane keeps the
+// index of the last char that could (run_start) -- brought up to date from the log's bit-1 nibbles every 8 chars (four VALU ops) -- and a
+// match ending at char i starts at the last such char below i.  No lengths, no backward walk (DFAClassBuilder.java:529-586 finds the
+// same start: the lowering proved it on the tables).
+template <int CW, bool GUARD, int CHB, bool RUNS = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(const FindAllArgs fa) {
     using G = Geom<CHB>;
     const ScanArgs &a = fa.s;
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
     uint64_t my_row = 0;
     bool row_ok = false;
     uint32_t len = 0, n_chunks = 1, e = 0;
+    uint32_t run_start = 0; // RUNS: index of the last char that may have begun a run
     uint32_t count = 0; // matches of this row so far -- ALL of them; the first `cap` are filed
     uint32_t cap = 0;   // matches this row may file
     // Result addressing: a wave-uniform 64-bit base per group (SGPRs: the group's first slot) + a 32-bit byte offset per lane --
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
         if (n_chunks == 0) n_chunks = 1;
         e = row_ok ? e_start : 0u;
         count = 0;
+        run_start = 0;
         gbase = (grp << 6) * fa.slots; // (group-blocked slots: the same first slot -- group * slots * 64)
         voff = fa.kshift ? (uint32_t)lane * 4u : (uint32_t)lane * fa.slots * 4u;
         cap = fa.count_only ? 0xFFFFFFFFu : fa.slots;
@@ -156,6 +163,28 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
     const bool direct_codes = a.hdr.ft_direct != 0u; // wave-uniform: codes are lengths (k = 0)
     const bool odd_codes = a.hdr.ft_odd != 0u; // wave-uniform: at most 8 codes, all odd -- bit 0 of a nibble = "a match ends here"
     auto decode = [&](uint32_t h, uint32_t pos0) __attribute__((always_inline)) {
+        if (RUNS) {
+            uint32_t t = h & 0x11111111u;              // bit 4j: a match ends in front of char j
+            const uint32_t tf = (h >> 1) & 0x11111111u; // bit 4j: char j may begin a run
+            if (fa.count_only) {
+                count += (uint32_t)__builtin_popcount(t);
+                return;
+            }
+            if (__ballot(t != 0u) != 0ull) {
+                do {
+                    const bool has = t != 0u;
+                    uint32_t b;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"(t));
+                    t &= t - 1u;
+                    const uint32_t below = tf & ((1u << (b & 31u)) - 1u); // the chars of this log in front of the match's end
+                    const uint32_t st = below ? pos0 + ((31u - (uint32_t)__builtin_clz(below)) >> 2) : run_start;
+                    const uint32_t en = pos0 + ((b & 31u) >> 2);
+                    file(has, en, en - st); // (d = length, k = 0: start = end - length)
+                } while (__ballot(t != 0u) != 0ull);
+            }
+            run_start = tf ? pos0 + ((31u - (uint32_t)__builtin_clz(tf)) >> 2) : run_start;
+            return;
+        }
         if (__ballot(h != 0u) == 0ull) return;
         uint32_t t = h; // bit 4j: char j ends a match
         if (!odd_codes) {
@@ -216,7 +245,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
         // there and sit in the dead state, whose PAD entry is 0)
         const uint32_t ee = lds_u16(__umul24(e >> 4, wk.ncols_e) + pad_addr);
         const uint32_t code = ee & 15u;
-        if (__ballot(code != 0u) != 0ull) file(code != 0u, len, lds_u32(codes_off + (code << 2)));
+        if (RUNS) {
+            if (__ballot(code != 0u) != 0ull) {
+                if (fa.count_only) count += code & 1u;
+                else file((code & 1u) != 0u, len, len - run_start);
+            }
+        } else if (__ballot(code != 0u) != 0ull) file(code != 0u, len, lds_u32(codes_off + (code << 2)));
         if (row_ok && fa.counts) fa.counts[my_row] = count < cap ? count : cap;
         if (__ballot(count > cap) != 0ull && lane == 0) *fa.more = 1;
     };
@@ -278,9 +312,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-template <int CW, bool GUARD, int CHB>
+template <int CW, bool GUARD, int CHB, bool RUNS>
 static hipError_t launch_ls(const FindAllArgs &fa, int grid, int waves, size_t lds, hipStream_t stream) {
-    auto k = find_all_lockstep_kernel<CW, GUARD, CHB>;
+    auto k = find_all_lockstep_kernel<CW, GUARD, CHB, RUNS>;
     static thread_local uint64_t configured = 0;
     if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(waves * 64), lds, stream, fa);
@@ -288,7 +322,8 @@ static hipError_t launch_ls(const FindAllArgs &fa, int grid, int waves, size_t l
 }
 template <int CW, bool GUARD>
 static hipError_t launch_ls_h(const FindAllArgs &fa, int chb, int grid, int waves, size_t lds, hipStream_t s) {
-    return chb == 128 ? launch_ls<CW, GUARD, 128>(fa, grid, waves, lds, s) : launch_ls<CW, GUARD, 64>(fa, grid, waves, lds, s);
+    if (fa.s.hdr.ft_on == 2u) return chb == 128 ? launch_ls<CW, GUARD, 128, true>(fa, grid, waves, lds, s) : launch_ls<CW, GUARD, 64, true>(fa, grid, waves, lds, s);
+    return chb == 128 ? launch_ls<CW, GUARD, 128, false>(fa, grid, waves, lds, s) : launch_ls<CW, GUARD, 64, false>(fa, grid, waves, lds, s);
 }
 
 // The kernel forms a match's result address as (uniform 64-bit group base) + (32-bit byte offset of the lane's row inside the group):

@@ -1296,87 +1296,10 @@ Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char
 
 
 // ---- the find-all transducer (needle_lower.h) -------------------------------------------------------------------------------------
-Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget) {
-    Program p;
-    memset(&p.hdr, 0, sizeof(p.hdr));
-    memset(&p.ng.p, 0, sizeof(p.ng.p));
-    p.hdr.mode = MODE_GLOBAL; // (= not available, with the empty blob)
-    if (!ml.ok) return p;
-    static const bool dbg = getenv("NEEDLE_ML_DEBUG") != nullptr;
-    const RefDfa &d = ml.dfa;
-    const int N = t.stride, OVER = N, PAD = N + 1, NC = N + 2, K = ml.n_dead;
-    auto step = [&](int m, int c) -> int { return c == OVER ? (int)ml.over[m] : (int)d.table[(size_t)m * N + c]; };
-    auto is_dead = [&](int m) { return m >= 1 && m <= K; };
-    // states: {m, s, k}; s = -2: no match pending (a plain state of the lengths automaton); s = -1: the shadow has died
-    std::map<std::array<int, 3>, int> ids;
-    std::vector<std::array<int, 3>> keys(1, std::array<int, 3>{-1, -1, -1}); // 0 = dead
-    auto tid = [&](int m, int s, int k) -> int {
-        const std::array<int, 3> key = {m, s, k};
-        auto it = ids.find(key);
-        if (it != ids.end()) return it->second;
-        const int id = (int)keys.size();
-        ids.emplace(key, id);
-        keys.push_back(key);
-        return id;
-    };
-    std::map<std::pair<int, int>, int> codes; // (length, k) -> 1 .. 15
-    bool ok = true;
-    auto code_of = [&](int L, int k) -> int {
-        auto it = codes.find({L, k});
-        if (it != codes.end()) return it->second;
-        const int c = (int)codes.size() + 1;
-        if (c > 15 || L > 255 || k > 255) ok = false;
-        codes.emplace(std::make_pair(L, k), c);
-        return c;
-    };
-    // after a transition that leaves plain state m2 of the lengths automaton current: dead, accepting (a match pending from here on:
-    // its shadow starts in the start state) or plain
-    auto enter = [&](int m2) -> int { return m2 < 0 ? 0 : d.accepting[m2] ? tid(m2, 0, 0) : tid(m2, -2, 0); };
-    std::vector<uint16_t> tab; // [state][NC]: target << 4 | code
-    tab.assign(NC, 0);         // the dead state's row
-    if (d.accepting[0] || ml.pend[0]) return p;
-    tid(0, -2, 0); // the start state: id 1
-    for (size_t i = 1; i < keys.size() && ok; ++i) {
-        if (keys.size() > 4095) { ok = false; break; }
-        const int m = keys[i][0], s = keys[i][1], k = keys[i][2];
-        tab.resize((i + 1) * NC, 0);
-        for (int c = 0; c < NC; ++c) {
-            uint32_t tgt = 0, code = 0;
-            if (s == -2) { // nothing pending
-                if (c != PAD) {
-                    const int m2 = step(m, c);
-                    if (m2 >= 0 && is_dead(m2)) { ok = false; break; } // (cannot be: nothing is pending)
-                    tgt = (uint32_t)enter(m2);
-                }
-            } else if (c == PAD) { // the row ends with a match pending
-                code = (uint32_t)code_of(ml.pend[m], k);
-            } else {
-                const int m2 = step(m, c), s2 = s >= 0 ? step(s, c) : -1;
-                if (m2 < 0) { ok = false; break; } // (cannot be: a state with a match pending dies into its D_L)
-                if (d.accepting[m2]) {
-                    tgt = (uint32_t)tid(m2, 0, 0); // a later accept of the same search: the shadow starts over
-                } else if (is_dead(m2)) {
-                    code = (uint32_t)code_of(ml.pend[m], k);
-                    if (s2 >= 0 && is_dead(s2)) { ok = false; break; } // (cannot be: the shadow has not accepted)
-                    tgt = (uint32_t)enter(s2); // the restarted search, already past the chars since the match's end
-                } else {
-                    if (s2 >= 0 && d.accepting[s2]) { // the restarted search would accept while this one still lives: a shadow of a
-                        if (dbg) fprintf(stderr, "[ft] shadow accepts under a live match: state (%d,%d,%d) column %d\n", m, s, k, c); // shadow
-                        ok = false;
-                        break;
-                    }
-                    if (k + 1 > 250) { ok = false; break; }
-                    tgt = (uint32_t)tid(m2, s2 < 0 ? -1 : s2, k + 1);
-                }
-            }
-            tab[i * NC + c] = (uint16_t)(tgt << 4 | code);
-        }
-    }
-    if (!ok || keys.size() > 4095) {
-        if (dbg) fprintf(stderr, "[ft] no transducer (%zu states, %zu codes)\n", keys.size(), codes.size());
-        return p;
-    }
-    const int n_t = (int)keys.size();
+// The device image of a find-all transducer (both kinds below): tab[state][NC] = target << 4 | code in reference columns (classes, OVER,
+// PAD) -> window layout or column maps + uint16 table + codes[16], MODE_TABLE16; empty blob when it does not fit.
+static Program emit_transducer(Program p, const RefTables &t, const RefDfa &d, std::vector<uint16_t> &tab, const int n_t, const int NC, const int PAD,
+                               const std::map<std::pair<int, int>, int> &codes, int char_width, size_t lds_table_budget, uint32_t ft_on) {
     // entries were written with ids that may exceed what existed when a row was made -- all ids are final now; nothing to patch
     const ColumnMaps cm = column_maps(t, d, char_width);
     Window win;
@@ -1457,13 +1380,14 @@ Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, in
         code_to[kv.second] = renum(kv.second, kv.first.first);
         ct[code_to[kv.second]] = (uint32_t)(kv.first.first + kv.first.second) | (uint32_t)kv.first.second << 16;
     }
-    {
+    if (ft_on == 1u) {
         uint16_t *cells = (uint16_t *)(p.blob.data() + (p.blob.size() - out.size() * 2));
         for (size_t i = 0; i < out.size(); ++i)
             if (cells[i] & 15u) cells[i] = (uint16_t)((cells[i] & ~15u) | (uint32_t)code_to[cells[i] & 15u]);
     }
-    p.hdr.ft_odd = (odd || direct_odd) ? 1u : 0u;
-    p.hdr.ft_direct = direct_odd ? 2u : direct ? 1u : 0u;
+    // (the run transducer's codes are event bits -- 1: a match ends, 2: a run may start -- and stay as written)
+    p.hdr.ft_odd = ft_on == 1u && (odd || direct_odd) ? 1u : 0u;
+    p.hdr.ft_direct = ft_on != 1u ? 0u : direct_odd ? 2u : direct ? 1u : 0u;
     p.hdr.ft_codes_off = append(p.blob, ct, sizeof(ct));
     while (p.blob.size() % 16) p.blob.push_back(0);
     if (p.blob.size() > lds_table_budget || p.blob.size() + 4u * 64u * 64u > 160u * 1024u) { // (no room beside even 4 waves of tiles)
@@ -1471,12 +1395,200 @@ Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, in
         return p;
     }
     p.hdr.mode = MODE_TABLE16;
-    p.hdr.ft_on = 1;
+    p.hdr.ft_on = ft_on;
     p.hdr.n_states = (uint32_t)n_t;
     p.hdr.start = 1;
     p.hdr.accept_lo = (uint32_t)n_t; // (no accepting states as far as any other reader is concerned)
     p.hdr.lds_bytes = (uint32_t)p.blob.size();
     return p;
 }
+Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget) {
+    Program p;
+    memset(&p.hdr, 0, sizeof(p.hdr));
+    memset(&p.ng.p, 0, sizeof(p.ng.p));
+    p.hdr.mode = MODE_GLOBAL; // (= not available, with the empty blob)
+    if (!ml.ok) return p;
+    static const bool dbg = getenv("NEEDLE_ML_DEBUG") != nullptr;
+    const RefDfa &d = ml.dfa;
+    const int N = t.stride, OVER = N, PAD = N + 1, NC = N + 2, K = ml.n_dead;
+    auto step = [&](int m, int c) -> int { return c == OVER ? (int)ml.over[m] : (int)d.table[(size_t)m * N + c]; };
+    auto is_dead = [&](int m) { return m >= 1 && m <= K; };
+    // states: {m, s, k}; s = -2: no match pending (a plain state of the lengths automaton); s = -1: the shadow has died
+    std::map<std::array<int, 3>, int> ids;
+    std::vector<std::array<int, 3>> keys(1, std::array<int, 3>{-1, -1, -1}); // 0 = dead
+    auto tid = [&](int m, int s, int k) -> int {
+        const std::array<int, 3> key = {m, s, k};
+        auto it = ids.find(key);
+        if (it != ids.end()) return it->second;
+        const int id = (int)keys.size();
+        ids.emplace(key, id);
+        keys.push_back(key);
+        return id;
+    };
+    std::map<std::pair<int, int>, int> codes; // (length, k) -> 1 .. 15
+    bool ok = true;
+    auto code_of = [&](int L, int k) -> int {
+        auto it = codes.find({L, k});
+        if (it != codes.end()) return it->second;
+        const int c = (int)codes.size() + 1;
+        if (c > 15 || L > 255 || k > 255) ok = false;
+        codes.emplace(std::make_pair(L, k), c);
+        return c;
+    };
+    // after a transition that leaves plain state m2 of the lengths automaton current: dead, accepting (a match pending from here on:
+    // its shadow starts in the start state) or plain
+    auto enter = [&](int m2) -> int { return m2 < 0 ? 0 : d.accepting[m2] ? tid(m2, 0, 0) : tid(m2, -2, 0); };
+    std::vector<uint16_t> tab; // [state][NC]: target << 4 | code
+    tab.assign(NC, 0);         // the dead state's row
+    if (d.accepting[0] || ml.pend[0]) return p;
+    tid(0, -2, 0); // the start state: id 1
+    for (size_t i = 1; i < keys.size() && ok; ++i) {
+        if (keys.size() > 4095) { ok = false; break; }
+        const int m = keys[i][0], s = keys[i][1], k = keys[i][2];
+        tab.resize((i + 1) * NC, 0);
+        for (int c = 0; c < NC; ++c) {
+            uint32_t tgt = 0, code = 0;
+            if (s == -2) { // nothing pending
+                if (c != PAD) {
+                    const int m2 = step(m, c);
+                    if (m2 >= 0 && is_dead(m2)) { ok = false; break; } // (cannot be: nothing is pending)
+                    tgt = (uint32_t)enter(m2);
+                }
+            } else if (c == PAD) { // the row ends with a match pending
+                code = (uint32_t)code_of(ml.pend[m], k);
+            } else {
+                const int m2 = step(m, c), s2 = s >= 0 ? step(s, c) : -1;
+                if (m2 < 0) { ok = false; break; } // (cannot be: a state with a match pending dies into its D_L)
+                if (d.accepting[m2]) {
+                    tgt = (uint32_t)tid(m2, 0, 0); // a later accept of the same search: the shadow starts over
+                } else if (is_dead(m2)) {
+                    code = (uint32_t)code_of(ml.pend[m], k);
+                    if (s2 >= 0 && is_dead(s2)) { ok = false; break; } // (cannot be: the shadow has not accepted)
+                    tgt = (uint32_t)enter(s2); // the restarted search, already past the chars since the match's end
+                } else {
+                    if (s2 >= 0 && d.accepting[s2]) { // the restarted search would accept while this one still lives: a shadow of a
+                        if (dbg) fprintf(stderr, "[ft] shadow accepts under a live match: state (%d,%d,%d) column %d\n", m, s, k, c); // shadow
+                        ok = false;
+                        break;
+                    }
+                    if (k + 1 > 250) { ok = false; break; }
+                    tgt = (uint32_t)tid(m2, s2 < 0 ? -1 : s2, k + 1);
+                }
+            }
+            tab[i * NC + c] = (uint16_t)(tgt << 4 | code);
+        }
+    }
+    if (!ok || keys.size() > 4095) {
+        if (dbg) fprintf(stderr, "[ft] no transducer (%zu states, %zu codes)\n", keys.size(), codes.size());
+        return p;
+    }
+    return emit_transducer(p, t, d, tab, (int)keys.size(), NC, PAD, codes, char_width, lds_table_budget, 1u);
+}
+
+// The RUN transducer (needle_lower.h): lock-step find-all for patterns whose matches have no bounded length but are "runs" -- `[0-9]+`,
+// `[a-z]{3}[a-z]*`: BASELINE's C2 and C5.  Read off the forward search automaton F (indexForwards', DFAClassBuilder.java:335-471) and the
+// anchored automaton M (matches(), :854-912); empty blob = the pattern is not of that kind (the one-pass kernel stays).
+Program lower_find_all_runs(const RefTables &t, int char_width, size_t lds_table_budget) {
+    Program p;
+    memset(&p.hdr, 0, sizeof(p.hdr));
+    memset(&p.ng.p, 0, sizeof(p.ng.p));
+    p.hdr.mode = MODE_GLOBAL; // (= not available, with the empty blob)
+    static const bool dbg = getenv("NEEDLE_ML_DEBUG") != nullptr;
+    auto no = [&](const char *why) {
+        if (dbg) fprintf(stderr, "[runs] no run transducer: %s\n", why);
+        return p;
+    };
+    const RefDfa &F = t.dfa[W_FORWARDS], &M = t.dfa[W_MATCHES];
+    const int N = t.stride, PAD = N + 1, NC = N + 2, nF = F.n_states;
+    if (nF <= 0 || nF > 4000 || M.n_states <= 0) return no("no automaton");
+    if (F.accepting[0] || M.accepting[0]) return no("the pattern matches the empty string");
+    if (F.max_char != 0xFFFF) return no("the search automaton has a maxChar");
+    auto stepF = [&](int q, int c) -> int { return (int)F.table[(size_t)q * N + c]; };
+    auto stepM = [&](int m, int c) -> int { return (int)M.table[(size_t)m * N + c]; };
+    // (the classes some char has: the table's width is rounded up -- DFAClassBuilder.java:240-253 -- and the padding columns are dead)
+    std::vector<int> cls;
+    {
+        std::vector<uint8_t> used(N, 0);
+        for (uint8_t c : t.class_map)
+            if (c < N) used[c] = 1;
+        for (int c = 0; c < N; ++c)
+            if (used[c]) cls.push_back(c);
+    }
+    // ---- states before a first accept (reachable from the start state through non-accepting states) never die; POST: the accepting
+    // states and what follows them -- every live successor accepts again, so a search dies on the char right behind its match (k = 0)
+    std::vector<uint8_t> pre(nF, 0), post(nF, 0);
+    {
+        std::vector<int> q{0};
+        pre[0] = 1;
+        for (size_t h = 0; h < q.size(); ++h)
+            for (int c : cls) {
+                const int q2 = stepF(q[h], c);
+                if (q2 < 0) return no("the search can die before a first match");
+                if (F.accepting[q2]) { post[q2] = 1; continue; }
+                if (!pre[q2]) pre[q2] = 1, q.push_back(q2);
+            }
+        std::vector<int> w;
+        for (int s = 0; s < nF; ++s)
+            if (post[s]) w.push_back(s);
+        for (size_t h = 0; h < w.size(); ++h)
+            for (int c : cls) {
+                const int q2 = stepF(w[h], c);
+                if (q2 < 0) continue;
+                if (!F.accepting[q2]) return no("a match can stay pending over chars that do not extend it");
+                if (!post[q2]) post[q2] = 1, w.push_back(q2);
+            }
+        for (int s = 0; s < nF; ++s)
+            if (pre[s] && post[s]) return no("a state before and after a first accept");
+    }
+    // ---- a run IS one attempt.  Pairs (state of F after u, state of the anchored automaton M after u) over every non-empty string u on
+    // which the attempt that began with u's first char is still alive (M alive): F must not stand in its start state there -- an attempt
+    // would be alive that the start state hides (`9*y`: the start state loops on '9', and indexBackwards, :529-586, walks back over the
+    // '9's) -- F must not accept where that attempt does not (the match would belong to a later start), and where the attempt dies F must
+    // be dead or back in its start state (else a later start lives on inside the run).  Then, whenever F stands in its start state no
+    // attempt is alive, a run is carried by the attempt of its first char, and a match's start -- the leftmost s with text[s, end) in the
+    // language -- is that char.
+    {
+        std::vector<uint32_t> seen((size_t)nF * (size_t)M.n_states / 32 + 1, 0u);
+        std::vector<std::pair<int, int>> w;
+        auto push = [&](int q, int m) {
+            const size_t id = (size_t)q * (size_t)M.n_states + (size_t)m;
+            if (seen[id >> 5] >> (id & 31) & 1u) return;
+            seen[id >> 5] |= 1u << (id & 31);
+            w.emplace_back(q, m);
+        };
+        w.emplace_back(0, 0); // (the empty string: not marked seen -- a return to (start, start) is the failure below)
+        for (size_t h = 0; h < w.size(); ++h)
+            for (int c : cls) {
+                const int q2 = stepF(w[h].first, c), m2 = stepM(w[h].second, c);
+                if (m2 < 0) {
+                    if (q2 > 0) return no("the search lives on where the attempt of the run's first char has died (a later start)");
+                    continue;
+                }
+                if (q2 < 0) continue; // (the search has pruned what the anchored automaton still follows: nothing is reported there)
+                if (q2 == 0) return no("an attempt is alive while the search stands in its start state (the pattern begins with a loop)");
+                if (F.accepting[q2] && !M.accepting[m2]) return no("the search accepts where the attempt of the run's first char does not");
+                push(q2, m2);
+                if (w.size() > (1u << 22)) return no("too many state pairs");
+            }
+    }
+    // ---- the table: device state = F state + 1 (0: the row is over); code bit 0: a match ends in front of this char (the search died on
+    // it and restarts ON it: the target is where the start state goes), bit 1: this char may begin a run (the source is the start state,
+    // or the restart); PAD: a pending match ends with the row
+    std::vector<uint16_t> tab((size_t)(nF + 1) * NC, 0);
+    for (int q = 0; q < nF; ++q)
+        for (int c = 0; c < N; ++c) {
+            const int q2 = stepF(q, c);
+            uint32_t tgt, code = q == 0 ? 2u : 0u;
+            if (q2 >= 0) tgt = (uint32_t)q2 + 1u;
+            else if (!post[q]) tgt = 0; // (unreachable: states before a first accept do not die)
+            else tgt = (uint32_t)stepF(0, c) + 1u, code = 3u;
+            tab[(size_t)(q + 1) * NC + c] = (uint16_t)(tgt << 4 | code);
+        }
+    for (int q = 0; q < nF; ++q) tab[(size_t)(q + 1) * NC + PAD] = post[q] ? 1u : 0u; // (OVER: no char is beyond maxChar 0xFFFF)
+    const std::map<std::pair<int, int>, int> none;
+    p = emit_transducer(p, t, F, tab, nF + 1, NC, PAD, none, char_width, lds_table_budget, 2u);
+    return p;
+}
+
 
 } // namespace needle

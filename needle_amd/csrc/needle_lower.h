@@ -91,5 +91,14 @@ Program lower_filter_wide(const RefTables &t, Which which, const MatchLengths *m
 // empty blob: not available (the one-pass kernel stays).  hdr: mode MODE_TABLE16, ft_on = 1, ft_codes_off = LDS offset of
 // uint32 codes[16] = (k + length) | k << 16 (ft_odd: at most 8 codes, numbered 1, 3, .. 15), start = the start state, pad_col, window addressing as for the scan kernels' tables.
 Program lower_find_all_transducer(const RefTables &t, const MatchLengths &ml, int char_width, size_t lds_table_budget);
+// The RUN transducer: lock-step find-all for patterns WITHOUT bounded match lengths whose matches are "runs" -- `[0-9]+`,
+// `[a-z]{3}[a-z]*` (BASELINE's C2 / C5 patterns).  Established on the tables: (1) after an accept every live successor state accepts,
+// so the search dies on the char right behind its match and restarts ON that char; (2) from the char that takes the search automaton
+// out of its start state until it is back there or dead, the anchored automaton started on that char lives exactly as long and accepts
+// exactly where the search does -- a match's start (indexBackwards, DFAClassBuilder.java:529-586) is then the run's first char.  The table
+// is the search automaton with its dying transitions redirected through the start state; entry = state << 4 | code, code bit 0: a match
+// ends in front of this char, bit 1: this char may begin a run.  The kernel logs both bits per char and keeps the last run start per lane
+// (needle_find_all_ls.hip).  hdr.ft_on = 2.  empty blob: not such a pattern.
+Program lower_find_all_runs(const RefTables &t, int char_width, size_t lds_table_budget);
 
 } // namespace needle

@@ -24,6 +24,7 @@ const Switch kSwitches[] = {
     {"NEEDLE_FIND_LENGTHS_PAIR", "1", "layout", "0: pair-table automata keep the two walks"},
     {"NEEDLE_FIND_ALL_LENGTHS", "1", "layout", "find-all's starts: 0 by backward walks, 1 by the lengths automaton where it fits the LDS as a plain table, 2 also in its compressed form (big dictionaries; measured: no faster)"},
     {"NEEDLE_FIND_ALL_LOCKSTEP", "1", "layout", "0: find-all never takes the lock-step kernel (the find-all transducer, needle_find_all_ls.hip); patterns that have one keep the per-lane one-pass kernel"},
+    {"NEEDLE_FIND_ALL_RUNS", "1", "layout", "0: find-all of run patterns (`[0-9]+`: no bounded match length) never takes the lock-step kernel with the run transducer; they keep the per-lane one-pass kernel and its backward walks"},
     {"NEEDLE_FIND_ALL_FILTER", "1", "layout", "0: find-all never runs behind the n-gram candidate filter (dictionaries whose find() does keep the one-pass find-all kernel)"},
     {"NEEDLE_FIND_ALL_WINDOW", "1", "layout", "0: the find-all kernel's lengths program keeps column-map lookups instead of window addressing"},
     {"NEEDLE_FIND_ALL_DEFER", "1", "layout", "0: find-all (two-walk form) finds each start as the match is found instead of deferring them to the row's end"},

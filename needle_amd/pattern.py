@@ -245,7 +245,9 @@ class Pattern:
     def find_all_transducer(self, char_width=1):
         """The device program of the find-all transducer (needle_pattern_find_all_transducer: lock-step find-all), or None when the
         pattern has none -> {"n_states", "n_cols", "pad_col", "start", "window", "win_lo_e", "win_hi_e", "off_table", "codes_off",
-        "lds_bytes", "n_pages", "blob": uint8[lds_bytes]}."""
+        "lds_bytes", "n_pages", "kind" (1: the transducer on the lengths automaton -- a code names (length, k); 2: the RUN transducer of
+        patterns without bounded match lengths -- code bit 0: a match ends in front of this char, bit 1: this char may begin a run),
+        "blob": uint8[lds_bytes]}."""
         L = _lib.lib()
         avail, need = ctypes.c_int32(0), ctypes.c_size_t(0)
         info = (ctypes.c_int32 * 12)()
@@ -254,7 +256,7 @@ class Pattern:
             return None
         blob = np.zeros(need.value, dtype=np.uint8)
         _check(L.needle_pattern_find_all_transducer(self._h, int(char_width), ctypes.byref(avail), info, blob.ctypes.data, blob.size, ctypes.byref(need)))
-        keys = ["n_states", "n_cols", "pad_col", "start", "window", "win_lo_e", "win_hi_e", "off_table", "codes_off", "lds_bytes", "n_pages"]
+        keys = ["n_states", "n_cols", "pad_col", "start", "window", "win_lo_e", "win_hi_e", "off_table", "codes_off", "lds_bytes", "n_pages", "kind"]
         out = {k: int(info[i]) for i, k in enumerate(keys)}
         out["blob"] = blob
         return out

@@ -98,6 +98,33 @@ for rx in ["abc|bcd|cdefg|a|xyzzy|zzy", "(foo|foobar|bar|barbaz|baz)x?", "ab|abc
         total += check(p, o, rows, lens, (rx, stride, "ragged"), every=2)
         if stride != 48:
             total += check(p, o, rows.to(torch.int16), lens, (rx, stride, "utf16 ragged"), every=5)
+# ---- patterns WITHOUT bounded match lengths whose matches are runs (BASELINE's C2 / C5 kind): the RUN transducer -- lock-step, the start
+# of a match from the lane's run-start register instead of indexBackwards (needle_lower.h lower_find_all_runs); NEEDLE_FIND_ALL_RUNS=0:
+# the one-pass kernel and its backward walks
+for rx in ["[0-9]+", "[a-c]{3}[a-c]*", "a+b+", "ab*", "[0-9]+x", "[a-z]+[0-9]"]:
+    p = DFACompiler.compile(rx, "t", 0)
+    o, _ = oracle_for(rx, 0)
+    ft = p.find_all_transducer(1)
+    assert ft is not None and ft["kind"] == 2, rx
+    alpha = np.array(sorted(set(ord(c) for c in rx if c.isalnum())) + [ord(c) for c in "0123456789abcx"] + [32, 32, 32, 10, 200], dtype=np.uint8)
+    for stride, n in ((256, 64 * 9 + 3), (48, 64 * 4 + 9), (320, 130), (16, 64 * 11 + 1)):
+        host = alpha[rng.integers(0, len(alpha), size=(n, stride))]
+        host[::5, stride - 3:] = alpha[0]   # runs that end with the row
+        rows = torch.from_numpy(host).to(dev)
+        total += check(p, o, rows, None, (rx, stride, "runs full"), every=2)
+        lens = torch.from_numpy(rng.integers(0, stride + 1, size=n).astype(np.int32)).to(dev)
+        total += check(p, o, rows, lens, (rx, stride, "runs ragged"), every=2)
+        if stride >= 48:
+            total += check(p, o, rows.to(torch.int16), lens, (rx, stride, "runs utf16 ragged"), every=5)
+rx = W.script_regex()  # C5: a run of >= 3 chars of 42 BMP ranges, UTF-16 rows
+p = DFACompiler.compile(rx, "t", 0)
+o, _ = oracle_for(rx, 0)
+assert p.find_all_transducer(2) is not None and p.find_all_transducer(2)["kind"] == 2
+for n in (64 * 30 + 7, 100):
+    rows = W.script_batch(torch, 17, n, 256, device=dev)
+    total += check(p, o, rows, None, ("c5", n, "full"), every=3)
+    lens = (torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 % 257).to(torch.int32)
+    total += check(p, o, rows, lens, ("c5", n, "ragged"), every=3)
 # ---- a pattern WITHOUT a transducer keeps the one-pass kernel whatever the switch says
 rx = "international|inter|nation|qrstuvwxyzab"
 p = DFACompiler.compile(rx, "t", 0)
@@ -114,8 +141,8 @@ print("LOCKSTEP-FIND-ALL-OK", lockstep, total)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"NEEDLE_FIND_ALL_LOCKSTEP": "0"}, {"NEEDLE_WINDOW": "0"}, {"NEEDLE_FIND_ALL_SHAPE": "8x64"}],
-                         ids=["lock-step", "off: one-pass kernel", "lock-step, column maps", "lock-step, 8 waves"])
+@pytest.mark.parametrize("env", [{}, {"NEEDLE_FIND_ALL_LOCKSTEP": "0"}, {"NEEDLE_WINDOW": "0"}, {"NEEDLE_FIND_ALL_SHAPE": "8x64"}, {"NEEDLE_FIND_ALL_RUNS": "0"}],
+                         ids=["lock-step", "off: one-pass kernel", "lock-step, column maps", "lock-step, 8 waves", "run patterns on the one-pass kernel"])
 def test_find_all_every_form_vs_oracle(env):
     on = env.get("NEEDLE_FIND_ALL_LOCKSTEP", "1")
     r = subprocess.run([sys.executable, "-c", CODE, on], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500, cwd=ROOT)
