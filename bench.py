@@ -708,7 +708,7 @@ def measure(workload, args, ctx, headline):
                                                    "packed16 = one dword per row")
         if form == "packed8":
             out["host_landed"]["pipelined16"] = pipelined("packed16")  # round 5's figure: 4 result bytes per row over PCIe
-    if rank == 0 and world == 1 and not args.no_extras and workload in ("c3", "c3s", "c3x", "c3s16", "c3x16", "c3m16") and is_find:
+    if rank == 0 and world == 1 and not args.no_extras and workload in ("c2", "c3", "c3s", "c3x", "c5", "c3s16", "c3x16", "c3m16"):
         # EVERY non-overlapping match of every row (the reference's repeated find()), one pass over
         # the batch (needle_find_all.hip; for dictionaries behind the n-gram candidate filter -- c3s -- that kernel's find-all form,
         # needle_ngram.hip): counts + dense per-row slots.  Its own figure, never the `value`.
@@ -728,7 +728,7 @@ def measure(workload, args, ctx, headline):
         fa_bytes = n_rows * (256 * cw + 4) + 8 * n_matches
         out["find_all"] = {"ms_per_step": dt * 1e3, "matches": n_matches, "matches_per_s": n_matches / dt, "max_per_row": int(fc.max().item()),
                            "slots": slots, "more": bool(more), "GB/s": fa_bytes / dt / 1e9, "algorithmic_bytes": fa_bytes,
-                           "kernel": ("needle::ngram_kernel (find-all form)" if pre["on"] else
+                           "kernel": ("needle::ngram_kernel (find-all form)" if (pre["on"] and is_find) else
                                       "needle::find_all_lockstep_kernel" if pattern.find_all_transducer(cw) is not None else "needle::find_all_kernel"),
                            "frac_of_hbm_peak": fa_bytes / dt / 1e9 / HBM_PEAK_GBS,
                            "note": "every non-overlapping match per row (repeated Matcher.find()), one pass; bytes = rows + 4 B count per row + 8 B per match"}
@@ -739,6 +739,10 @@ def measure(workload, args, ctx, headline):
         torch.cuda.synchronize()
         dtp = (time.perf_counter() - t) / k2
         assert int(fc.sum().item()) == n_matches and ((fs >> 16) & 0xFFFF)[:, 0][fc > 0].eq(fe[:, 0][fc > 0]).all()
+        if workload == "c2":  # '[0-9]+': every row's first match is what find() reports -- and the batch's rows have at most one run of digits
+            fb_, fs_, fe_ = pattern.find_batch(rows)
+            assert fe_[fc > 0].eq(fe[:, 0][fc > 0]).all() and fs_[fc > 0].eq(fs[:, 0][fc > 0] & 0xFFFF).all()
+            del fb_, fs_, fe_
         out["find_all"]["packed16"] = {"ms_per_step": dtp * 1e3, "matches_per_s": n_matches / dtp,
                                        "algorithmic_bytes": n_rows * (256 * cw + 4) + 4 * n_matches,
                                        "frac_of_hbm_peak": (n_rows * (256 * cw + 4) + 4 * n_matches) / dtp / 1e9 / HBM_PEAK_GBS}
@@ -836,30 +840,28 @@ def slim(w):
     if "error" in w:
         return w
     r = w["roofline"]
-    o = {"workload": w["config"]["workload"].split(":")[0], "ms": _r(w["ms_per_step"]), "kernel_ms": _r(r["kernel_ms"]), "GBs": _r(r["achieved"], 1),
-         "frac": _r(r["frac"]), "kernel": r["kernel"].replace("needle::", ""), "mode": w["config"]["automaton"]["kernel_mode"][:24],
+    o = {"ms": _r(w["ms_per_step"]), "kernel_ms": _r(r["kernel_ms"]), "GBs": _r(r["achieved"], 0), "frac": _r(r["frac"], 3),
+         "kernel": r["kernel"].replace("needle::", "").replace("_kernel", ""), "mode": w["config"]["automaton"]["kernel_mode"][:14],
          "states": w["config"]["automaton"]["states"],
-         "traffic_x": _r(r["traffic"] / r["algorithmic_bytes_per_launch"], 3) if r.get("traffic") else None,
-         "rows_s": _r(w["rows_per_s"], 0), "match_s": _r(w["matches_per_s"], 0), "matched": _r(w["matched_fraction"], 3)}
+         "traffic_x": _r(r["traffic"] / r["algorithmic_bytes_per_launch"], 2) if r.get("traffic") else None,
+         "match_s": _r(w["matches_per_s"], 0), "matched": _r(w["matched_fraction"], 3)}
     if "cold" in w:
-        o["cold_ms"], o["steady_ms"] = _r(w["cold"]["ms_per_step"]), _r(w["steady"]["ms_per_step"]) if "steady" in w else None
+        o["cold_ms"], o["steady_ms"] = _r(w["cold"]["ms_per_step"], 3), _r(w["steady"]["ms_per_step"], 3) if "steady" in w else None
     if "gather_verified" in w:
         o["gather_verified"], o["scan_ms"], o["gather_ms"] = w["gather_verified"], _r(w.get("scan_ms")), _r(w.get("gather_ms"))
     hl = w.get("host_landed")
-    if hl:
-        o["host_landed_ms"] = {"plain": _r(hl["ms_per_step"]), **{k: _r(hl[k]["ms_per_step"]) for k in ("packed16", "compact", "pipelined", "pipelined16") if k in hl}}
-        if "pipelined" in hl:
-            o["host_landed_ms"]["pipelined_frac"] = _r(hl["pipelined"]["frac_of_hbm_peak"])
-            o["host_landed_ms"]["form"] = hl["pipelined"].get("form")
+    if hl and "pipelined" in hl:  # results landed in host memory, steady state (scan k + 1 beside the D2H of step k)
+        o["host_ms"] = {"pipelined": _r(hl["pipelined"]["ms_per_step"], 3), "frac": _r(hl["pipelined"]["frac_of_hbm_peak"], 3), "form": hl["pipelined"].get("form")}
+        if "pipelined16" in hl:
+            o["host_ms"]["dword"] = _r(hl["pipelined16"]["ms_per_step"], 3)
     fa = w.get("find_all")
-    if fa:
-        o["find_all"] = {"ms": _r(fa["ms_per_step"]), "frac": _r(fa["frac_of_hbm_peak"]), "packed16_ms": _r(fa["packed16"]["ms_per_step"]),
-                         "packed16_frac": _r(fa["packed16"]["frac_of_hbm_peak"]), "blocked16_ms": _r(fa["blocked16"]["ms_per_step"]),
-                         "blocked16_frac": _r(fa["blocked16"]["frac_of_hbm_peak"]), "count_ms": _r(fa.get("count_pass_ms")),
-                         "Gmatch_s": _r(fa["blocked16"]["matches_per_s"] / 1e9, 2), "matches": fa["matches"], "kernel": fa["kernel"].replace("needle::", "")}
+    if fa:  # every match of every row: two arrays / one dword per match row-major / one dword per match in group-blocked slots / count only
+        o["find_all"] = {"ms": _r(fa["ms_per_step"], 3), "dword_ms": _r(fa["packed16"]["ms_per_step"], 3), "blocked_ms": _r(fa["blocked16"]["ms_per_step"], 3),
+                         "blocked_frac": _r(fa["blocked16"]["frac_of_hbm_peak"], 3), "count_ms": _r(fa.get("count_pass_ms"), 3),
+                         "Gmatch_s": _r(fa["blocked16"]["matches_per_s"] / 1e9, 2), "kernel": fa["kernel"].replace("needle::", "").replace("_kernel", "")[:18]}
     cb = w.get("cpu_baseline")
     if cb:
-        o["cpu_GBs"] = {"all": _r(cb["value"], 2), "cores": cb["cores"], "one": _r(cb["single_core"]["value"], 2), "kind": cb["kind"]}
+        o["cpu_GBs"] = {"all": _r(cb["value"], 2), "cores": cb["cores"], "one": _r(cb["single_core"]["value"], 2)}
     return o
 
 
@@ -882,11 +884,12 @@ def slim_line(out):
     if "must_read" in out:
         line["must_read_GBs"] = _r(out["must_read"]["GB/s"], 1)
     hl = out.get("host_landed")
-    if hl:
-        line["host_landed_ms"] = {"plain": _r(hl["ms_per_step"]), **{k: _r(hl[k]["ms_per_step"]) for k in ("packed16", "compact", "pipelined", "pipelined16") if k in hl}}
-        if "pipelined" in hl:
-            line["host_landed_ms"]["pipelined_frac"] = _r(hl["pipelined"]["frac_of_hbm_peak"])
-            line["host_landed_ms"]["form"] = hl["pipelined"].get("form")
+    if hl and "pipelined" in hl:
+        line["host_ms"] = {"plain": _r(hl["ms_per_step"], 3), "pipelined": _r(hl["pipelined"]["ms_per_step"], 3), "frac": _r(hl["pipelined"]["frac_of_hbm_peak"], 3),
+                           "form": hl["pipelined"].get("form")}
+    if "find_all" in out:
+        line["find_all"] = slim({"roofline": out["roofline"], "ms_per_step": out["ms_per_step"], "config": out["config"], "matches_per_s": out["matches_per_s"],
+                                 "matched_fraction": out["matched_fraction"], "find_all": out["find_all"]})["find_all"]
     if "c4_shard_step" in out:
         line["c4_shard_step"] = {w: ({"ms": _r(v["ms_per_step"]), "kernel_ms": _r(v["kernel_ms"]), "overhead": _r(v["overhead_frac"], 3)} if "error" not in v else v)
                                  for w, v in out["c4_shard_step"].items()}
