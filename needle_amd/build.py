@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-variable"]
+    flags = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-x", "hip", "-Wall", "-Wno-unused-variable"]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
@@ -70,7 +70,7 @@ def build(force=False, verbose=False):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)

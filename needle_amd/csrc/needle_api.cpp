@@ -753,22 +753,24 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // flood watch) leaves these rows to the UTF-16 kernels.
     const Utf16Route u16 = v->char_width == 2 ? utf16_route(p) : Utf16Route();
     if (v->char_width == 2 && op != OP_MATCHES && !d_from && !d_end_state && !no_backward && ngram_level() > 0 && dict_env == 0 && u16.page >= 0 &&
-        v->row_stride * 2 < 8 * (uint64_t)kStripeBytes) {
+        v->row_stride * 2 < 8 * (uint64_t)kStripeBytes) do {
+        // (every step of this route is speculative -- lowering and uploading the page's byte programs for a pattern that may have no
+        // filter at all: a failure here means "route unavailable", the UTF-16 kernels below serve the call)
         const DevProgram *tp = nullptr;
         const int cw8 = 1 | (u16.page << 8); // the byte program of the pattern's page
         rc = get_program(p, which, cw8, need_backward ? 2 : 0, &tp, &n_cus);
-        if (rc) return rc;
+        if (rc) break;
         bool ok = false;
         if (tp->prog.hdr.mode == MODE_HYBRID || tp->prog.hdr.mode == MODE_GLOBAL) {
             rc = get_program(p, which, cw8, 9, &tp, nullptr);
-            if (rc) return rc;
+            if (rc) break;
             ok = tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0);
         } else {
             bool lengths8 = false;
             if (need_backward && find_lengths_for(tp->prog.hdr.mode)) {
                 const DevProgram *lp = nullptr;
                 rc = get_program(p, W_FORWARDS, cw8, 7, &lp, nullptr);
-                if (rc) return rc;
+                if (rc) break;
                 if (lp && !(tp->prog.hdr.mode == MODE_PAIR && lp->prog.hdr.mode != MODE_PAIR)) tp = lp, lengths8 = true;
             }
             ok = tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || lengths8 || p->t.fixed_len >= 0);
@@ -781,7 +783,7 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
                 return NEEDLE_OK;
             }
         }
-    }
+    } while (0);
     rc = get_program(p, which, (int)v->char_width, need_backward ? 2 : 0, &fp, &n_cus);
     if (rc) return rc;
     // UTF-16 rows of a pattern that lives on SEVERAL pages of the BMP (Latin + Cyrillic + CJK dictionaries: DFA.java:438-463, the reference's
@@ -1474,8 +1476,6 @@ int needle_pattern_set_prefilter(needle_pattern *p, int mode) {
     return NEEDLE_OK;
 }
 
-// What the flood watch of this pattern's filter program(s) for `which` on the CURRENT device knows (no device needed to ask; all zero
-// before the first scan).  Several programs may carry a filter (plain / lengths / HBM-table forms): the one that ran last is reported.
 int needle_pattern_utf16_route(const needle_pattern *p, int32_t *page, int32_t *sub) {
     if (!p || !page || !sub) return fail(NEEDLE_ERR_INVALID, "NULL argument");
     const Utf16Route r = utf16_route(p);
@@ -1483,6 +1483,8 @@ int needle_pattern_utf16_route(const needle_pattern *p, int32_t *page, int32_t *
     return NEEDLE_OK;
 }
 
+// What the flood watch of this pattern's filter program(s) for `which` on the CURRENT device knows (no device needed to ask; all zero
+// before the first scan).  Several programs may carry a filter (plain / lengths / HBM-table forms): the one that ran last is reported.
 int needle_pattern_prefilter_state(const needle_pattern *cp, int which, needle_prefilter_state *o) {
     needle_pattern *p = const_cast<needle_pattern *>(cp);
     if (!p || !o) return fail(NEEDLE_ERR_INVALID, "NULL argument");
@@ -1851,7 +1853,10 @@ static int find_all_one_pass(needle_pattern *p, const needle_batch_view *v, uint
     // LOCK-STEP: one table lookup per char, every lane at the same char, the restarts folded into the automaton (needle_find_all_ls.hip).
     // NEEDLE_FIND_ALL_LOCKSTEP=0: off (A/B, tests: the per-lane one-pass kernel below).
     static const bool lockstep_on = !(getenv("NEEDLE_FIND_ALL_LOCKSTEP") && atoi(getenv("NEEDLE_FIND_ALL_LOCKSTEP")) == 0);
-    if (lockstep_on && slots < (1u << 23) && stride_bytes < (1ull << 23)) { // (find_all_lockstep_shape_ok)
+    FindAllArgs shape; // (what the launcher's own check looks at: one definition of "the lock-step kernel takes this shape")
+    memset(&shape, 0, sizeof(shape));
+    shape.slots = slots, shape.s.stride_bytes = stride_bytes;
+    if (lockstep_on && find_all_lockstep_shape_ok(shape)) {
         const DevProgram *tp = nullptr;
         int cus = 0;
         if (lengths_on) {

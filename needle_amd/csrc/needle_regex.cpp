@@ -37,6 +37,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <set>
 #include <stdexcept>
@@ -913,7 +914,7 @@ class SubsetBuilder { // NFAToDFACompiler.java
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         static const bool timing = getenv("NEEDLE_COMPILE_TIMING") != nullptr;
         while (!pending.empty()) {
-            double ta = now();
+            double ta = timing ? now() : 0.0; // (the clock is only read when NEEDLE_COMPILE_TIMING asks for it)
             auto lap = [&](int k) { if (timing) { const double tb = now(); T[k] += tb - ta; ta = tb; } };
             StateSet cur = std::move(pending.back());
             pending.pop_back();
@@ -1380,23 +1381,35 @@ int compile_regex(const std::u16string &regex, int flags, RefTables &out, std::s
         };
         // the four automata are independent: the two search-mode ones (each state set carries the root's closure: the heavy ones
         // for a dictionary) are built side by side
+        // (only for big programs -- dictionaries: a small regex compiles in microseconds and gains nothing from a thread; and a thread that
+        // cannot be created -- EAGAIN in a restricted container -- must not turn a compile that works sequentially into an error)
         std::exception_ptr err_ci;
-        std::thread t_ci([&] {
+        std::thread t_ci;
+        bool threaded = false;
+        if (fwd.size() >= 512) {
             try {
-                dfas[W_CONTAINED_IN] = build(fwd, CONTAINED_IN);
-            } catch (...) {
-                err_ci = std::current_exception();
+                t_ci = std::thread([&] {
+                    try {
+                        dfas[W_CONTAINED_IN] = build(fwd, CONTAINED_IN);
+                    } catch (...) {
+                        err_ci = std::current_exception();
+                    }
+                });
+                threaded = true;
+            } catch (const std::system_error &) {
+                threaded = false;
             }
-        });
+        }
         try {
             dfas[W_MATCHES] = build(fwd, BASIC);
             dfas[W_BACKWARDS] = build(rev, BASIC);
             dfas[W_FORWARDS] = build(fwd, DFA_SEARCH);
+            if (!threaded) dfas[W_CONTAINED_IN] = build(fwd, CONTAINED_IN);
         } catch (...) {
-            t_ci.join();
+            if (threaded) t_ci.join();
             throw;
         }
-        t_ci.join();
+        if (threaded) t_ci.join();
         if (err_ci) std::rethrow_exception(err_ci);
         lap("four automata");
         for (const Dfa &d : dfas) // DFACompiler.checkForOverLongDFAs :76-83

@@ -1,7 +1,10 @@
-"""What lets UTF-16 rows run behind the BYTE program's filter (needle_api.cpp utf16_filter_ok, needle_ngram.h narrow16): for a pattern whose
-chars all lie below 0xFF -- the anchored automaton's maxChar < 0xFF -- a char above 0xFE is "beyond maxChar" (DFAClassBuilder.java:440,
-:565: `c > maxChar`), and so is byte 0xFF.  Hence the reference's answers on UTF-16 rows are its answers on the rows narrowed char by char
-to min(c, 0xFF).  Checked here on the CPU oracle alone (no device): matches / containedIn / find / repeated find on random dictionaries and
+"""What lets UTF-16 rows run behind the BYTE program's filter (needle_api.cpp utf16_route, needle_ngram.h narrow16).  Round 4's rule: for a
+pattern whose chars all lie below 0xFF -- the anchored automaton's maxChar < 0xFF -- a char above 0xFE is "beyond maxChar"
+(DFAClassBuilder.java:440, :565: `c > maxChar`), and so is byte 0xFF: the reference's answers on UTF-16 rows are its answers on the rows
+narrowed char by char to min(c, 0xFF) (first test).  Round 5's general rule -- the one the library ships: a pattern that lives on ONE page P of
+the BMP (every char outside it is of the pattern's "other" class, and so is the page's char P << 8 | sub) gives, on any UTF-16 row, the
+answers it gives on the row with every char outside the page replaced by P << 8 | sub -- which is what the page's byte program sees once the
+kernel has narrowed the text (test_route_rule_on_the_oracle: patterns with sub != 0xFF, pages other than 0, negated classes).  Checked here on the CPU oracle alone (no device): matches / containedIn / find / repeated find on random dictionaries and
 a few regexes, with chars above 0xFF planted next to, inside and in place of keyword chars."""
 import os
 import sys
@@ -71,3 +74,44 @@ def test_route_reports_the_patterns_page():
     assert DFACompiler.compile("[Ѐ-ӿ]{4}[Ѐ-ӿ]*x?", "t", 0).utf16_route() is None  # two pages (x), and page 4 has no other char
     r = DFACompiler.compile("abcdefÿgh|bcdefgh", "t", 0).utf16_route()
     assert r is not None and r[0] == 0 and r[1] != 0xFF
+
+
+ROUTED = [
+    ("|".join("".join(chr(0x0430 + ord(c) - 97) for c in w) for w in W.keywords(150, min_len=5, max_len=8)), 4),   # Cyrillic dictionary: page 4
+    ("abcdefÿgh|bcdefgh|[x-z]{5}", 0),                                                                         # 0xFF in the pattern: sub != 0xFF
+    ("[α-ω]{3}[α-ω]*|λόγος", 3),                                                                                      # Greek: page 3
+    ("(foo|bar)[a-z]*baz|[0-9]{4}", 0),
+]
+
+
+@pytest.mark.parametrize("rx,page", ROUTED)
+def test_route_rule_on_the_oracle(rx, page):
+    """For the route (page, sub) the library reports: oracle(rows) == oracle(rows with every char outside the page replaced by page << 8 | sub)
+    for find / containedIn / repeated find -- chars of other pages planted next to, inside and in place of the pattern's chars, among them
+    chars with the LOW BYTE of a pattern char under another high byte."""
+    p = DFACompiler.compile(rx, "t", 0)
+    o, _ = oracle_for(rx, 0)
+    route = p.utf16_route()
+    assert route is not None and route[0] == page, (rx[:30], route)
+    sub = route[1]
+    rng = np.random.default_rng(len(rx) + page)
+    n, width = 500, 80
+    own = np.array(sorted(set(ord(c) for c in rx if c.isalnum())), dtype=np.uint16)
+    alpha = np.concatenate([own, np.array([32, 32, 48, 57, 0x41, 0x0416, 0x03A9, 0x4E2D], dtype=np.uint16)])
+    rows = rng.choice(alpha, (n, width)).astype(np.uint16)
+    words = [w for w in rx.split("|") if w.isalnum()] or ["abcdefgh"]
+    for r in range(0, n, 2):
+        w = np.array([ord(c) for c in words[r % len(words)]], dtype=np.uint16)[:width]
+        at = int(rng.integers(0, width - len(w) + 1))
+        rows[r, at:at + len(w)] = w
+        if r % 6 == 0:
+            rows[r, at + int(rng.integers(0, len(w)))] ^= 0x0100   # a pattern char's low byte on the neighbouring page
+    m = rng.random(rows.shape) < 0.03
+    rows[m] = rng.integers(0, 0xFFFF, size=int(m.sum()), dtype=np.uint16)
+    replaced = np.where((rows >> 8) == page, rows, np.uint16(page << 8 | sub)).astype(np.uint16)
+    of, ofs, ofe = o.batch_find(rows)
+    nf, nfs, nfe = o.batch_find(replaced)
+    assert of.sum() > 20, rx[:30]
+    assert (of == nf).all() and (ofs == nfs).all() and (ofe == nfe).all(), rx[:30]
+    assert (o.batch_contained_in(rows) == o.batch_contained_in(replaced)).all(), rx[:30]
+    assert all(o.find_all(rows[i]) == o.find_all(replaced[i]) for i in range(0, n, 5)), rx[:30]
