@@ -168,6 +168,8 @@ struct needle_pattern {
     //          8 the find-all transducer (lock-step find-all, needle_find_all_ls.hip; absent when the pattern does not allow it)
     //          9 the filter program of an automaton that fits the LDS in no form (lower_filter_hbm: HBM-table layout + n-gram filter;
     //            W_CONTAINED_IN, or W_FORWARDS in the lengths form / for one-length patterns; absent when no filter can be built)
+    //          12 variant 9 for find() of a pattern WITHOUT bounded match lengths: the forward search automaton itself (no lengths form) with
+    //            the backward automaton's column maps in its LDS part -- verified candidates find their starts by backward walks
     //          11 the RUN transducer (lock-step find-all of patterns without bounded match lengths whose matches are runs: `[0-9]+`;
     //            needle_lower.h lower_find_all_runs); absent when the pattern is not of that kind
     //          10 the WIDE filter program (lower_filter_wide: char_width 2 only -- UTF-16 rows of a pattern on several pages of the BMP:
@@ -267,12 +269,12 @@ static int get_program(needle_pattern *p, int which, int cw, int variant, const 
     auto it = p->cache.find(key);
     if (it == p->cache.end()) {
         DevProgram dp;
-        if (variant == 9 || variant == 10) {
-            if ((wants_ml && !ml67) || (variant == 10 && cw != 2)) {
+        if (variant == 9 || variant == 10 || variant == 12) {
+            if ((wants_ml && !ml67) || (variant == 10 && cw != 2) || (variant == 12 && (which != W_FORWARDS || cw != 1))) {
                 *out = nullptr;
                 return NEEDLE_OK;
             }
-            dp.prog = variant == 10 ? lower_filter_wide(*tt, (Which)which, ml67) : lower_filter_hbm(*tt, (Which)which, ml67);
+            dp.prog = variant == 10 ? lower_filter_wide(*tt, (Which)which, ml67) : lower_filter_hbm(*tt, (Which)which, variant == 12 ? nullptr : ml67, variant == 12);
             if (dp.prog.blob.empty() || !dp.prog.ng.p.on) { // (no filter: the ordinary program is what runs)
                 p->cache.emplace(key, DevProgram());
                 *out = nullptr;
@@ -828,8 +830,21 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
         const DevProgram *tp = nullptr;
         rc = get_program(p, which, 1, 9, &tp, nullptr);
         if (rc) return rc;
-        if (tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0)) {
-            const ScanArgs a = filter_scan_args(v, v->row_stride, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed, packed8);
+        // find() without bounded match lengths (no lengths form): the forward search automaton + backward walks for the starts (variant 12)
+        static const bool unbounded_on = !(getenv("NEEDLE_PREFILTER_UNBOUNDED") && atoi(getenv("NEEDLE_PREFILTER_UNBOUNDED")) == 0);
+        const DevProgram *bwp = nullptr;
+        if (!tp && op == OP_FIND && need_backward && unbounded_on) {
+            rc = get_program(p, which, 1, 12, &tp, nullptr);
+            if (rc) return rc;
+            if (tp) {
+                rc = get_program(p, W_BACKWARDS, 1, 1, &bwp, nullptr);
+                if (rc) return rc;
+                if (!bwp) tp = nullptr;
+            }
+        }
+        if (tp && tp->d_ng && tp->prog.ng.p.on && (op == OP_CONTAINED_IN || tp->prog.hdr.fa_len_off || p->t.fixed_len >= 0 || bwp)) {
+            ScanArgs a = filter_scan_args(v, v->row_stride, tp, op == OP_FIND ? p->t.fixed_len : -1, d_bitmap, d_start, d_end, d_packed, packed8);
+            if (bwp) a.bprog = bwp->d_blob, a.bhdr = bwp->prog.hdr;
             if (ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, tp->prog.ng.p) && ngram_watch_allows(p, tp)) {
                 HIP_TRY(launch_ngram(op, a, tp->prog.ng.p, tp->d_ng, tp->d_ng_stats, n_cus, (hipStream_t)stream));
                 HIP_TRY(ngram_watch_after_launch(tp, (hipStream_t)stream));
@@ -920,8 +935,12 @@ static int run_dev(const needle_pattern *cp, int op, const needle_batch_view *v,
     // The n-gram candidate filter (needle_ngram.hip): the automaton only runs where a hashed 4-byte window of the
     // text can stand ahead of a match.  For programs whose lowering established that this gives the reference's answers
     // (needle_ngram_host.cpp), on containedIn() and on find() whose start is end - length (lengths programs, one-length patterns).
+    // (find() of a pattern WITHOUT bounded match lengths -- `(kw1|..|kw1000)[0-9]+` -- takes it too: its verified candidates find their
+    // starts by indexBackwards, the lock-step backward walk on text out of L2.  NEEDLE_PREFILTER_UNBOUNDED=0: the scan kernel)
+    static const bool unbounded_on = !(getenv("NEEDLE_PREFILTER_UNBOUNDED") && atoi(getenv("NEEDLE_PREFILTER_UNBOUNDED")) == 0);
+    const bool by_backward_walk = op == OP_FIND && a.fixed_len < 0 && !lengths_form && a.bprog != nullptr && unbounded_on && !d_from;
     if (fp->d_ng && fp->prog.ng.p.on && ngram_level() > 0 && v->char_width == 1 && op != OP_MATCHES && !skip_backward &&
-        (op == OP_CONTAINED_IN || lengths_form || a.fixed_len >= 0) && ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, fp->prog.ng.p)) {
+        (op == OP_CONTAINED_IN || lengths_form || a.fixed_len >= 0 || by_backward_walk) && ngram_shape_ok(a) && ngram_lds_bytes(a.hdr, fp->prog.ng.p)) {
         if (ngram_watch_allows(p, fp)) {
             HIP_TRY(launch_ngram(op, a, fp->prog.ng.p, fp->d_ng, fp->d_ng_stats, n_cus, (hipStream_t)stream));
             HIP_TRY(ngram_watch_after_launch(fp, (hipStream_t)stream));
@@ -1536,11 +1555,18 @@ static int prefilter_info_uncached(const needle_pattern *p, int which, needle_pr
     if (!wide && (pr.hdr.mode == MODE_HYBRID || pr.hdr.mode == MODE_GLOBAL) && ngram_level() > 0) {
         // an automaton that fits the LDS in no form: the filter program walks its table out of HBM / L2 (lower_filter_hbm)
         const MatchLengths *ml = backward ? pattern_ml(p) : nullptr;
+        static const bool unbounded_hbm = !(getenv("NEEDLE_PREFILTER_UNBOUNDED") && atoi(getenv("NEEDLE_PREFILTER_UNBOUNDED")) == 0);
         if (!backward || ml) {
             Program hp = lower_filter_hbm(p->t, (Which)which, ml);
             if (!hp.blob.empty() && hp.hdr.mode == MODE_GLOBAL) pr = std::move(hp), usable = true;
+        } else if (unbounded_hbm) { // no bounded match lengths: the forward search automaton + backward walks (get_program variant 12)
+            Program hp = lower_filter_hbm(p->t, (Which)which, nullptr, true);
+            if (!hp.blob.empty() && hp.hdr.mode == MODE_GLOBAL) pr = std::move(hp), usable = true;
         }
     }
+    // (find() of a pattern without bounded match lengths: behind the filter of its ordinary LDS-resident program, starts by backward walks)
+    static const bool unbounded_on = !(getenv("NEEDLE_PREFILTER_UNBOUNDED") && atoi(getenv("NEEDLE_PREFILTER_UNBOUNDED")) == 0);
+    if (!wide && !usable && backward && unbounded_on && pr.hdr.mode != MODE_GLOBAL && pr.hdr.mode != MODE_HYBRID) usable = true;
     const NgramFilter &f = pr.ng;
     o->mode = (int32_t)pr.hdr.mode;
     if (!usable) {

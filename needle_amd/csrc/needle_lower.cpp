@@ -462,10 +462,12 @@ Program lower(const RefTables &t, Which which, int char_width, size_t lds_table_
 // the Bloom bitmap (and the 512-byte column map) in LDS and verifies its candidates -- ~3 per KiB of text, ~10 steps each -- by
 // walking the plain uint16 table out of HBM / L2.  which: W_CONTAINED_IN, or W_FORWARDS with ml (start = end - pend[stop state]) or
 // for one-length patterns.  8-bit rows.  ng.p.on = 0: no filter (the blob is still a valid HBM-table program).
-Program lower_filter_hbm(const RefTables &t, Which which, const MatchLengths *ml) {
+Program lower_filter_hbm(const RefTables &t, Which which, const MatchLengths *ml, bool with_backward_maps) {
     LowerAux aux;
     aux.ml_in_hbm = true;
-    Program p = lower_core(t, which, 1, 0, false, false, false, ml, &aux);
+    // (with_backward_maps: find() of a pattern without bounded match lengths -- the backward automaton's column maps ride in the LDS part,
+    // the filter kernel's verified candidates find their starts by indexBackwards)
+    Program p = lower_core(t, which, 1, 0, false, with_backward_maps, false, ml, &aux);
     memset(&p.ng.p, 0, sizeof(p.ng.p));
     if (p.blob.empty() || p.hdr.mode != MODE_GLOBAL || ngram_level() <= 0) return p;
     p.ng = build_ngram_filter(aux.next.data(), aux.n_dev, aux.n_cols, aux.cmap8.data(), aux.start, aux.accept_lo, aux.dead_hi, which == W_CONTAINED_IN,

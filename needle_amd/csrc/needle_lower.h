@@ -73,7 +73,7 @@ Program lower_match_lengths(const RefTables &t, const MatchLengths &ml, int char
 
 
 // The filter program of an automaton too big for the LDS in any form (needle_lower.cpp): HBM-table layout + the n-gram filter.
-Program lower_filter_hbm(const RefTables &t, Which which, const MatchLengths *ml);
+Program lower_filter_hbm(const RefTables &t, Which which, const MatchLengths *ml, bool with_backward_maps = false);
 Program lower_filter_wide(const RefTables &t, Which which, const MatchLengths *ml); // UTF-16 rows, windows of four code units (needle_ngram.h)
 
 // ---- find-all in LOCK-STEP (needle_find_all_ls.hip): the find-all transducer -------------------------------------------

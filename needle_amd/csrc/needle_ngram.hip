@@ -67,9 +67,14 @@ typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 // narrowed to bytes where it is loaded (the probe stream, the candidates' pieces, the second-level windows), nothing else differs.
 // WIDE (CW = 2 only): the pattern lives on several pages of the BMP -- nothing is narrowed: the windows are four 16-bit code units hashed as
 // they stand (needle_ngram.h ngram_piece16), the candidates walk the UTF-16 program (two-level page map in LDS, table out of HBM / L2).
-template <int OP, int MODE, int S, int CW = 1, bool WIDE = false>
+// BWD (find(), 8-bit rows, LDS-resident automata): patterns WITHOUT bounded match lengths (`(kw1|..|kw1000)[0-9]+`: no lengths automaton) --
+// a verified candidate's start is indexBackwards(end - 1, 0) (DFAClassBuilder.java:529-586) by the lock-step backward_walk of needle_walk.h
+// on the row's text out of L2, for the lanes whose run found a match; the program is the ordinary forward program with its backward column
+// maps, a.bprog the backward table.
+template <int OP, int MODE, int S, int CW = 1, bool WIDE = false, bool BWD = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramArgs A) {
     static_assert(!WIDE || (CW == 2 && MODE == MODE_GLOBAL), "the wide filter verifies on the UTF-16 HBM-table program");
+    static_assert(!BWD || (OP == OP_FIND && CW == 1 && !WIDE), "backward walks: find() on 8-bit rows");
     constexpr int TW = WIDE ? 2 : 1; // width of the code units the probes and the walks see
     const ScanArgs &a = A.a;
     constexpr int NW = 16 / S; // windows per 16-byte piece
@@ -301,7 +306,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         h.found = found, h.died = died && !found, h.crossed = crossed, h.first = first, h.last = last, h.start = 0;
         if (FINDLIKE) {
             const int32_t fixed_len = (int32_t)NEEDLE_NG_U32(a.fixed_len);
-            if (fixed_len >= 0) {
+            if (BWD) {
+                h.start = backward_walk<1>(a, found, (int32_t)last, 0, 16u, 0u, 0u, 0u, rowp); // (no window in LDS: every char from memory)
+            } else if (fixed_len >= 0) {
                 h.start = (int32_t)last - fixed_len; // :640-646
             } else {
                 uint32_t pidx = st;
@@ -604,9 +611,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     }
 }
 
-template <int OP, int MODE, int S, int CW, bool WIDE = false>
+template <int OP, int MODE, int S, int CW, bool WIDE = false, bool BWD = false>
 static hipError_t launch_ng(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
-    auto k = ngram_kernel<OP, MODE, S, CW, WIDE>;
+    auto k = ngram_kernel<OP, MODE, S, CW, WIDE, BWD>;
     static thread_local uint64_t configured = 0;
     if (hipError_t e = allow_full_lds((const void *)k, configured); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(n_cus), dim3(kWavesPerBlock * 64), lds, stream, A);
@@ -616,6 +623,10 @@ static hipError_t launch_ng(const NgramArgs &A, int n_cus, size_t lds, hipStream
 template <int OP, int MODE>
 static hipError_t launch_ng_s(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
     if (A.char_width == 2) return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 2>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 2>(A, n_cus, lds, stream);
+    if constexpr (OP == OP_FIND) {
+        if (A.a.bprog) // find() of a pattern without bounded match lengths: starts by backward walks
+            return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 1, false, true>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 1, false, true>(A, n_cus, lds, stream);
+    }
     return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 1>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 1>(A, n_cus, lds, stream);
 }
 

@@ -22,6 +22,13 @@ level = int(sys.argv[1])
 big = W.keywords(1000, min_len=6, max_len=8)
 small = ["Sherlock", "Holmes", "Watson", "Moriarty", "Mycroft", "Baskerville"]
 cases = [("|".join(big), big, 6, True)]
+# patterns WITHOUT bounded match lengths behind the filter (find()'s starts by backward walks, needle_ngram.hip BWD): a dictionary followed by
+# a run of digits -- the automaton in no LDS form (HBM-table filter program, get_program variant 12) ...
+ub = [w + str(10 + 7 * i % 90) for i, w in enumerate(big)]
+cases += [("(" + "|".join(big) + ")[0-9]+", ub, 3, True)]
+if level == 2:  # ... and small ones as plain LDS tables
+    names = [w + d for w, d in zip(small, ["1", "22", "333", "4", "55", "6"])]
+    cases += [("(" + "|".join(small) + ")[0-9]+", names, None, True), ("(abcdef|bcdefgh)x+y", ["abcdefxy", "bcdefghxxxy", "abcdefxxxxxxy"], None, True)]
 if level == 2:
     cases += [("|".join(small), small, None, True), ("abcdef|bcdefgh|cdefghij|xabcde", ["abcdef", "bcdefgh", "cdefghij", "xabcde"], None, True),
               ("abcdefgh", ["abcdefgh"], None, True), ("|".join(W.keywords(200, min_len=5, max_len=9)), W.keywords(200, min_len=5, max_len=9), None, True)]
