@@ -28,7 +28,7 @@ ub = [w + str(10 + 7 * i % 90) for i, w in enumerate(big)]
 cases += [("(" + "|".join(big) + ")[0-9]+", ub, 3, True)]
 if level == 2:  # ... and small ones as plain LDS tables
     names = [w + d for w, d in zip(small, ["1", "22", "333", "4", "55", "6"])]
-    cases += [("(" + "|".join(small) + ")[0-9]+", names, None, True), ("(abcdef|bcdefgh)x+y", ["abcdefxy", "bcdefghxxxy", "abcdefxxxxxxy"], None, True)]
+    cases += [("(" + "|".join(small) + ")[0-9]+", names, None, True), ("(abcdef|bcdefgh|cdefghij)[xy]+", ["abcdefxy", "bcdefghxxxy", "cdefghijyyxxxy"], None, True)]
 if level == 2:
     cases += [("|".join(small), small, None, True), ("abcdef|bcdefgh|cdefghij|xabcde", ["abcdef", "bcdefgh", "cdefghij", "xabcde"], None, True),
               ("abcdefgh", ["abcdefgh"], None, True), ("|".join(W.keywords(200, min_len=5, max_len=9)), W.keywords(200, min_len=5, max_len=9), None, True)]
