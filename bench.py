@@ -74,6 +74,11 @@ def make_pattern(workload):
         return (DFACompiler.compile("|".join(words), "Keywords3k"),
                 "union-of-3k-keywords (12 270 states) find() over UTF-16 rows (Java's strings): the byte program's n-gram filter, text narrowed as it is "
                 "loaded, candidates' walks out of L2", words)
+    if workload == "c3u":
+        kws = W.keywords(1000, min_len=6, max_len=8)
+        words = [w + str(10 + 7 * i % 90) for i, w in enumerate(kws)]  # what the rows hold: a keyword and two digits
+        return (DFACompiler.compile("(" + "|".join(kws) + ")[0-9]+", "Keywords1kDigits"),
+                "(union-of-1k-keywords)[0-9]+ -- no bounded match length: find() behind the n-gram filter, starts by backward walks", words)
     if workload == "c3m16":
         words = W.keywords_mixed(1000)
         return (DFACompiler.compile("|".join(words), "KeywordsMixed3k"),
@@ -121,7 +126,7 @@ def make_rows(workload, words, row0, n_rows, device):
         n = min(slab, n_rows - s)
         if workload == "c2":
             out[s:s + n] = W.digits_batch(torch, row0 + s, n, 256, device=device)
-        elif workload in ("c3", "c3s", "c3x", "c3s16", "c3x16"):
+        elif workload in ("c3", "c3s", "c3x", "c3s16", "c3x16", "c3u"):
             out[s:s + n] = W.keyword_batch(torch, words, row0 + s, n, 256, device=device)
         elif workload == "c3m16":
             out[s:s + n] = W.mixed_keyword_batch(torch, words, row0 + s, n, 256, device=device)
@@ -934,7 +939,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16", "c3m16"], help="the headline workload")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16", "c3m16", "c3u"], help="the headline workload")
     ap.add_argument("--also", default=None, help="comma list of further workloads measured into \"workloads\" "
                     "(default: c3,c3s,c3x,c5,c5w,c3s16,c3x16 at 1 GPU, c3 at N > 1; 'none' for profiling runs; c3s16 / c3x16: the c3s / c3x dictionaries over UTF-16 rows)")
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows in total (strong) or per GPU (weak)")
@@ -1004,7 +1009,7 @@ def main():
         if int(ok.item()) == 0:
             ctx.comm = None
     if args.also is None:
-        also = ["c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16", "c3m16"] if world == 1 else ["c3"]
+        also = ["c3", "c3s", "c3x", "c5", "c5w", "c3s16", "c3x16", "c3m16", "c3u"] if world == 1 else ["c3"]
         if args.regex or args.op or args.rows != 10_000_000:
             also = []
     else:
