@@ -121,9 +121,12 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     if (warm < 0) return no("a restarted walk does not catch up within 14 chars");
 
     // ---- stride: one window every S chars needs min_len >= 4 + S - 1 and K + S - 1 <= 16
+    // (NEEDLE_PREFILTER_STRIDE=2: never 4 -- stride 4 halves the probes but a pattern whose shortest match is 7 chars then has no second
+    // level, which wants 5 + S - 1 <= min_len: A/B)
+    static const int max_stride = getenv("NEEDLE_PREFILTER_STRIDE") ? atoi(getenv("NEEDLE_PREFILTER_STRIDE")) : 4;
     int S = 1;
     for (int cand : {4, 2})
-        if (kN + cand - 1 <= min_len && warm + cand - 1 <= 16) { S = cand; break; }
+        if (cand <= max_stride && kN + cand - 1 <= min_len && warm + cand - 1 <= 16) { S = cand; break; }
     if (S == 1) return no("matches shorter than 5 chars: every char would need a window (the kernel samples every 2nd or 4th)");
     if (warm + S - 1 > 16) return no("run-up longer than one load");
 

@@ -19,6 +19,7 @@ const Switch kSwitches[] = {
     {"NEEDLE_PREFILTER_UTF16", "1", "layout", "0: UTF-16 rows never take a filter kernel (patterns on one page of the BMP: the byte program's, text narrowed as it is loaded; several pages: the wide filter)"},
     {"NEEDLE_PREFILTER_WIDE", "1", "layout", "0: UTF-16 rows of patterns on several pages of the BMP never take the wide filter (windows of four 16-bit code units, needle_ngram.h ngram_piece16); NEEDLE_PREFILTER_UTF16=0 switches it off too"},
     {"NEEDLE_PREFILTER_UNBOUNDED", "1", "layout", "0: find() of patterns without bounded match lengths never runs behind the n-gram filter (whose verified candidates find their starts by backward walks)"},
+    {"NEEDLE_PREFILTER_STRIDE", "4", "layout", "largest window stride the n-gram filter may choose (2: never 4 -- keeps the second-level window for patterns whose shortest match is 7 chars)"},
     {"NEEDLE_PREFILTER_WATCH", "1", "layout", "0: the filter kernel is never suspended (the flood watch: after a launch that saw more than 16 candidates per KiB of text the program's next 32 .. 1024 calls take the ordinary scan kernel)"},
     {"NEEDLE_FIND_LENGTHS", "1", "layout", "find() by the lengths automaton (start = end - length, no backward walk): 0 never (forward + backward walks), 1 where the ordinary program is an LDS table, 2 also instead of a pair table"},
     {"NEEDLE_FIND_LENGTHS_SPARSE", "1", "layout", "0: compressed-form automata keep the two walks"},
