@@ -124,9 +124,15 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     // (NEEDLE_PREFILTER_STRIDE=2: never 4 -- stride 4 halves the probes but a pattern whose shortest match is 7 chars then has no second
     // level, which wants 5 + S - 1 <= min_len: A/B)
     static const int max_stride = getenv("NEEDLE_PREFILTER_STRIDE") ? atoi(getenv("NEEDLE_PREFILTER_STRIDE")) : 4;
+    // Stride 4 only where the second level survives it (5 + 4 - 1 <= min_len): with shortest matches of 7 chars, stride 2 + the second
+    // level beats stride 4 without one (c3u, a dictionary followed by [0-9]+: 0.89 against 1.00 ms) -- what the automaton runs on costs
+    // more than the probes saved.  NEEDLE_PREFILTER_LEVEL2=0 (no second level at all): stride 4 from 7 chars on, as before.
+    static const bool level2_wanted = !(getenv("NEEDLE_PREFILTER_LEVEL2") && atoi(getenv("NEEDLE_PREFILTER_LEVEL2")) == 0);
     int S = 1;
-    for (int cand : {4, 2})
+    for (int cand : {4, 2}) {
+        if (cand == 4 && level2_wanted && min_len < kN + 1 + cand - 1) continue;
         if (cand <= max_stride && kN + cand - 1 <= min_len && warm + cand - 1 <= 16) { S = cand; break; }
+    }
     if (S == 1) return no("matches shorter than 5 chars: every char would need a window (the kernel samples every 2nd or 4th)");
     if (warm + S - 1 > 16) return no("run-up longer than one load");
 
