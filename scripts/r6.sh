@@ -33,6 +33,17 @@ fa_prof)
   done; done ;;
 bench)
   timeout 1700 python bench.py "$@" > $O/bench_$TAG.json 2> $O/bench_$TAG.err; grep -v "^{" $O/bench_$TAG.err | tail -3; wc -c $O/bench_$TAG.json; tail -c 1500 $O/bench_$TAG.json ;;
+profiles)
+  # everything profiles/r06_* is made from: per workload the rocprofv3 kernel trace + FETCH / WRITE / EA passes (scripts/profile.sh), PMC
+  # groups of the filter / walk kernels (scripts/pmc.sh), the find-all kernels' trace + counters in both one-dword forms, then the default bench
+  for w in ${@:-c2 c3 c3s c3x c5 c5w c3s16 c3x16 c3m16 c3u}; do scripts/profile.sh $w > gpurun_out/profile_$w.log 2>&1; done
+  G1="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SMEM"
+  G2="SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY"
+  G3="SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+  for w in c3s c3x c5w c3m16; do scripts/pmc.sh $w r6 "$G1" "$G2" "$G3" > gpurun_out/pmc_${w}_r6.log 2>&1; done
+  rm -rf $O/fa_prof; $0 fa_prof c3 > $O/fa_prof.log 2>&1
+  for w in c3 c2 c5 c3s c3x; do $0 fa $w > $O/fa_$w.log 2>&1; done
+  timeout 1700 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python scripts/bench_digest.py $O/bench_default.json ;;
 py)
   s=$1; shift
   python $s "$@" > $O/$(basename $s .py)_$TAG.log 2>&1; tail -30 $O/$(basename $s .py)_$TAG.log ;;
