@@ -197,6 +197,28 @@ public final class GpuPattern implements Pattern, AutoCloseable {
     }
 
     /**
+     * find() on rows of at most 256 chars with every row's result as ONE short (needle_find_packed8_host): decode with
+     * {@link #start8(short)} / {@link #end8(short)}.  Returns the match bitmap.
+     */
+    public long[] findBatchPacked8(ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen, ByteBuffer lengths, short[] startLen) {
+        long[] bitmap = new long[(int) ((nRows + 63) / 64)];
+        check(Native.findPacked8Host(handle, rows, charWidth, nRows, rowStride, rowLen, lengths, bitmap, startLen), null);
+        return bitmap;
+    }
+
+    /** start() of a findBatchPacked8 entry (-1: no match): Matcher.start(), DFAClassBuilder.java:660-667. */
+    public static int start8(short e) {
+        int x = e & 0xFFFF;
+        return x == 0xFFFF ? -1 : x == 0xFFFE ? 0 : (x & 0xFF);
+    }
+
+    /** end() of a findBatchPacked8 entry (-1: no match). */
+    public static int end8(short e) {
+        int x = e & 0xFFFF;
+        return x == 0xFFFF ? -1 : x == 0xFFFE ? 256 : (x & 0xFF) + (x >> 8);
+    }
+
+    /**
      * Whether find() of this pattern runs behind the n-gram candidate filter on batches of 8-bit rows (the table-level form of the
      * reference's prefix / first-byte narrowing, DFAClassBuilder.java:365-376, :420-426); the reason when it does not.
      */

@@ -77,6 +77,13 @@ final class Native {
     static native int findPacked16Host(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
                                        java.nio.ByteBuffer lengths, long[] bitmap, int[] startEnd);
 
+    /**
+     * needle_find_packed8_host (round 6): rows of at most 256 chars, ONE short per row -- start | (end - start) << 8; 0xFFFF = no match,
+     * 0xFFFE = the match (0, 256): 2 result bytes per row over PCIe.
+     */
+    static native int findPacked8Host(long handle, java.nio.ByteBuffer rows, int charWidth, long nRows, long rowStride, int rowLen,
+                                      java.nio.ByteBuffer lengths, long[] bitmap, short[] startLen);
+
     /** needle_tuning_info: the library's NEEDLE_* environment switches, tab-separated lines (name, default, current, scope, effect). */
     static native String tuningInfo();
 

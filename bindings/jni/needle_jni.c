@@ -217,6 +217,19 @@ NATIVE(jint, findPacked16Host)(JNIEnv *env, jclass c, jlong h, jobject rows, jin
     return rc;
 }
 
+/* needle_find_packed8_host: rows of at most 256 chars, ONE short per row (start | (end - start) << 8; 0xFFFF: no match, 0xFFFE: (0, 256)) */
+NATIVE(jint, findPacked8Host)(JNIEnv *env, jclass c, jlong h, jobject rows, jint cw, jlong n, jlong stride, jint rowLen, jobject lengths, jlongArray bitmap, jshortArray startLen) {
+    needle_batch_view v;
+    view_of(env, &v, rows, cw, n, stride, rowLen, lengths);
+    if (!long_room(env, bitmap, (n + 63) / 64) || startLen == NULL || (jlong)(*env)->GetArrayLength(env, startLen) < n) return NEEDLE_ERR_INVALID;
+    jlong *bm = (*env)->GetLongArrayElements(env, bitmap, NULL);
+    jshort *sl = (*env)->GetShortArrayElements(env, startLen, NULL);
+    int rc = needle_find_packed8_host((const needle_pattern *)(intptr_t)h, &v, (uint64_t *)bm, (uint16_t *)sl);
+    (*env)->ReleaseLongArrayElements(env, bitmap, bm, 0);
+    (*env)->ReleaseShortArrayElements(env, startLen, sl, 0);
+    return rc;
+}
+
 NATIVE(jstring, tuningInfo)(JNIEnv *env, jclass c) {
     size_t need = 0;
     if (needle_tuning_info(NULL, 0, &need) != NEEDLE_OK || need == 0) return (*env)->NewStringUTF(env, "");
