@@ -53,7 +53,29 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+_PATTERNS = {}
+
+
 def make_pattern(workload):
+    """(pattern, label, planted words) of a workload; compiled once per process and regex (c3s16 / c3x16 scan the c3s / c3x dictionaries:
+    a 3000-keyword compile takes ~30 s)."""
+    key = {"c3s16": "c3s", "c3x16": "c3x"}.get(workload, workload)
+    if key not in _PATTERNS:
+        _PATTERNS[key] = _make_pattern(key)
+    p, _, words = _PATTERNS[key]
+    return p, _make_label(workload, _PATTERNS[key][1]), words
+
+
+def _make_label(workload, label):
+    if workload == "c3s16":
+        return "union-of-1k-keywords (6..8 chars) find() over UTF-16 rows (Java's strings): the byte program's n-gram filter, text narrowed as it is loaded"
+    if workload == "c3x16":
+        return ("union-of-3k-keywords (12 270 states) find() over UTF-16 rows (Java's strings): the byte program's n-gram filter, text narrowed as it is "
+                "loaded, candidates' walks out of L2")
+    return label
+
+
+def _make_pattern(workload):
     from needle_amd import workload as W
     from needle_amd.pattern import DFACompiler
     if workload == "c2":
