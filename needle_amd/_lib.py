@@ -11,7 +11,7 @@ NEEDLE_OK, ERR_INVALID, ERR_SYNTAX, ERR_COMPILE, ERR_UNSUPPORTED, ERR_DEVICE = 0
 EXPORTS = [
     "needle_version", "needle_last_error", "needle_device_count", "needle_trim_scratch", "needle_tuning_info", "needle_compile", "needle_pattern_from_tables",
     "needle_pattern_destroy", "needle_pattern_serialize", "needle_pattern_deserialize", "needle_pattern_get_info", "needle_pattern_program_info", "needle_pattern_prefilter_info", "needle_pattern_prefilter_info2", "needle_pattern_set_prefilter", "needle_pattern_prefilter_state", "needle_pattern_utf16_route", "needle_pattern_match_lengths", "needle_pattern_find_all_transducer", "needle_pattern_get_class_map", "needle_pattern_get_table",
-    "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_find_packed16_dev", "needle_find_packed8_dev", "needle_find_next_dev", "needle_find_all_dev", "needle_find_all_packed16_dev", "needle_find_all_blocked16_dev", "needle_count_matches_dev", "needle_find_all_csr_dev", "needle_find_all_host", "needle_find_all_packed16_host", "needle_find_all_csr_host",
+    "needle_matches_dev", "needle_contained_in_dev", "needle_find_dev", "needle_find_packed16_dev", "needle_find_packed8_dev", "needle_find_next_dev", "needle_find_all_dev", "needle_find_all_packed16_dev", "needle_find_all_blocked16_dev", "needle_find_all_compact16_dev", "needle_count_matches_dev", "needle_find_all_csr_dev", "needle_find_all_host", "needle_find_all_packed16_host", "needle_find_all_csr_host",
     "needle_pack_start_end16_dev", "needle_unpack_start_end16_dev", "needle_matches_host",
     "needle_contained_in_host", "needle_find_host", "needle_find_compact_dev", "needle_find_compact_host", "needle_find_packed16_host", "needle_find_packed8_host", "needle_matcher_create", "needle_matcher_destroy",
     "needle_matcher_matches", "needle_matcher_contained_in", "needle_matcher_find", "needle_matcher_find_range",
@@ -118,6 +118,7 @@ def lib():
     L.needle_find_all_dev.argtypes = [VP, P(BatchView), ctypes.c_uint32, VP, VP, VP, P(I), VP]
     L.needle_find_all_packed16_dev.argtypes = [VP, P(BatchView), ctypes.c_uint32, VP, VP, P(I), VP]
     L.needle_find_all_blocked16_dev.argtypes = [VP, P(BatchView), ctypes.c_uint32, VP, VP, P(I), VP]
+    L.needle_find_all_compact16_dev.argtypes = [VP, P(BatchView), ctypes.c_uint32, VP, VP, ctypes.c_uint64, VP, P(I), VP]
     L.needle_find_all_packed16_host.argtypes = [VP, P(BatchView), ctypes.c_uint32, VP, VP, P(I)]
     L.needle_count_matches_dev.argtypes = [VP, P(BatchView), VP, VP]
     L.needle_find_all_csr_dev.argtypes = [VP, P(BatchView), VP, VP, VP, P(I), VP]

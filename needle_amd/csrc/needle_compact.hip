@@ -151,6 +151,117 @@ int find_compact(const needle_pattern *p, const needle_batch_view *v, uint64_t *
     return done(NEEDLE_OK);
 }
 
+// ---- every match of every row in COMPACT (CSR) form in one call (needle_find_all_compact16_dev).  The two-pass form
+// (needle_count_matches_dev, the caller's prefix sum, needle_find_all_csr_dev) walks the text TWICE; here the text is walked once --
+// needle_find_all_blocked16_dev into scratch: group-blocked slots, slot k of 64 rows one 256-byte run -- and three small kernels turn
+// counts + blocks into offsets + a dense match array:
+//   group_sum_kernel     one wave per 64-row group: the group's matches
+//   u32_scan_kernel      exclusive prefix of the group sums inside blocks of 2048 groups, block totals (then block_scan_kernel)
+//   compact_kernel       one wave per group, one row per lane: offsets[row] = group base + prefix of the counts below it; slot k of the
+//                        group is read as one coalesced run and its live entries go to offsets[row] + k
+__global__ __launch_bounds__(256) void group_sum_kernel(const uint32_t *counts, uint64_t n_rows, uint64_t n_groups, uint32_t *gsum) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < n_groups; g += waves) {
+        const uint64_t row = (g << 6) + (uint64_t)lane;
+        uint32_t c = row < n_rows ? counts[row] : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+        if (lane == 0) gsum[g] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void u32_scan_kernel(const uint32_t *v, uint64_t n, uint32_t *off, uint32_t *block_sum) {
+    __shared__ uint32_t lds4[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * kWordsPerBlock + (uint64_t)threadIdx.x * 8;
+    uint32_t c[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        c[k] = (i0 + k < n) ? v[i0 + k] : 0u;
+        sum += c[k];
+    }
+    uint32_t total;
+    uint32_t at = block_exclusive_scan_256(sum, lds4, total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (i0 + k < n) off[i0 + k] = at;
+        at += c[k];
+    }
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(const uint32_t *counts, const uint32_t *blocks, uint32_t slots, uint64_t n_rows, uint64_t n_groups,
+                                                       const uint32_t *goff, const uint64_t *block_off, const uint64_t *total, uint64_t *offsets,
+                                                       uint32_t *out, uint64_t cap) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < n_groups; g += waves) {
+        const uint64_t row = (g << 6) + (uint64_t)lane;
+        const uint32_t c = row < n_rows ? counts[row] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += t;
+        }
+        const uint64_t base = block_off[g / kWordsPerBlock] + goff[g] + (incl - c);
+        if (row < n_rows) offsets[row] = base;
+        uint32_t most = c;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)most, o);
+            most = t > most ? t : most;
+        }
+        const uint32_t *blk = blocks + g * (uint64_t)slots * 64u + (uint32_t)lane;
+        for (uint32_t k = 0; k < most; ++k) { // (wave-uniform trip count: the group's busiest row)
+            if (k < c) {
+                const uint32_t m = blk[(uint64_t)k * 64u];
+                if (base + k < cap) out[base + k] = m;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n_rows] = *total;
+}
+
+int find_all_compact16(const needle_pattern *p, const needle_batch_view *v, uint32_t max_per_row, uint64_t *d_offsets, uint32_t *d_start_end16,
+                       uint64_t cap, uint64_t *d_total, int *more, void *stream_) {
+    if (!p || !v) return fail(NEEDLE_ERR_INVALID, "NULL argument");
+    if (!d_offsets || !d_total || (cap && !d_start_end16)) return fail(NEEDLE_ERR_INVALID, "output buffer is NULL");
+    if (max_per_row == 0 || max_per_row > 4096) return fail(NEEDLE_ERR_INVALID, "max_per_row must be 1 .. 4096");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (more) *more = 0;
+    if (v->n_rows == 0) {
+        if (hipMemsetAsync(d_total, 0, 8, stream) != hipSuccess || hipMemsetAsync(d_offsets, 0, 8, stream) != hipSuccess) return fail(NEEDLE_ERR_DEVICE, "hipMemsetAsync");
+        return NEEDLE_OK;
+    }
+    const uint64_t n = v->n_rows, n_groups = (n + 63) / 64;
+    const uint32_t n_blocks = (uint32_t)((n_groups + kWordsPerBlock - 1) / kWordsPerBlock);
+    auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+    const uint64_t o_blocks = up(n * 4), o_gsum = o_blocks + up(n_groups * (uint64_t)max_per_row * 256), o_goff = o_gsum + up(n_groups * 4),
+                   o_bsum = o_goff + up(n_groups * 4), o_boff = o_bsum + up((uint64_t)n_blocks * 4), total = o_boff + up((uint64_t)n_blocks * 8);
+    uint8_t *tmp = nullptr;
+    if (needle::scratch_malloc((void **)&tmp, total, stream) != hipSuccess) return fail(NEEDLE_ERR_DEVICE, "hipMallocAsync (compact find-all scratch)");
+    auto done = [&](int code) {
+        (void)needle::scratch_free(tmp, stream);
+        return code;
+    };
+    uint32_t *counts = (uint32_t *)tmp, *blocks = (uint32_t *)(tmp + o_blocks), *gsum = (uint32_t *)(tmp + o_gsum), *goff = (uint32_t *)(tmp + o_goff),
+             *bsum = (uint32_t *)(tmp + o_bsum);
+    uint64_t *boff = (uint64_t *)(tmp + o_boff);
+    // (more == NULL: no synchronisation -- a row with more than max_per_row matches is then silently cut, as in the dense forms)
+    const int rc = needle_find_all_blocked16_dev(p, v, max_per_row, counts, blocks, more, stream_);
+    if (rc) return done(rc);
+    const unsigned grid = (unsigned)std::min<uint64_t>((n_groups + 3) / 4, 4096);
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid), dim3(256), 0, stream, counts, n, n_groups, gsum);
+    hipLaunchKernelGGL(u32_scan_kernel, dim3(n_blocks), dim3(256), 0, stream, gsum, n_groups, goff, bsum);
+    hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, stream, bsum, n_blocks, boff, d_total);
+    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(256), 0, stream, counts, blocks, max_per_row, n, n_groups, goff, boff, d_total, d_offsets,
+                       d_start_end16, cap);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return done(fail(NEEDLE_ERR_DEVICE, std::string("compact find-all kernels: ") + hipGetErrorString(e)));
+    return done(NEEDLE_OK);
+}
+
 // ---- host batches: chunks of at most ~2 GiB of rows resident at a time (64-row boundaries: whole bitmap words)
 struct HostChunk {
     uint8_t *d_rows = nullptr;
@@ -207,6 +318,11 @@ uint64_t rows_per_chunk(const needle_batch_view *v) {
 } // namespace
 
 extern "C" {
+
+int needle_find_all_compact16_dev(const needle_pattern *p, const needle_batch_view *v, uint32_t max_per_row, uint64_t *d_offsets,
+                                  uint32_t *d_start_end16, uint64_t cap, uint64_t *d_total, int *more, void *stream) {
+    return find_all_compact16(p, v, max_per_row, d_offsets, d_start_end16, cap, d_total, more, stream);
+}
 
 int needle_find_compact_dev(const needle_pattern *p, const needle_batch_view *v, uint64_t *d_bitmap, needle_match_rec *d_recs, uint64_t cap,
                             uint64_t *d_n_matched, void *stream_) {

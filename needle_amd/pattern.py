@@ -465,6 +465,29 @@ class Pattern:
                                                    ctypes.byref(more) if want_more else None, s))
         return counts, blocks, (bool(more.value) if want_more else None)
 
+    def find_all_compact16(self, rows, max_per_row=32, lengths=None, stream=None, cap=None, want_more=True):
+        """needle_find_all_compact16_dev: every match of every row in compact (CSR) form in ONE call that walks the text once
+        -> (offsets int64[n + 1], start_end16 int32[total] (start | end << 16), more: bool or None).  cap: dwords of room for the matches
+        (default: 8 per row, grown to the exact total when that was too little); more = some row had more than max_per_row matches (its
+        list is cut: raise max_per_row, or use find_all_csr)."""
+        import torch
+        L = _lib.lib()
+        v, n = self._dev_view(rows, lengths), rows.shape[0]
+        with torch.cuda.device(rows.device):
+            s = torch.cuda.current_stream(rows.device).cuda_stream if stream is None else stream
+            offsets = torch.empty(n + 1, dtype=torch.int64, device=rows.device)
+            total = torch.zeros(1, dtype=torch.int64, device=rows.device)
+            cap = int(cap) if cap is not None else max(1024, 8 * n)
+            while True:
+                se = torch.empty(cap, dtype=torch.int32, device=rows.device)
+                more = ctypes.c_int(0)
+                _check(L.needle_find_all_compact16_dev(self._h, ctypes.byref(v), int(max_per_row), offsets.data_ptr(), se.data_ptr(), cap,
+                                                       total.data_ptr(), ctypes.byref(more) if want_more else None, s))
+                t = int(total.item())
+                if t <= cap:
+                    return offsets, se[:t], (bool(more.value) if want_more else None)
+                cap = t
+
     @staticmethod
     def unblock16(blocks, n_rows):
         """[groups, slots, 64] group-blocked slots -> [n_rows, slots] row-major (a copy)."""

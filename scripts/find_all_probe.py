@@ -70,7 +70,14 @@ for rep in range(0 if os.environ.get("FIND_ALL_PROBE_DENSE_ONLY") else 3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out["csr_ms"] = round(dt * 1e3, 3) if rep == 0 or dt * 1e3 < out["csr_ms"] else out["csr_ms"]
+for rep in range(0 if os.environ.get("FIND_ALL_PROBE_DENSE_ONLY") else 3):  # the compact form in one call (blocked pass + scan + compaction)
+    t0 = time.perf_counter()
+    o2, se2, _ = pattern.find_all_compact16(rows, slots, cap=total + 16, want_more=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["compact16_ms"] = round(dt * 1e3, 3) if rep == 0 or dt * 1e3 < out["compact16_ms"] else out["compact16_ms"]
 if not os.environ.get("FIND_ALL_PROBE_DENSE_ONLY"):
+    assert int(o2[-1].item()) == total and len(se2) == total
     assert int(offs[-1].item()) == total or more
 if len(sys.argv) > 4 and sys.argv[4] == "check":
     import numpy as np

@@ -45,6 +45,11 @@ def check(p, o, rows, lens, tag, every=1):
         assert (c3.cpu().numpy() == counts).all() and more3 == more, (tag, "blocked counts")
         assert (bv[filed] == sev[filed]).all() and (bv[~filed] == 0xFFFFFFFF).all(), (tag, "blocked form")
         assert (blocks.cpu().numpy().reshape(-1, slots, 64).transpose(0, 2, 1).reshape(-1, slots)[n:] == -1).all(), (tag, "rows beyond the batch")
+        # the compact form in one call (needle_find_all_compact16_dev: the blocked pass + scan + compaction): offsets + a dense match array
+        o2, se2, more4 = p.find_all_compact16(rows, slots, lens, cap=max(1, int(counts.sum()) // 2))  # (a capacity that is too small: retried)
+        o2, se2 = o2.cpu().numpy(), se2.cpu().numpy().view(np.uint32)
+        assert more4 == more and (np.diff(o2) == counts).all() and o2[0] == 0 and o2[-1] == counts.sum() == len(se2), (tag, "compact16 offsets")
+        assert (se2 == sev[filed]).all(), (tag, "compact16 matches")
         for i, w in want.items():
             k = min(len(w), slots)
             assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == w[:k], (tag, slots, i, counts[i], st[i].tolist(), en[i].tolist(), w[:8])

@@ -64,6 +64,9 @@ def check(p, o, rows, lens, tag):
         c3, blocks, more3 = p.find_all_blocked16(rows, slots, lens)  # group-blocked slots behind the filter
         bv = p.unblock16(blocks, n).cpu().numpy().view(np.uint32)
         assert (c3.cpu().numpy() == counts).all() and more3 == more and (bv[filed] == sev[filed]).all() and (bv[~filed] == 0xFFFFFFFF).all(), (tag, "find-all blocked")
+        o2, se2, more4 = p.find_all_compact16(rows, slots, lens)  # the compact form in one call, behind the filter
+        o2, se2 = o2.cpu().numpy(), se2.cpu().numpy().view(np.uint32)
+        assert more4 == more and (np.diff(o2) == counts).all() and o2[-1] == counts.sum() == len(se2) and (se2 == sev[filed]).all(), (tag, "find-all compact16")
         for i, w in want.items():
             k = min(len(w), slots)
             assert counts[i] == k and list(zip(st[i, :k].tolist(), en[i, :k].tolist())) == w[:k], (tag, "find-all", i, counts[i], st[i], en[i], w[:6])
