@@ -67,3 +67,18 @@ def test_self_launch_command_is_the_drivers(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "MASTER_PORT" not in seen["env"]
+
+
+def test_stdout_digest_stays_under_8_kb():
+    """The driver keeps the last 8 KB of stdout: the ONE line bench.py prints there (slim_line) must carry the contract's fields, `roofline`,
+    `cpu_baseline` and every workload's digest inside that -- checked on the full result of a real default run (profiles/r06_bench_full.json)."""
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_full.json")).read())
+    line = bench.slim_line(full)
+    text = json.dumps(line)
+    assert len(text) < 8000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and line["cpu_baseline"]["kind"] in ("port", "reference")
+    assert set(full["workloads"]) == set(line["workloads"]) and "ragged" in line and line["config"]["workload"].startswith("c2")
