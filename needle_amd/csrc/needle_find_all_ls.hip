@@ -159,6 +159,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
         }
         count += hit ? 1u : 0u;
     };
+    // RUNS: a match [st, en) as it stands -- a run's length is not bounded by 16 bits the way (length, k) codes are (rows of up to 8 MB)
+    auto file_se = [&](bool hit, uint32_t st, uint32_t en) __attribute__((always_inline)) {
+        if (hit && count < cap && !fa.count_only) {
+            const uint32_t off = voff + (count << kshift4);
+            if (fa.packed) {
+                store32(fa.packed + gbase, off, st | en << 16); // (one-dword forms: rows of at most 65 535 chars)
+            } else {
+                store32(fa.starts + gbase, off, st);
+                store32(fa.ends + gbase, off, en);
+            }
+        }
+        count += hit ? 1u : 0u;
+    };
     // The match codes of 8 consecutive chars (char j of them in nibble j of h; pos0 = row index of char 0)
     const bool direct_codes = a.hdr.ft_direct != 0u; // wave-uniform: codes are lengths (k = 0)
     const bool odd_codes = a.hdr.ft_odd != 0u; // wave-uniform: at most 8 codes, all odd -- bit 0 of a nibble = "a match ends here"
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
                     const uint32_t below = tf & ((1u << (b & 31u)) - 1u); // the chars of this log in front of the match's end
                     const uint32_t st = below ? pos0 + ((31u - (uint32_t)__builtin_clz(below)) >> 2) : run_start;
                     const uint32_t en = pos0 + ((b & 31u) >> 2);
-                    file(has, en, en - st); // (d = length, k = 0: start = end - length)
+                    file_se(has, st, en);
                 } while (__ballot(t != 0u) != 0ull);
             }
             run_start = tf ? pos0 + ((31u - (uint32_t)__builtin_clz(tf)) >> 2) : run_start;
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void find_all_lockstep_kernel(
         if (RUNS) {
             if (__ballot(code != 0u) != 0ull) {
                 if (fa.count_only) count += code & 1u;
-                else file((code & 1u) != 0u, len, len - run_start);
+                else file_se((code & 1u) != 0u, run_start, len);
             }
         } else if (__ballot(code != 0u) != 0ull) file(code != 0u, len, lds_u32(codes_off + (code << 2)));
         if (row_ok && fa.counts) fa.counts[my_row] = count < cap ? count : cap;

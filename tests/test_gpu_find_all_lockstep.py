@@ -121,6 +121,19 @@ for rx in ["[0-9]+", "[a-c]{3}[a-c]*", "a+b+", "ab*", "[0-9]+x", "[a-z]+[0-9]"]:
         total += check(p, o, rows, lens, (rx, stride, "runs ragged"), every=2)
         if stride >= 48:
             total += check(p, o, rows.to(torch.int16), lens, (rx, stride, "runs utf16 ragged"), every=5)
+# runs LONGER than 16 bits can hold, on rows beyond the one-dword forms' 65 535 chars (two int32 arrays; rows of up to 8 MB stay lock-step)
+p = DFACompiler.compile("[0-9]+", "t", 0)
+o, _ = oracle_for("[0-9]+", 0)
+host = np.full((70, 70016), ord("a"), dtype=np.uint8)
+host[::2, 10:66000] = ord("7")
+host[1::2, 5:9] = ord("3")
+host[1::2, 69000:] = ord("5")
+host[3::4, 30000:30001] = ord("9")
+cnt_, st_, en_, more_ = p.find_all_dense(torch.from_numpy(host).to(dev), 4)
+cnt_, st_, en_ = cnt_.cpu().numpy(), st_.cpu().numpy(), en_.cpu().numpy()
+for i in range(70):
+    w = o.find_all(host[i])
+    assert not more_ and cnt_[i] == len(w) and list(zip(st_[i, :len(w)].tolist(), en_[i, :len(w)].tolist())) == [tuple(x) for x in w], ("long runs", i, w)
 rx = W.script_regex()  # C5: a run of >= 3 chars of 42 BMP ranges, UTF-16 rows
 p = DFACompiler.compile(rx, "t", 0)
 o, _ = oracle_for(rx, 0)
