@@ -1581,7 +1581,7 @@ static int prefilter_info_uncached(const needle_pattern *p, int which, needle_pr
     o->bitmap_bytes = (int32_t)f.p.bm_bytes;
     o->m1 = f.p.m1, o->m2 = f.p.m2, o->addr_shift = f.p.addr_shift, o->addr_mask = f.p.addr_mask;
     *m1b = f.p.m1b, *m2b = f.p.m2b;
-    o->on2 = (int32_t)(o->on && f.p.on2 ? 1 : 0);
+    o->on2 = (int32_t)(o->on ? f.p.on2 : 0); // (2: two-sided, NgramParams::on2)
     if (o->on2) o->n_windows2 = (int32_t)f.p.n_grams2, o->bitmap2_bytes = (int32_t)f.p.bm2_bytes, o->m3 = f.p.m3, o->addr_mask2 = f.p.addr_mask2;
     snprintf(o->why, sizeof(o->why), "%s", f.p.on ? "" : (f.why.empty() ? (ngram_level() > 0 ? "not a mode the filter is built for" : "NEEDLE_PREFILTER=0") : f.why.c_str()));
     if (f.p.on) {

@@ -128,9 +128,14 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     // level beats stride 4 without one (c3u, a dictionary followed by [0-9]+: 0.89 against 1.00 ms) -- what the automaton runs on costs
     // more than the probes saved.  NEEDLE_PREFILTER_LEVEL2=0 (no second level at all): stride 4 from 7 chars on, as before.
     static const bool level2_wanted = !(getenv("NEEDLE_PREFILTER_LEVEL2") && atoi(getenv("NEEDLE_PREFILTER_LEVEL2")) == 0);
+    // Round 6: stride 3 (24-byte pieces, needle_ngram.h ngram_piece3) and the TWO-SIDED second level (NgramParams::on2 == 2), which needs
+    // min_len >= 5 + S - 2 only: shortest matches of 6 chars take stride 3 (was 2), of 7 chars stride 4 (was 2), each with a second level.
+    // The wide filter keeps strides 2 and 4 and the one-sided second level.
     int S = 1;
-    for (int cand : {4, 2}) {
-        if (cand == 4 && level2_wanted && min_len < kN + 1 + cand - 1) continue;
+    for (int cand : {4, 3, 2}) {
+        if (wide && cand == 3) continue;
+        const int need2 = kN + 1 + cand - (wide ? 1 : 2); // the shortest match for which this stride still has a second level
+        if (cand > 2 && level2_wanted && min_len < need2) continue;
         if (cand <= max_stride && kN + cand - 1 <= min_len && warm + cand - 1 <= 16) { S = cand; break; }
     }
     if (S == 1) return no("matches shorter than 5 chars: every char would need a window (the kernel samples every 2nd or 4th)");
@@ -150,8 +155,8 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
 
     // ---- windows: label sequences x1..xN of paths p0 -> .. -> pN with p_m in T[o + N - m]; frontier = (state, labels so far).
     // N = 4: the filter's windows; N = 5: the second level's.  false: too many paths.
-    auto enum_labels = [&](int N, std::unordered_set<uint64_t> &labels) -> bool {
-        for (int o = 0; o < S; ++o) {
+    auto enum_labels = [&](int N, std::unordered_set<uint64_t> &labels, int n_off) -> bool {
+        for (int o = 0; o < n_off; ++o) {
             std::vector<std::pair<uint32_t, uint64_t>> fr; // (state, labels: 8 bits per column)
             for (int s : order)
                 if (T[o + N][s]) fr.emplace_back((uint32_t)s, 0ull);
@@ -180,7 +185,7 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
         return true;
     };
     std::unordered_set<uint64_t> labels;
-    if (!enum_labels(kN, labels)) return no("too many window paths");
+    if (!enum_labels(kN, labels, S)) return no("too many window paths");
     if (labels.empty()) return no("no windows");
 
     // ---- expand columns to code units (16 bits per position; 8-bit programs: values below 256)
@@ -264,10 +269,16 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     // for them to lie inside it (else their first column is "any char" and they select nothing)
     f.p.on2 = 0;
     static const bool level2_on = !(getenv("NEEDLE_PREFILTER_LEVEL2") && atoi(getenv("NEEDLE_PREFILTER_LEVEL2")) == 0);
-    if (level2_on && min_len >= kN + 1 + S - 1) {
+    // TWO-SIDED (min_len == 5 + S - 2; not for the wide filter): the 5-column windows ending o = 0 .. S - 2 chars ahead of a first accept.  A
+    // candidate's window ends o chars ahead of the accept it announces, o = 0 .. S - 1 (unknown to the kernel).  o <= S - 2: the 5 chars
+    // ending where the window ends lie inside the match (it is >= 5 + o chars long) and are in the set.  o = S - 1: the 5 chars ending
+    // one char BEHIND the window's end -- the window's four and the match's next char -- end S - 2 ahead of the accept: in the set.  The
+    // kernel asks for both and lets the candidate pass when either is there (needle_ngram.hip level2).
+    const bool two_sided = !wide && S >= 2 && min_len == kN + 1 + S - 2;
+    if (level2_on && (min_len >= kN + 1 + S - 1 || two_sided)) {
         std::unordered_set<uint64_t> labels5;
         std::vector<std::pair<uint64_t, uint32_t>> grams5; // (the 4-unit window, the unit in front of it)
-        bool ok5 = enum_labels(kN + 1, labels5) && !labels5.empty();
+        bool ok5 = enum_labels(kN + 1, labels5, two_sided ? S - 1 : S) && !labels5.empty();
         for (uint64_t lab : labels5) {
             if (!ok5) break;
             const std::vector<uint16_t> *b[kN + 1];
@@ -293,7 +304,7 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
             while (bm2 >= 1024 && !ngram_layout((uint32_t)prog_lds_bytes, (uint32_t)bm_bytes, nullptr, kNgWaveLds, (uint32_t)bm2)) bm2 >>= 1;
             while (bm2 > 1024 && grams5.size() * 128 < bm2 * 8) bm2 >>= 1;
             if (bm2 >= 1024 && (double)grams5.size() / (double)(bm2 * 8) <= 0.10) {
-                f.p.on2 = 1;
+                f.p.on2 = two_sided ? 2u : 1u;
                 f.p.m3 = 0x9E3779u;
                 f.p.bm2_bytes = (uint32_t)bm2;
                 f.p.addr_mask2 = (uint32_t)(bm2 - 1) & ~3u;

@@ -41,7 +41,13 @@ def candidate(info, t, e, all_windows):
     if not window_passes(info, info["bitmap"], x):
         return False
     if info.get("on2") and e >= 5 and not info.get("no_level2"):
-        return bool(window2_passes(info, info["bitmap2"], x, int(t[e - 5])))
+        if window2_passes(info, info["bitmap2"], x, int(t[e - 5])):
+            return True
+        # two-sided (NgramParams::on2 == 2): or the 5 chars ending one char behind the window -- chars [e - 4, e + 1)
+        if info["on2"] == 2 and e < len(t):
+            xf = int(t[e - 3] | (t[e - 2] << 8) | (t[e - 1] << 16) | (t[e] << 24))
+            return bool(window2_passes(info, info["bitmap2"], xf, int(t[e - 4])))
+        return False
     return True
 
 
@@ -119,15 +125,16 @@ def run_window(au, text, qn, K, S, fixed_len, contained):
     return (first, last, last - L)
 
 
-def filtered(p, op, text, all_windows=False, info=None):
-    """(found, start, end) of one row by the filter algorithm; all_windows: every sampled window counts as a candidate."""
+def filtered(p, op, text, all_windows=False, info=None, phase=0):
+    """(found, start, end) of one row by the filter algorithm; all_windows: every sampled window counts as a candidate.  phase: the sampled
+    window ends are = phase (mod S) -- the kernel samples group-relative offsets, which for S = 3 is a different phase in every row."""
     info = info or p.prefilter_info("contained_in" if op == "contained_in" else "forwards", with_bitmap=True)
     assert info["on"], info
     au, fixed = from_pattern(p, op)
     S, K = info["stride"], info["warm"]
     best = None
     t = np.asarray(text).astype(np.int64)
-    for e in range(S, len(t) + 1, S):
+    for e in range(S + phase % S, len(t) + 1, S):
         if e < 4:
             continue
         if not candidate(info, t, e, all_windows):
@@ -171,7 +178,7 @@ def walk_row_sim(au, text, qn, r, lim0, fixed_len):
     return h
 
 
-def filtered_find_all(p, text, info=None, all_windows=False, row_slots=2, with_crossed=True):
+def filtered_find_all(p, text, info=None, all_windows=False, row_slots=2, with_crossed=True, phase=0):
     """Every match of one row by the filter kernel's find-all logic: verified candidates are filed with their row (found, or died /
     crossed an earlier accept on the way: "unknown"), and the row resolves them in window order against its moving cursor; rows with
     more than row_slots entries, and re-runs that cross an unfiled match, take the exact match-by-match loop.  with_crossed=False: the
@@ -182,7 +189,7 @@ def filtered_find_all(p, text, info=None, all_windows=False, row_slots=2, with_c
     S, K = info["stride"], info["warm"]
     t = np.asarray(text).astype(np.int64)
     entries = []
-    for e in range(S, len(t) + 1, S):
+    for e in range(S + phase % S, len(t) + 1, S):
         if e < 4:
             continue
         if not candidate(info, t, e, all_windows):  # (the find-all form asks the second level too where its LDS has room: exact either way)

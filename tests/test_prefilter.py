@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
-    """C3-sparse (1000 keywords of 6..8 chars, the compressed automaton): stride 2, run-up 8 = max_len, ~2000 windows."""
+    """C3-sparse (1000 keywords of 6..8 chars, the compressed automaton): stride 3 (round 6; 2 before), run-up 8 = max_len, ~3000
+    windows, the TWO-SIDED second level (shortest match 6 = 5 + 3 - 2)."""
     from needle_amd import workload as W
     from needle_amd.pattern import DFACompiler
     from test_compile_matches_txt import oracle_for
@@ -26,9 +27,9 @@ def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
     o, _ = oracle_for(rx, 0)
     for which in ("contained_in", "forwards"):
         i = p.prefilter_info(which)
-        assert i["on"] == 1 and i["mode"] == 6 and i["stride"] == 2 and i["warm"] == 8 and i["min_len"] == 6, i
-        assert 1500 <= i["n_windows"] <= 2000 and i["bitmap_bytes"] == 32768, i
-        assert i["on2"] == 1 and 1500 <= i["n_windows2"] <= 2100 and i["bitmap2_bytes"] == 8192, i  # the second level: 5-byte windows
+        assert i["on"] == 1 and i["mode"] == 6 and i["stride"] == 3 and i["warm"] == 8 and i["min_len"] == 6, i
+        assert 2500 <= i["n_windows"] <= 3000 and i["bitmap_bytes"] == 32768, i
+        assert i["on2"] == 2 and 1500 <= i["n_windows2"] <= 2100 and i["bitmap2_bytes"] == 8192, i  # the second level: 5-byte windows, two-sided
     rows = W.keyword_batch(np, words, 11, 72, 256)
     rows[::7, 256 - len(words[3]):] = [ord(c) for c in words[3]]        # a keyword that ends with the row
     rows[3::7, 256 - len(words[4]) + 1:] = [ord(c) for c in words[4]][:-1]  # ... and one the row's end cuts
@@ -40,9 +41,10 @@ def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
     for k, row in enumerate(rows):
         for text in (row, row[:lens[k]]):
             want = o.find_all(text)[:1]
-            got = sim.filtered(p, "find", text, info=fi)
-            assert got == ((True,) + want[0] if want else (False, -1, -1)), (k, len(text), got, want)
-            assert sim.filtered(p, "contained_in", text, info=ci)[0] == bool(want)
+            for phase in range(fi["stride"]):  # (the kernel's windows end at GROUP-relative multiples of 3: any phase inside a row)
+                got = sim.filtered(p, "find", text, info=fi, phase=phase)
+                assert got == ((True,) + want[0] if want else (False, -1, -1)), (k, len(text), phase, got, want)
+                assert sim.filtered(p, "contained_in", text, info=ci, phase=phase)[0] == bool(want)
             n_match += bool(want)
         if k % 8 == 0:  # every window a candidate: the restart K chars ahead alone
             want = o.find_all(row)[:1]
@@ -108,11 +110,12 @@ for rx, want_f, want_c in CASES:
         text = np.array(sum(parts, []), dtype=np.uint8)[:int(rng.integers(0, 64))]
         want = o.find_all(text)[:1]
         exp = ((True,) + want[0]) if want else (False, -1, -1)
+        ph = trial % 3
         if fi["on"]:
-            assert sim.filtered(p, "find", text, info=fi) == exp, (rx, bytes(text), exp)
-            assert sim.filtered(p, "find", text, all_windows=True, info=fi) == exp, (rx, bytes(text), exp)
+            assert sim.filtered(p, "find", text, info=fi, phase=ph) == exp, (rx, bytes(text), exp)
+            assert sim.filtered(p, "find", text, all_windows=True, info=fi, phase=ph) == exp, (rx, bytes(text), exp)
         if ci["on"]:
-            assert sim.filtered(p, "contained_in", text, info=ci)[0] == bool(want), (rx, bytes(text))
+            assert sim.filtered(p, "contained_in", text, info=ci, phase=ph)[0] == bool(want), (rx, bytes(text))
 assert n_on >= 7, n_on
 # find-all behind the filter: a candidate's run that CROSSES an earlier accept and lives on (the search automaton keeps the
 # higher-priority longer alternative and drops the restart threads) says nothing about its window -- filed as unknown, re-run
