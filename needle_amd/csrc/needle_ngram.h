@@ -18,8 +18,7 @@ namespace needle {
 // What the device needs to know about a filter (filled by the host analysis, needle_ngram_host.cpp).
 struct NgramParams {
     uint32_t on;          // 0: no filter for this program
-    uint32_t stride;      // S: one window every S chars (2, 3 or 4): window ENDS at group-relative offsets = 0 (mod S) -- S = 2, 4: also row-relative
-                          // (strides are multiples of 16); S = 3: whatever phase a row has, one of S consecutive positions is sampled
+    uint32_t stride;      // S: one window every S chars (1, 2 or 4), row-relative positions q = 0 (mod S)
     uint32_t warm;        // K: chars the automaton is run ahead of a window's end
     uint32_t m1, m2;      // hash multipliers (16 bits each): u = (x & 0xFFFF) * m1 + (x >> 16) * m2 (mod 2^32) -- one v_dot2_u32_u16
     uint32_t addr_shift;  // the window's two bits of the word: (u >> addr_shift) & 31 and (u >> (addr_shift - 8)) & 31; addr_shift = 24: the shift
@@ -175,39 +174,6 @@ __device__ __forceinline__ uint32_t ngram_piece(uint32_t log, uint32_t pw, uint3
     return log;
 }
 
-// S = 3: a lane holds 24 bytes (w[0 .. 5]; pw = the dword before them) and tests the eight windows ENDING at its bytes 3, 6, .. 24 -- the
-// ones starting at byte 3 k - 4 of the piece: six of them one v_alignbit away from the dwords, two aligned.  A third fewer probes per byte than
-// S = 2 and a unit's bookkeeping (load, previous dword, loop) spread over 1.5 KiB instead of 1.  Same three phases, same log layout (eight
-// verdicts shifted in from the top).
-__device__ __forceinline__ uint32_t ngram_piece3(uint32_t log, uint32_t pw, const uint32_t (&w)[6], uint32_t m, uint32_t addr_mask, uint32_t bm_base) {
-    const uint32_t q[7] = {pw, w[0], w[1], w[2], w[3], w[4], w[5]};
-    uint32_t x[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { // the window ending at piece byte 3 (k + 1) starts at byte a = 3 (k + 1) of q
-        const int a = 3 * (k + 1), d = a >> 2, sh = (a & 3) * 8;
-        x[k] = sh == 0 ? q[d] : __builtin_amdgcn_alignbit(q[d + 1], q[d], (uint32_t)sh);
-    }
-    uint32_t u[8], wv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(u[i]) : "v"(x[i]), "v"(m));
-        uint32_t a;
-        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(u[i]), "s"(addr_mask), "v"(bm_base));
-        wv[i] = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint32_t r1, r2;
-        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r1) : "v"(u[i]), "v"(wv[i]));
-        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r2) : "v"(u[i]), "v"(wv[i]));
-        log = __builtin_amdgcn_alignbit(r1 & r2, log, 1);
-    }
-    return log;
-}
-
 // The WIDE form: 16 UTF-16 code units held by one lane as eight dwords (lo, hi; pw = the dword before them: the previous lane's hi[3]).  A
 // window is four code units = two dwords (x0, x1), u = dot2(x0, mA) + dot2(x1, mB): with S = 2 every window is a pair of adjacent dwords and
 // each dword's first product serves the next window -- two v_dot2_u32_u16 per dword, no v_alignbit; S = 4: the pairs (0, 1), (2, 3), ...
@@ -276,24 +242,6 @@ __device__ __forceinline__ ng_u32x4 narrow16(const ng_u32x4 &A, const ng_u32x4 &
         o[2] = narrow_pair_patched(B[0], B[1], 0u, sub4), o[3] = narrow_pair_patched(B[2], B[3], 0u, sub4);
     }
     return o;
-}
-
-// ... 24 chars (S = 3: A, B, C = 12 dwords) -> 24 bytes
-__device__ __forceinline__ void narrow24(const ng_u32x4 &A, const ng_u32x4 &B, const ng_u32x4 &C, uint32_t page4, uint32_t sub4, uint32_t (&o)[6]) {
-    if (page4 != 0u) { // wave-uniform
-        o[0] = narrow_pair_patched(A[0], A[1], page4, sub4), o[1] = narrow_pair_patched(A[2], A[3], page4, sub4);
-        o[2] = narrow_pair_patched(B[0], B[1], page4, sub4), o[3] = narrow_pair_patched(B[2], B[3], page4, sub4);
-        o[4] = narrow_pair_patched(C[0], C[1], page4, sub4), o[5] = narrow_pair_patched(C[2], C[3], page4, sub4);
-        return;
-    }
-    o[0] = narrow_pair(A[0], A[1]), o[1] = narrow_pair(A[2], A[3]), o[2] = narrow_pair(B[0], B[1]), o[3] = narrow_pair(B[2], B[3]);
-    o[4] = narrow_pair(C[0], C[1]), o[5] = narrow_pair(C[2], C[3]);
-    const uint32_t any_hi = ((A[0] | A[1] | A[2]) | (A[3] | B[0] | B[1]) | (B[2] | B[3] | C[0]) | (C[1] | C[2] | C[3])) & 0xFF00FF00u;
-    if (__builtin_expect(__ballot(any_hi != 0u) != 0ull, 0)) {
-        o[0] = narrow_pair_patched(A[0], A[1], 0u, sub4), o[1] = narrow_pair_patched(A[2], A[3], 0u, sub4);
-        o[2] = narrow_pair_patched(B[0], B[1], 0u, sub4), o[3] = narrow_pair_patched(B[2], B[3], 0u, sub4);
-        o[4] = narrow_pair_patched(C[0], C[1], 0u, sub4), o[5] = narrow_pair_patched(C[2], C[3], 0u, sub4);
-    }
 }
 
 // The dword in front of this lane's piece when lanes hold consecutive pieces: lane l - 1's w3 (DPP wave_shr:1); lane 0 takes

@@ -18,6 +18,7 @@
 // length (DFAClassBuilder.java:640-646).
 #include <string.h>
 #include <stdio.h>
+#include <algorithm>
 #include <vector>
 #include "needle_walk.h"
 #include "needle_ngram.h"
@@ -60,9 +61,6 @@ constexpr int OP_NG_FIND_ALL = 3; // (beside OP_CONTAINED_IN / OP_FIND of needle
 constexpr int kNgPF = 4;                                // units in flight per wave = units per batch
 
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
-typedef u32x4 u32x4_a4 __attribute__((aligned(4))); // (a lane's piece of a 1.5 K unit starts at a multiple of 8 bytes)
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
 
@@ -78,16 +76,9 @@ template <int OP, int MODE, int S, int CW = 1, bool WIDE = false, bool BWD = fal
 __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramArgs A) {
     static_assert(!WIDE || (CW == 2 && MODE == MODE_GLOBAL), "the wide filter verifies on the UTF-16 HBM-table program");
     static_assert(!BWD || (OP == OP_FIND && CW == 1 && !WIDE), "backward walks: find() on 8-bit rows");
-    static_assert(!(WIDE && S == 3), "the wide filter samples every 2nd or 4th code unit");
     constexpr int TW = WIDE ? 2 : 1; // width of the code units the probes and the walks see
     const ScanArgs &a = A.a;
-    // S = 3 (needle_ngram.h ngram_piece3): a lane holds 24 chars of a unit, a unit is 1.5 K chars -- a multiple of 3, so that the sampled window
-    // ends (group-relative offsets = 0 mod 3) sit at the same places of every piece; a 64-row group is then NOT a whole number of units: its
-    // last unit is partly the next group's text (windows that end there belong to no row of this group and are dropped), and the unit slots of
-    // its last batch beyond that are loaded and not probed.
-    constexpr int LB = S == 3 ? 24 : 16;   // chars a lane holds of a unit
-    constexpr uint32_t UB = 64u * (uint32_t)LB; // chars per unit
-    constexpr int NW = LB / S;             // windows per piece
+    constexpr int NW = 16 / S; // windows per 16-byte piece
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,16 +151,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     if (g >= n_groups) return;
     // a group is stride / 16 units; batches are kNgPF units: where that does not divide, a group's last batch reaches into the next
     // group's text (read, masked, not used -- ngram_shape_ok bounds the waste)
-    const uint32_t units_full = (((64u * stride + UB - 1u) / UB) + (uint32_t)(kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
+    const uint32_t units_full = (((64u * stride) >> 10) + (uint32_t)(kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
     auto units_of = [&](uint64_t grp) -> uint32_t {
         if (grp + 1 < n_groups) return units_full;
         const uint32_t rows_in = (uint32_t)(a.n_rows - (grp << 6));
-        return (((rows_in * stride + UB - 1u) / UB) + (kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
+        return (((rows_in * stride + 1023u) >> 10) + (kNgPF - 1)) & ~(uint32_t)(kNgPF - 1);
     };
     // The prefetch cursor, one batch (kNgPF units) ahead of the one being filtered: the byte offset of its first unit is carried along
     // (+ 4 KiB per batch) and only recomputed when the cursor moves to another group, together with a flag that says whether the whole
     // group lies inside the rows -- a unit of such a group needs no clamping.
-    const uint32_t lane16 = (uint32_t)lane * (uint32_t)LB; // (this lane's piece inside a unit)
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     uint64_t pf_g = g, pf_base = 0;
     uint32_t pf_u = 0, pf_units = 0;
     bool pf_interior = false;
@@ -177,7 +168,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         pf_u = 0;
         pf_base = (pf_g << 6) * a.stride_bytes;
         pf_units = pf_g < n_groups ? units_of(pf_g) : (uint32_t)kNgPF;
-        pf_interior = pf_g < n_groups && pf_base + (uint64_t)pf_units * UB <= a.total_bytes;
+        pf_interior = pf_g < n_groups && pf_base + ((uint64_t)pf_units << 10) <= a.total_bytes;
     };
     // The cursor stands on a BATCH (kNgPF units of one group); unit k of it is loaded while unit k of the batch before is filtered, and the
     // cursor moves on after the batch's last unit.  A unit's load is ONE instruction -- the batch's base (SGPRs) + a per-unit lane offset
@@ -185,14 +176,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
     // (units past the rows read their last KiB, lanes past them their last 16 bytes -- never used).  No branch around a load: with one the
     // compiler's vmcnt bookkeeping gives up and waits for EVERY load in flight (measured: + 4.5 %).  (Round 5's per-UNIT cursor cost ~18
     // instructions and two branches per KiB -- a quarter of the filter phase: profiles/r06_filter_trace.md.)
-    struct Raw { u32x4 lo, hi, top; }; // a lane's chars of a unit as loaded (16 bytes: lo; 24: + hi[0 .. 1]; 32: + hi; 48: + top)
+    struct Raw { u32x4 lo, hi; }; // 16 chars as loaded (CW = 1: lo only)
     const uint8_t *nb_ptr = a.rows;
     uint32_t nb_off[kNgPF]; // in bytes
     auto set_batch = [&]() __attribute__((always_inline)) {
         uint64_t base = pf_base;
         uint32_t room = 0xFFFFFFFFu; // chars between the batch's base and the last place a 16-char load may start
         if (!pf_interior) { // wave-uniform: the rows' last group(s), or a prefetch past their end
-            const uint64_t last = a.total_bytes - (uint64_t)LB;
+            const uint64_t last = a.total_bytes - 16u;
             base = base < last ? base : last;
             const uint64_t r = last - base;
             room = r < 0x7FFFFFFFull ? (uint32_t)r : 0x7FFFFFFFu;
@@ -200,7 +191,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         nb_ptr = a.rows + base * CW;
 #pragma unroll
         for (int k = 0; k < kNgPF; ++k) {
-            const uint32_t o = lane16 + (uint32_t)k * UB;
+            const uint32_t o = lane16 + (uint32_t)k * 1024u;
             nb_off[k] = (o < room ? o : room) * CW;
         }
     };
@@ -209,18 +200,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         // text then never hits the L2 either)
         Raw v;
         const uint8_t *src = nb_ptr + nb_off[k];
-        v.lo = *(const u32x4_a4 *)src;
-        if (CW == 2) v.hi = *(const u32x4_a4 *)(src + 16);
-        if (CW == 2 && S == 3) v.top = *(const u32x4_a4 *)(src + 32);
-        if (CW == 1 && S == 3) { // 24 bytes: dwordx4 + dwordx2
-            const u32x2 h = *(const u32x2_a4 *)(src + 16);
-            v.hi[0] = h[0], v.hi[1] = h[1];
-        }
+        v.lo = *(const u32x4 *)src;
+        if (CW == 2) v.hi = *(const u32x4 *)(src + 16);
         return v;
     };
     auto advance_batch = [&]() __attribute__((always_inline)) {
         pf_u += (uint32_t)kNgPF;
-        pf_base += UB * kNgPF;
+        pf_base += 1024u * kNgPF;
         if (pf_u >= pf_units) {
             pf_g += wave_cnt;
             pf_enter_group();
@@ -420,8 +406,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
         const uint32_t rows_in = (g + 1 < n_groups) ? 64u : (uint32_t)(a.n_rows - (g << 6));
         const uint32_t gbytes = rows_in * stride;
         const uint32_t units = units_of(g);
-        n_units += (units * (UB >> 9)) >> 1; // (in KiB)
-        const uint32_t units_live = S == 3 ? (gbytes + UB - 1u) / UB : units; // S = 3: the slots of the last batch beyond the group's text are not probed
+        n_units += units;
         NG_STAMP(5)
         // ---- the group's result slots
         if (FA) *(lds_u32_t *)(uintptr_t)(cbase + (uint32_t)lane * 4u) = 0u;
@@ -454,33 +439,30 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 R[k] = load_unit(k);
                 if (k == kNgPF - 1) advance_batch();
                 asm volatile("" ::: "memory");
-                if (S == 3) {
-                    uint32_t w[6];
-                    if (CW == 1) w[0] = raw.lo[0], w[1] = raw.lo[1], w[2] = raw.lo[2], w[3] = raw.lo[3], w[4] = raw.hi[0], w[5] = raw.hi[1];
-                    else narrow24(raw.lo, raw.hi, raw.top, A.page4, A.sub4, w);
-                    const uint32_t pw = ngram_prev_dword(w[5], carry);
-                    carry = (uint32_t)__builtin_amdgcn_readlane((int)w[5], 63);
-                    if (k == 0 || u0 + (uint32_t)k < units_live) log = ngram_piece3(log, pw, w, mm, amask, bm_base);
-                    else log >>= NW;
-                } else if (WIDE) {
+                if (dbg == 4u) { // (measurement builds: the text is loaded and waited for, nothing is probed)
+                    log |= raw.lo[0] == 0x12345678u ? 1u : 0u;
+                    if (CW == 2) log |= raw.hi[0] == 0x12345678u ? 1u : 0u;
+                    continue;
+                }
+                if (WIDE) {
                     const uint32_t pw = ngram_prev_dword(raw.hi[3], carry);
                     carry = (uint32_t)__builtin_amdgcn_readlane((int)raw.hi[3], 63);
-                    log = ngram_piece16<(S == 3 ? 2 : S)>(log, pw, raw.lo, raw.hi, mm, mmB, amask, bm_base);
+                    log = ngram_piece16<S>(log, pw, raw.lo, raw.hi, mm, mmB, amask, bm_base);
                 } else {
                 const u32x4 v = CW == 1 ? raw.lo : narrow16(raw.lo, raw.hi, A.page4, A.sub4);
                 const uint32_t pw = ngram_prev_dword(v[3], carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)v[3], 63);
-                log = ngram_piece<(S == 3 ? 2 : S)>(log, pw, v[0], v[1], v[2], v[3], mm, amask, bm_base);
+                log = ngram_piece<S>(log, pw, v[0], v[1], v[2], v[3], mm, amask, bm_base);
                 }
                 NG_STAMP(1)
             }
             NG_STAMP(1)
-            const uint32_t po0 = u0 * UB + lane16; // byte offset of this lane's piece of the batch's first unit
+            const uint32_t po0 = (u0 << 10) + lane16; // byte offset of this lane's piece of the batch's first unit
             if (NW * kNgPF < 32) log >>= 32 - NW * kNgPF; // window wi of unit j at bit j * NW + wi
-            if (gbytes < (u0 + kNgPF) * UB) { // wave-uniform: the batch's last group: pieces past its rows hold nothing
+            if (gbytes < ((u0 + kNgPF) << 10)) { // wave-uniform: the batch's last group: pieces past its rows hold nothing
 #pragma unroll
                 for (int k = 0; k < kNgPF; ++k)
-                    if (po0 + (uint32_t)k * UB >= gbytes) log &= ~(((1u << NW) - 1u) << (k * NW));
+                    if (po0 + ((uint32_t)k << 10) >= gbytes) log &= ~(((1u << NW) - 1u) << (k * NW));
             }
             // ---- candidates to the queue; full sets of 64 run at once, the rest with the group's last batch
             const bool last_batch = u0 + kNgPF >= units;
@@ -489,7 +471,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void ngram_kernel(const NgramA
                 if (any != 0ull) {
                     const bool has = log != 0u;
                     const uint32_t b = (uint32_t)__builtin_ctz(log | 0x80000000u);
-                    const uint32_t e = po0 + (b / NW) * UB + ((b % NW) + 1u) * S; // end of the window inside the group
+                    const uint32_t e = po0 + ((b / NW) << 10) + ((b % NW) + 1u) * S; // end of the window inside the group
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
                     if (has) *(lds_u32_t *)(uintptr_t)(qbase + (((qtail + rank) & (kNgQueue - 1u)) << 2)) = e;
                     qtail += (uint32_t)__builtin_popcountll(any);
@@ -657,29 +639,20 @@ static hipError_t launch_ng(const NgramArgs &A, int n_cus, size_t lds, hipStream
     return hipGetLastError();
 }
 
-template <int OP, int MODE, int CW, bool BWD>
-static hipError_t launch_ng_stride(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
-    switch (A.ng.stride) {
-    case 4: return launch_ng<OP, MODE, 4, CW, false, BWD>(A, n_cus, lds, stream);
-    case 3: return launch_ng<OP, MODE, 3, CW, false, BWD>(A, n_cus, lds, stream);
-    case 2: return launch_ng<OP, MODE, 2, CW, false, BWD>(A, n_cus, lds, stream);
-    default: return hipErrorInvalidValue;
-    }
-}
-
 template <int OP, int MODE>
 static hipError_t launch_ng_s(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
-    if (A.char_width == 2) return launch_ng_stride<OP, MODE, 2, false>(A, n_cus, lds, stream);
+    if (A.char_width == 2) return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 2>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 2>(A, n_cus, lds, stream);
     if constexpr (OP == OP_FIND) {
-        if (A.a.bprog) return launch_ng_stride<OP, MODE, 1, true>(A, n_cus, lds, stream); // find() of a pattern without bounded match lengths: starts by backward walks
+        if (A.a.bprog) // find() of a pattern without bounded match lengths: starts by backward walks
+            return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 1, false, true>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 1, false, true>(A, n_cus, lds, stream);
     }
-    return launch_ng_stride<OP, MODE, 1, false>(A, n_cus, lds, stream);
+    return A.ng.stride == 4 ? launch_ng<OP, MODE, 4, 1>(A, n_cus, lds, stream) : launch_ng<OP, MODE, 2, 1>(A, n_cus, lds, stream);
 }
 
 template <int OP>
 static hipError_t launch_ng_m(const NgramArgs &A, int n_cus, size_t lds, hipStream_t stream) {
     if (A.ng.wide) { // UTF-16 rows, windows of four code units, walks on the UTF-16 HBM-table program (lower_filter_wide)
-        if (A.char_width != 2 || A.a.hdr.mode != MODE_GLOBAL || A.ng.stride == 3) return hipErrorInvalidValue;
+        if (A.char_width != 2 || A.a.hdr.mode != MODE_GLOBAL) return hipErrorInvalidValue;
         return A.ng.stride == 4 ? launch_ng<OP, MODE_GLOBAL, 4, 2, true>(A, n_cus, lds, stream) : launch_ng<OP, MODE_GLOBAL, 2, 2, true>(A, n_cus, lds, stream);
     }
     switch (A.a.hdr.mode) {
@@ -745,12 +718,6 @@ static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams 
     A.page4 = (uint32_t)(page & 255) * 0x01010101u, A.sub4 = (uint32_t)(sub & 255) * 0x01010101u;
     A.a = a;
     A.ng = ng;
-    // A filter built for one window every 3 chars (its windows: 0 .. 2 chars ahead of an accept) also serves the kernel that samples every
-    // 2nd: that is what batch shapes take whose 64-row groups the 1.5 K units of the stride-3 form divide badly (rows 64 or 128 bytes apart)
-    if (ng.stride == 3) {
-        const uint64_t units = (64u * a.stride_bytes + 1535u) / 1536u, rounded = (units + (kNgPF - 1)) & ~(uint64_t)(kNgPF - 1);
-        if (rounded * 4 > units * 5) A.ng.stride = 2;
-    }
     A.ng_bitmap = d_bitmap;
     A.stats = d_stats;
     const uint32_t stride = (uint32_t)a.stride_bytes;
@@ -797,6 +764,28 @@ static hipError_t launch_ngram_any(int op, const ScanArgs &a, const NgramParams 
         fprintf(stderr, "NG-STAMPS op %d mode %u S %u cw %d wide %u: waves %zu, mean lifetime %.0f cycles (max %.0f); shares: text-wait %.3f probe %.3f queue %.3f level2 %.3f walk %.3f group %.3f staging %.3f\n",
                 op, a.hdr.mode, ng.stride, char_width, ng.wide, n_waves, sum[7] / n_waves, mx, sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7],
                 sum[3] / sum[7], sum[4] / sum[7], sum[5] / sum[7], sum[6] / sum[7]);
+        { // how unevenly the waves finish: percentiles of their lifetimes, and the mean by XCD (block % 8) and by wave slot
+            std::vector<double> life(n_waves);
+            double xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, slot[kWavesPerBlock];
+            for (int k = 0; k < kWavesPerBlock; ++k) slot[k] = 0;
+            for (size_t w = 0; w < n_waves; ++w) life[w] = (double)h[w * 8 + 7], xcd[(w / kWavesPerBlock) % 8] += life[w], slot[w % kWavesPerBlock] += life[w];
+            std::vector<double> srt = life;
+            std::sort(srt.begin(), srt.end());
+            fprintf(stderr, "NG-LIFE p01 %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; by xcd:", srt[n_waves / 100], srt[n_waves / 10], srt[n_waves / 2], srt[n_waves * 9 / 10],
+                    srt[n_waves * 99 / 100], srt[n_waves - 1]);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %.0f", xcd[k] / (n_waves / 8));
+            fprintf(stderr, "; by wave slot:");
+            for (int k = 0; k < kWavesPerBlock; ++k) fprintf(stderr, " %.0f", slot[k] / n_cus);
+            fprintf(stderr, "\n");
+            for (int q = 0; q < 4; ++q) { // the four waves of a SIMD, oldest first: mean cycles by section
+                double sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t w = 0; w < n_waves; ++w)
+                    if ((int)((w % kWavesPerBlock) / 4) == q)
+                        for (int k = 0; k < 8; ++k) sec[k] += (double)h[w * 8 + k];
+                fprintf(stderr, "NG-SLOT %d: text-wait %.0f probe %.0f queue %.0f level2 %.0f walk %.0f group %.0f total %.0f\n", q, sec[0] / (n_waves / 4), sec[1] / (n_waves / 4),
+                        sec[2] / (n_waves / 4), sec[3] / (n_waves / 4), sec[4] / (n_waves / 4), sec[5] / (n_waves / 4), sec[7] / (n_waves / 4));
+            }
+        }
         return hipSuccess;
     }
 #endif

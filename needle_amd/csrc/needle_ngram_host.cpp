@@ -128,12 +128,13 @@ NgramFilter build_ngram_filter(const uint16_t *next, int n_dev, int n_cols, cons
     // level beats stride 4 without one (c3u, a dictionary followed by [0-9]+: 0.89 against 1.00 ms) -- what the automaton runs on costs
     // more than the probes saved.  NEEDLE_PREFILTER_LEVEL2=0 (no second level at all): stride 4 from 7 chars on, as before.
     static const bool level2_wanted = !(getenv("NEEDLE_PREFILTER_LEVEL2") && atoi(getenv("NEEDLE_PREFILTER_LEVEL2")) == 0);
-    // Round 6: stride 3 (24-byte pieces, needle_ngram.h ngram_piece3) and the TWO-SIDED second level (NgramParams::on2 == 2), which needs
-    // min_len >= 5 + S - 2 only: shortest matches of 6 chars take stride 3 (was 2), of 7 chars stride 4 (was 2), each with a second level.
-    // The wide filter keeps strides 2 and 4 and the one-sided second level.
+    // Round 6: the TWO-SIDED second level (NgramParams::on2 == 2) needs min_len >= 5 + S - 2 only: shortest matches of 7 chars take stride 4
+    // with it (was: stride 2), of 5 chars stride 2 with it (was: no second level).  The wide filter keeps the one-sided second level.
+    // (Tried and dropped: stride 3 -- 24-byte pieces, 1.5 K units, a third fewer probes per byte than stride 2 -- for shortest matches of 6
+    // chars: c3s 0.600 against 0.604 ms, c3x 0.79 against 0.73: the extra candidates of its two-sided second level cost what the probes save;
+    // profiles/r06_filter_trace.md.)
     int S = 1;
-    for (int cand : {4, 3, 2}) {
-        if (wide && cand == 3) continue;
+    for (int cand : {4, 2}) {
         const int need2 = kN + 1 + cand - (wide ? 1 : 2); // the shortest match for which this stride still has a second level
         if (cand > 2 && level2_wanted && min_len < need2) continue;
         if (cand <= max_stride && kN + cand - 1 <= min_len && warm + cand - 1 <= 16) { S = cand; break; }

@@ -1,0 +1,113 @@
+// What HBM read rate do the kernels' FETCH PATTERNS reach by themselves on gfx950?  Persistent grid (one 1024-thread workgroup per CU, as the
+// scan / filter kernels), every wave keeps PF 1 KiB loads (64 lanes x 16 bytes) in flight and xors what arrives; nothing else.  Patterns:
+//   0  filter-like: a wave owns a CHUNK (16 KiB = a 64-row group of 256-byte rows) and reads it front to back, 1 KiB per load; the 16 waves
+//      of a CU own 16 adjacent chunks; next chunk = + all the grid's waves (needle_ngram.hip)
+//   1  CU-interleaved: the 16 waves of a CU read ONE 16-chunk region together, wave w the units w, w + 16, ...
+//   2  scan-like: a chunk = 64 rows, a load = 128-byte lines of 8 rows (lane -> row l / 8 + 8 j, bytes (l & 7) * 16 of the line), lines left
+//      to right (needle_scan.h)
+//   3  wave-major: a wave owns one long contiguous range of the buffer (4096 streams spread over all of it)
+//   4  like 0, the waves of a CU rotated: wave w starts its chunk at unit (5 w) mod units and wraps
+// hipcc --offload-arch=gfx950 -O3 -o /tmp/stream_pattern scripts/probes/stream_pattern.hip && /tmp/stream_pattern
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int PF, int MODE>
+__global__ __launch_bounds__(1024) void stream_kernel(const uint8_t *base, uint64_t total, uint32_t chunk, uint32_t stride, uint32_t *sink) {
+    extern __shared__ uint8_t smem[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 16, gw = (uint64_t)blockIdx.x * 16 + wave;
+    const uint32_t units = chunk >> 10, ushift = 31u - (uint32_t)__builtin_clz(units); // 1 KiB loads per chunk (a power of two >= PF)
+    const uint64_t n_chunks = total / chunk, per = n_chunks / n_waves;
+    uint32_t acc = 0;
+    if (smem[threadIdx.x & 15] == 77) acc = 1; // (keeps the LDS allocation alive)
+    // unit t of this wave's sequence -> address
+    auto addr = [&](uint64_t t) -> const uint8_t * {
+        uint64_t c, u = t & (units - 1u);
+        const uint64_t i = t >> ushift;
+        if (MODE == 3) {
+            c = gw * per + i;
+            if (i >= per) return base + (uint64_t)lane * 16u;
+        } else if (MODE == 1) {
+            // region r = 16 chunks of this CU; the wave's units inside it: w, w + 16, ...
+            const uint64_t r = (uint64_t)blockIdx.x + i * gridDim.x;
+            if ((r + 1) * 16 > n_chunks) return base + (uint64_t)lane * 16u;
+            return base + r * 16u * chunk + (u * 16u + wave) * 1024u + lane * 16u;
+        } else {
+            c = gw + i * n_waves;
+        }
+        if (c >= n_chunks) return base + (uint64_t)lane * 16u;
+        if (MODE == 2) { // units: line-major, 8 loads of 8 rows each per 128-byte line
+            const uint32_t j = (uint32_t)u & 7u, line = (uint32_t)u >> 3;
+            return base + c * chunk + (uint64_t)((lane >> 3) + 8u * j) * stride + line * 128u + (lane & 7u) * 16u;
+        }
+        if (MODE == 4) u = (u + 5u * wave) & (units - 1u);
+        return base + c * chunk + u * 1024u + lane * 16u;
+    };
+    uint64_t my_units;
+    if (MODE == 3) my_units = per * units;
+    else if (MODE == 1) my_units = ((n_chunks / 16 + gridDim.x - 1) / gridDim.x) * units;
+    else my_units = ((n_chunks + n_waves - 1) / n_waves) * units;
+    u32x4 R[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) R[k] = *(const u32x4 *)addr((uint64_t)k);
+    for (uint64_t t = 0; t < my_units; t += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const u32x4 v = R[k];
+            asm volatile("" ::: "memory");
+            R[k] = *(const u32x4 *)addr(t + PF + k);
+            acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PF; ++k) acc ^= R[k][0];
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int PF, int MODE>
+static void run(const char *name, const uint8_t *d, uint64_t total, uint32_t chunk, uint32_t stride, uint32_t *d_sink, size_t lds) {
+    auto k = stream_kernel<PF, MODE>;
+    hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k, dim3(256), dim3(1024), lds, 0, d, total, chunk, stride, d_sink);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    hipError_t e = hipGetLastError();
+    printf("%-16s PF %d chunk %6u LDS %6zu: %.3f ms = %.2f TB/s%s\n", name, PF, chunk, lds, best, (double)total / best * 1e-9, e == hipSuccess ? "" : " (ERROR)");
+}
+
+int main() {
+    const uint64_t total = 10000000ull * 256ull / 16384ull * 16384ull; // whole 16 KiB chunks of the bench batch (10^7 rows of 256 bytes)
+    uint8_t *d;
+    uint32_t *d_sink;
+    if (hipMalloc(&d, total + 65536) != hipSuccess) return 1;
+    hipMalloc(&d_sink, 64);
+    hipMemset(d, 1, total + 65536);
+    for (size_t lds : {(size_t)0, (size_t)160 * 1024}) {
+        run<4, 0>("filter-like", d, total, 16384, 256, d_sink, lds);
+        run<8, 0>("filter-like", d, total, 16384, 256, d_sink, lds);
+        run<4, 0>("filter-like", d, total, 65536, 256, d_sink, lds);
+        run<4, 1>("cu-interleaved", d, total, 16384, 256, d_sink, lds);
+        run<8, 1>("cu-interleaved", d, total, 16384, 256, d_sink, lds);
+        run<4, 2>("scan-like", d, total, 16384, 256, d_sink, lds);
+        run<8, 2>("scan-like", d, total, 16384, 256, d_sink, lds);
+        run<4, 3>("wave-major", d, total, 16384, 256, d_sink, lds);
+        run<8, 3>("wave-major", d, total, 16384, 256, d_sink, lds);
+        run<4, 4>("filter-rotated", d, total, 16384, 256, d_sink, lds);
+        run<8, 4>("filter-rotated", d, total, 16384, 256, d_sink, lds);
+    }
+    return 0;
+}

@@ -127,7 +127,7 @@ def run_window(au, text, qn, K, S, fixed_len, contained):
 
 def filtered(p, op, text, all_windows=False, info=None, phase=0):
     """(found, start, end) of one row by the filter algorithm; all_windows: every sampled window counts as a candidate.  phase: the sampled
-    window ends are = phase (mod S) -- the kernel samples group-relative offsets, which for S = 3 is a different phase in every row."""
+    window ends are = phase (mod S) (the kernel's are multiples of S; the algorithm does not depend on it)."""
     info = info or p.prefilter_info("contained_in" if op == "contained_in" else "forwards", with_bitmap=True)
     assert info["on"], info
     au, fixed = from_pattern(p, op)

@@ -15,8 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
-    """C3-sparse (1000 keywords of 6..8 chars, the compressed automaton): stride 3 (round 6; 2 before), run-up 8 = max_len, ~3000
-    windows, the TWO-SIDED second level (shortest match 6 = 5 + 3 - 2)."""
+    """C3-sparse (1000 keywords of 6..8 chars, the compressed automaton): stride 2, run-up 8 = max_len, ~2000 windows."""
     from needle_amd import workload as W
     from needle_amd.pattern import DFACompiler
     from test_compile_matches_txt import oracle_for
@@ -27,9 +26,9 @@ def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
     o, _ = oracle_for(rx, 0)
     for which in ("contained_in", "forwards"):
         i = p.prefilter_info(which)
-        assert i["on"] == 1 and i["mode"] == 6 and i["stride"] == 3 and i["warm"] == 8 and i["min_len"] == 6, i
-        assert 2500 <= i["n_windows"] <= 3000 and i["bitmap_bytes"] == 32768, i
-        assert i["on2"] == 2 and 1500 <= i["n_windows2"] <= 2100 and i["bitmap2_bytes"] == 8192, i  # the second level: 5-byte windows, two-sided
+        assert i["on"] == 1 and i["mode"] == 6 and i["stride"] == 2 and i["warm"] == 8 and i["min_len"] == 6, i
+        assert 1500 <= i["n_windows"] <= 2000 and i["bitmap_bytes"] == 32768, i
+        assert i["on2"] == 1 and 1500 <= i["n_windows2"] <= 2100 and i["bitmap2_bytes"] == 8192, i  # the second level: 5-byte windows
     rows = W.keyword_batch(np, words, 11, 72, 256)
     rows[::7, 256 - len(words[3]):] = [ord(c) for c in words[3]]        # a keyword that ends with the row
     rows[3::7, 256 - len(words[4]) + 1:] = [ord(c) for c in words[4]][:-1]  # ... and one the row's end cuts
@@ -41,7 +40,7 @@ def test_bench_dictionary_gets_a_filter_and_it_is_exact(oracle_lib):
     for k, row in enumerate(rows):
         for text in (row, row[:lens[k]]):
             want = o.find_all(text)[:1]
-            for phase in range(fi["stride"]):  # (the kernel's windows end at GROUP-relative multiples of 3: any phase inside a row)
+            for phase in range(fi["stride"]):  # (whatever phase the sampled window ends have inside a row)
                 got = sim.filtered(p, "find", text, info=fi, phase=phase)
                 assert got == ((True,) + want[0] if want else (False, -1, -1)), (k, len(text), phase, got, want)
                 assert sim.filtered(p, "contained_in", text, info=ci, phase=phase)[0] == bool(want)
@@ -74,6 +73,7 @@ rng = np.random.default_rng(5)
 # (regex, filter expected for find, for containedIn)
 CASES = [("Sherlock|Holmes|Watson|Irene|Adler|John|Baker", False, False),   # min_len 4 < 5: no stride fits
          ("Sherlock|Holmes|Watson|Moriarty|Mycroft", True, True),
+         ("Sherlock|Holmes|Watson|Irene|Adler|Baker", True, True),           # min_len 5: stride 2 with the TWO-SIDED second level (round 6)
          ("abcdef|bcdefgh|cdefghij|xabcde", True, True),                     # keywords inside / overlapping one another
          ("[Ss]herlock|[Hh]olmes(es)?", True, True),
          ("(foo|foobar|bar|barbaz|baz)quux", True, True),
@@ -83,6 +83,7 @@ CASES = [("Sherlock|Holmes|Watson|Irene|Adler|John|Baker", False, False),   # mi
          ("a[0-9]+bcdefg", None, None),                                       # unbounded: whatever the analysis says must be exact
          ("abcde.{0,3}fghij", None, None)]
 n_on = 0
+two_sided = set()
 for rx, want_f, want_c in CASES:
     p = DFACompiler.compile(rx, "t", 0)
     o, _ = oracle_for(rx, 0)
@@ -95,6 +96,8 @@ for rx, want_f, want_c in CASES:
         assert fi["why"] and ci["why"]
         continue
     n_on += 1
+    if fi["on"] and fi["on2"] == 2:
+        two_sided.add((fi["stride"], fi["min_len"]))
     # texts built from pieces of the regex's own literals, so that near misses, overlaps and matches at both row ends are common
     lits = [w for w in rx.replace("(", "|").replace(")", "|").replace("?", "|").replace("[", "|").replace("]", "|").split("|") if w.isalnum()]
     for trial in range(100):
@@ -116,7 +119,8 @@ for rx, want_f, want_c in CASES:
             assert sim.filtered(p, "find", text, all_windows=True, info=fi, phase=ph) == exp, (rx, bytes(text), exp)
         if ci["on"]:
             assert sim.filtered(p, "contained_in", text, info=ci, phase=ph)[0] == bool(want), (rx, bytes(text))
-assert n_on >= 7, n_on
+assert n_on >= 8, n_on
+assert (2, 5) in two_sided and (4, 7) in two_sided, two_sided  # shortest match 5 -> stride 2, 7 -> stride 4: both with the two-sided second level
 # find-all behind the filter: a candidate's run that CROSSES an earlier accept and lives on (the search automaton keeps the
 # higher-priority longer alternative and drops the restart threads) says nothing about its window -- filed as unknown, re-run
 # from the row's cursor (ADVICE r4: `international|inter|nation` on "internationa..": "nation" was lost)
