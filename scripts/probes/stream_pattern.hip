@@ -7,6 +7,7 @@
 //      to right (needle_scan.h)
 //   3  wave-major: a wave owns one long contiguous range of the buffer (4096 streams spread over all of it)
 //   4  like 0, the waves of a CU rotated: wave w starts its chunk at unit (5 w) mod units and wraps
+//   5  like 0, but a wave takes its NEXT chunk from a global counter (atomicAdd) when it starts one: XCDs / CUs that get more bandwidth take more chunks
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/stream_pattern scripts/probes/stream_pattern.hip && /tmp/stream_pattern
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,6 +69,79 @@ __global__ __launch_bounds__(1024) void stream_kernel(const uint8_t *base, uint6
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+template <int PF>
+__global__ __launch_bounds__(1024) void stream_dynamic(const uint8_t *base, uint64_t total, uint32_t chunk, uint32_t *sink, uint32_t *counter) {
+    extern __shared__ uint8_t smem[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t units = chunk >> 10;
+    const uint32_t n_chunks = (uint32_t)(total / chunk);
+    uint32_t acc = 0;
+    if (smem[threadIdx.x & 15] == 77) acc = 1;
+    auto grab = [&]() -> uint32_t {
+        uint32_t n = 0;
+        if (lane == 0) n = atomicAdd(counter, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+    };
+    uint32_t c = grab(), c_next = grab();
+    // the cursor (what is loaded next) runs PF units ahead of what is consumed
+    uint32_t lc = c, lu = 0; // cursor: chunk, unit
+    uint32_t ln = c_next;    // the chunk the cursor enters after lc
+    auto next_addr = [&]() -> const uint8_t * {
+        const uint8_t *p = lc < n_chunks ? base + (uint64_t)lc * chunk + (uint64_t)lu * 1024u + lane * 16u : base + (uint64_t)lane * 16u;
+        if (++lu == units) {
+            lu = 0;
+            lc = ln;
+            ln = lc < n_chunks ? grab() : lc;
+        }
+        return p;
+    };
+    u32x4 R[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) R[k] = *(const u32x4 *)next_addr();
+    uint32_t cu = 0; // consumed units of chunk c
+    while (c < n_chunks) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const u32x4 v = R[k];
+            asm volatile("" ::: "memory");
+            R[k] = *(const u32x4 *)next_addr();
+            acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+        }
+        cu += PF;
+        if (cu == units) {
+            cu = 0;
+            c = c_next;       // (the consumer follows the cursor's sequence: c_next was grabbed when c began)
+            c_next = lc == c ? ln : lc; // the chunk after: what the cursor holds
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int PF>
+static void run_dynamic(const uint8_t *d, uint64_t total, uint32_t chunk, uint32_t *d_sink, size_t lds) {
+    auto k = stream_dynamic<PF>;
+    hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    uint32_t *d_ctr;
+    hipMalloc(&d_ctr, 64);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipMemsetAsync(d_ctr, 0, 64, 0);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k, dim3(256), dim3(1024), lds, 0, d, total, chunk, d_sink, d_ctr);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    hipError_t e = hipGetLastError();
+    printf("%-16s PF %d chunk %6u LDS %6zu: %.3f ms = %.2f TB/s%s\n", "dynamic", PF, chunk, lds, best, (double)total / best * 1e-9, e == hipSuccess ? "" : " (ERROR)");
+    hipFree(d_ctr);
+}
+
 template <int PF, int MODE>
 static void run(const char *name, const uint8_t *d, uint64_t total, uint32_t chunk, uint32_t stride, uint32_t *d_sink, size_t lds) {
     auto k = stream_kernel<PF, MODE>;
@@ -108,6 +182,9 @@ int main() {
         run<8, 3>("wave-major", d, total, 16384, 256, d_sink, lds);
         run<4, 4>("filter-rotated", d, total, 16384, 256, d_sink, lds);
         run<8, 4>("filter-rotated", d, total, 16384, 256, d_sink, lds);
+        run_dynamic<4>(d, total, 16384, d_sink, lds);
+        run_dynamic<8>(d, total, 16384, d_sink, lds);
+        run_dynamic<4>(d, total, 65536, d_sink, lds);
     }
     return 0;
 }
