@@ -7,7 +7,8 @@ n = 2_560_000_000 // stride
 p = DFACompiler.compile(rx, "d")
 rows = torch.randint(97, 123, (n, stride), dtype=torch.uint8, device="cuda")
 rows[::3, stride // 2] = 53
-for op, name in ((p.contained_in_batch, "containedIn"), (p.find_batch, "find"), (p.find_packed16_batch, "find (one dword per row)")):
+for op, name in ((p.contained_in_batch, "containedIn"), (p.find_batch, "find"), (p.find_packed16_batch, "find (one dword per row)"),
+                 (p.find_packed8_batch, "find (one uint16 per row)")):  # round 6: needle_find_packed8_dev
     for _ in range(2): r = op(rows)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
