@@ -335,3 +335,42 @@ def test_c3s_find_all_behind_the_filter_full_size(workload):
             assert got == o.find_all(host[i]), idx[i]
         total += len(got)
     assert total > 800
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c3m16", "c3u"])
+def test_round6_filter_forms_full_size(workload):
+    """Round 6's filter forms at 10^7 rows -- c3m16: the WIDE filter (1000 Latin + 1000 Cyrillic + 1000 CJK keywords over mixed-script UTF-16
+    rows); c3u: `(1000 keywords)[0-9]+`, find() of a pattern without bounded match lengths behind the filter (stride 4, the two-sided second
+    level, starts by backward walks).  find() and containedIn() behind the filter against (1) the SAME calls with the filter switched off
+    (needle_pattern_set_prefilter: the ordinary scan kernels, another code path) on ALL rows, (2) the oracle on rows sampled over the whole
+    batch, (3) two unequal shards joined; the 2-byte and 4-byte result forms against the two arrays."""
+    import torch
+    from needle_amd.pattern import Pattern, unpack_bitmap
+    p, rows, words = make(workload)
+    n = rows.shape[0]
+    fw, fs, fe = p.find_batch(rows)
+    cw = p.contained_in_batch(rows)
+    torch.cuda.synchronize()
+    assert torch.equal(fw, cw)
+    f_bits = unpack_bitmap(fw, n)
+    assert 0.05 < f_bits.mean() < 0.6
+    check_sample_against_oracle(p, rows, f_bits, fs.cpu().numpy(), fe.cpu().numpy(), unpack_bitmap(cw, n))
+    partition_invariant(p.find_batch, rows, fw)
+    w16, se16 = p.find_packed16_batch(rows)
+    sev = se16.cpu().numpy().view(np.uint32)
+    s_np, e_np = fs.cpu().numpy(), fe.cpu().numpy()
+    assert torch.equal(w16, fw) and ((sev == 0xFFFFFFFF) == ~f_bits).all()
+    assert ((sev & 0xFFFF)[f_bits] == s_np[f_bits]).all() and ((sev >> 16)[f_bits] == e_np[f_bits]).all()
+    w8, se8 = p.find_packed8_batch(rows)
+    s8, e8 = Pattern.unpack8(se8.cpu().numpy())
+    assert torch.equal(w8, fw) and (s8 == s_np).all() and (e8 == e_np).all()
+    # the same calls without the filter: every row
+    p.set_prefilter(p.PREFILTER_OFF)
+    try:
+        gw, gs, ge = p.find_batch(rows)
+        gc = p.contained_in_batch(rows)
+        torch.cuda.synchronize()
+    finally:
+        p.set_prefilter(p.PREFILTER_AUTO)
+    assert torch.equal(gw, fw) and torch.equal(gc, cw) and torch.equal(gs, fs) and torch.equal(ge, fe)
