@@ -171,3 +171,41 @@ def test_prefilter_levels_match_oracle(level):
         env["NEEDLE_PAIR_MAX_BYTES"] = "0"  # (the small automata as plain uint8 tables: the pair table has no filter kernel)
     r = subprocess.run([sys.executable, "-c", CODE, str(level)], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert "PREFILTER-GPU-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_len", [5, 7])
+def test_two_sided_second_level_at_row_and_batch_ends(min_len):
+    """The two-sided second level (NgramParams::on2 == 2: shortest match 5 -> stride 2, 7 -> stride 4) asks for the 5 chars ending one char
+    BEHIND a candidate's window: at a row's last char there is none (the next row's first char, or -- the batch's last row -- nothing at all:
+    the read stays inside the batch).  Keywords planted at the very end of rows, of the LAST rows of full and partial 64-row groups, cut by
+    one char, and at the rows' starts; full rows and ragged ones; against the oracle on every row."""
+    import numpy as np
+    import torch
+    from needle_amd import workload as W
+    from needle_amd.pattern import unpack_bitmap
+    from test_gpu_configs import compiled
+    words = W.keywords(1000, min_len=min_len, max_len=min_len + 3)  # (big enough for the compressed automaton: the filter's default territory)
+    p, o = compiled("|".join(words))
+    i = p.prefilter_info("forwards")
+    assert i["on"] == 1 and i["on2"] == 2 and i["stride"] == (2 if min_len == 5 else 4) and i["min_len"] == min_len, i
+    enc = [np.frombuffer(w.encode(), dtype=np.uint8) for w in words]
+    for width in (64, 256, 320):
+        for n in (64 * 300, 64 * 300 + 1, 70_000 + 37):
+            host = W.keyword_batch(np, words, 3, n, width).copy()
+            for j, r in enumerate(range(n - 1, max(n - 200, -1), -1)):
+                w = enc[j % len(enc)]
+                if j % 4 == 0: host[r, width - len(w):] = w                      # ends with the row
+                elif j % 4 == 1: host[r, width - len(w) + 1:] = w[:-1]            # cut by the row's end
+                elif j % 4 == 2: host[r, :len(w)] = w                             # at the row's start
+                else: host[r, width - len(w) - 1:width - 1] = w                   # one char in front of the end
+            for lens in (None, ((np.arange(n, dtype=np.uint64) * 2654435761) % (width + 1)).astype(np.uint32)):
+                rows = torch.from_numpy(host).cuda()
+                tl = None if lens is None else torch.from_numpy(lens.astype(np.int32)).cuda()
+                fw, fs, fe = p.find_batch(rows, tl)
+                cw = p.contained_in_batch(rows, tl)
+                torch.cuda.synchronize()
+                m, os_, oe = o.batch_find(host, lens, threads=8)
+                assert (unpack_bitmap(fw, n) == m).all() and (unpack_bitmap(cw, n) == m).all(), (min_len, width, n, lens is None)
+                assert (fs.cpu().numpy() == os_).all() and (fe.cpu().numpy() == oe).all(), (min_len, width, n, lens is None)
+                assert m[-200:].sum() >= 50 or lens is not None
