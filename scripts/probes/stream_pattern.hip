@@ -69,6 +69,38 @@ __global__ __launch_bounds__(1024) void stream_kernel(const uint8_t *base, uint6
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// when do the XCDs finish?  (block b runs on XCD b % 8: the dispatcher deals workgroups round-robin)  The filter-like pattern, every wave's
+// finish time (s_memtime since its start) written out: mean by XCD
+template <int PF>
+__global__ __launch_bounds__(1024) void stream_timed(const uint8_t *base, uint64_t total, uint32_t chunk, uint32_t *sink, uint64_t *finish) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 16, gw = (uint64_t)blockIdx.x * 16 + wave;
+    const uint32_t units = chunk >> 10;
+    const uint64_t n_chunks = total / chunk;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    uint32_t acc = 0;
+    for (uint64_t c = gw; c < n_chunks; c += n_waves) {
+        const uint8_t *p = base + c * chunk + lane * 16u;
+        u32x4 R[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) R[k] = *(const u32x4 *)(p + (uint64_t)k * 1024u);
+        for (uint32_t u = 0; u < units; u += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const u32x4 v = R[k];
+                asm volatile("" ::: "memory");
+                const uint32_t nu = u + PF + k < units ? u + PF + k : k;
+                R[k] = *(const u32x4 *)(p + (uint64_t)nu * 1024u);
+                acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) acc ^= R[k][0];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+    if (lane == 0) finish[gw] = __builtin_amdgcn_s_memtime() - t0;
+}
+
 template <int PF>
 __global__ __launch_bounds__(1024) void stream_dynamic(const uint8_t *base, uint64_t total, uint32_t chunk, uint32_t *sink, uint32_t *counter) {
     extern __shared__ uint8_t smem[];
@@ -163,6 +195,99 @@ static void run(const char *name, const uint8_t *d, uint64_t total, uint32_t chu
     printf("%-16s PF %d chunk %6u LDS %6zu: %.3f ms = %.2f TB/s%s\n", name, PF, chunk, lds, best, (double)total / best * 1e-9, e == hipSuccess ? "" : " (ERROR)");
 }
 
+// the same stream with an UNEVEN static split: block b streams the contiguous chunk range [range[b], range[b + 1]), its 16 waves interleaved
+// inside it -- ranges proportional to per-XCD weights (block b on XCD b % 8)
+template <int PF>
+__global__ __launch_bounds__(1024) void stream_ranges(const uint8_t *base, uint32_t chunk, const uint32_t *range, uint32_t *sink, uint64_t *finish) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t units = chunk >> 10;
+    const uint32_t c0 = range[blockIdx.x], c1 = range[blockIdx.x + 1];
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    uint32_t acc = 0;
+    for (uint32_t c = c0 + wave; c < c1; c += 16) {
+        const uint8_t *p = base + (uint64_t)c * chunk + lane * 16u;
+        u32x4 R[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) R[k] = *(const u32x4 *)(p + (uint64_t)k * 1024u);
+        for (uint32_t u = 0; u < units; u += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const u32x4 v = R[k];
+                asm volatile("" ::: "memory");
+                const uint32_t nu = u + PF + k < units ? u + PF + k : k;
+                R[k] = *(const u32x4 *)(p + (uint64_t)nu * 1024u);
+                acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) acc ^= R[k][0];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+    if (lane == 0) finish[(uint64_t)blockIdx.x * 16 + wave] = __builtin_amdgcn_s_memtime() - t0;
+}
+
+static void run_ranges(const uint8_t *d, uint64_t total, uint32_t *d_sink, const double (&w)[8], const char *tag) {
+    const uint32_t chunk = 16384, n_chunks = (uint32_t)(total / chunk);
+    std::vector<uint32_t> range(257, 0);
+    double sum = 0;
+    for (int b = 0; b < 256; ++b) sum += w[b % 8];
+    double accw = 0;
+    for (int b = 0; b < 256; ++b) {
+        accw += w[b % 8];
+        range[b + 1] = (uint32_t)((double)n_chunks * accw / sum);
+    }
+    range[256] = n_chunks;
+    uint32_t *d_range;
+    uint64_t *d_fin;
+    hipMalloc(&d_range, 257 * 4);
+    hipMalloc(&d_fin, 4096 * 8);
+    hipMemcpy(d_range, range.data(), 257 * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(stream_ranges<4>, dim3(256), dim3(1024), 0, 0, d, chunk, d_range, d_sink, d_fin);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    std::vector<uint64_t> h(4096);
+    hipMemcpy(h.data(), d_fin, 4096 * 8, hipMemcpyDeviceToHost);
+    double xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx = 0;
+    for (int i = 0; i < 4096; ++i) {
+        xcd[(i / 16) % 8] += (double)h[i];
+        if ((double)h[i] > mx) mx = (double)h[i];
+    }
+    printf("ranges %-22s: %.3f ms = %.2f TB/s; finish max %.0f, by XCD:", tag, best, (double)total / best * 1e-9, mx);
+    for (int k = 0; k < 8; ++k) printf(" %.0f", xcd[k] / 512);
+    printf("\n");
+    hipFree(d_range);
+    hipFree(d_fin);
+}
+
+static void run_timed(const uint8_t *d, uint64_t total, uint32_t *d_sink) {
+    uint64_t *d_fin;
+    hipMalloc(&d_fin, 4096 * 8);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(stream_timed<4>, dim3(256), dim3(1024), 0, 0, d, total, 16384u, d_sink, d_fin);
+    hipDeviceSynchronize();
+    std::vector<uint64_t> h(4096);
+    hipMemcpy(h.data(), d_fin, 4096 * 8, hipMemcpyDeviceToHost);
+    double xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx = 0, mean = 0;
+    for (int w = 0; w < 4096; ++w) {
+        xcd[(w / 16) % 8] += (double)h[w];
+        mean += (double)h[w];
+        if ((double)h[w] > mx) mx = (double)h[w];
+    }
+    printf("filter-like, wave finish times (cycles): mean %.0f max %.0f; by XCD:", mean / 4096, mx);
+    for (int k = 0; k < 8; ++k) printf(" %.0f", xcd[k] / 512);
+    printf("\n");
+    hipFree(d_fin);
+}
+
 int main() {
     const uint64_t total = 10000000ull * 256ull / 16384ull * 16384ull; // whole 16 KiB chunks of the bench batch (10^7 rows of 256 bytes)
     uint8_t *d;
@@ -170,6 +295,19 @@ int main() {
     if (hipMalloc(&d, total + 65536) != hipSuccess) return 1;
     hipMalloc(&d_sink, 64);
     hipMemset(d, 1, total + 65536);
+    run_timed(d, total, d_sink);
+    {
+        const double even[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        run_ranges(d, total, d_sink, even, "equal shares");
+        const double w90[8] = {1, 0.93, 1, 0.93, 1, 0.93, 1, 0.93};
+        run_ranges(d, total, d_sink, w90, "odd XCDs 0.93");
+        const double w87[8] = {1, 0.87, 1, 0.87, 1, 0.87, 1, 0.87};
+        run_ranges(d, total, d_sink, w87, "odd XCDs 0.87");
+        const double w80[8] = {1, 0.80, 1, 0.80, 1, 0.80, 1, 0.80};
+        run_ranges(d, total, d_sink, w80, "odd XCDs 0.80");
+        const double inv[8] = {0.87, 1, 0.87, 1, 0.87, 1, 0.87, 1};
+        run_ranges(d, total, d_sink, inv, "EVEN XCDs 0.87");
+    }
     for (size_t lds : {(size_t)0, (size_t)160 * 1024}) {
         run<4, 0>("filter-like", d, total, 16384, 256, d_sink, lds);
         run<8, 0>("filter-like", d, total, 16384, 256, d_sink, lds);
